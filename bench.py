@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""Headline benchmark: log_prob samples/sec of a 32-layer RQ-NSF coupling flow (D=64, K=8)
+on synthetic Gaussian batches, one process per GPU, batch-sharded (BASELINE.json cfg 3/4).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one ``Flow.log_prob`` pass of every rank's 2^20-sample shard through all 32
+layers (conditioners on PyTorch-ROCm, bijectors in the HIP kernels) + the RCCL all-reduce of
+{sum log_prob, count}.  Inputs are resident in HBM before the timed region.  Prints ONE JSON
+line on rank 0 (contract in the task statement), carrying ``roofline`` for the dominant kernel
+(fc_rq_spline) and ``cpu_baseline`` (the CPU oracle timed on the host cores, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import flowconductor_amd  # noqa: E402,F401
+from flowconductor_amd import distributions, flows, ops, transforms, utils  # noqa: E402
+from flowconductor_amd.nn import nets  # noqa: E402
+
+FEATURES, LAYERS, BINS, HIDDEN, BLOCKS, TAIL_BOUND = 64, 32, 8, 64, 2, 3.0
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_flow():
+    """BASELINE.json cfg 3: 32 x PiecewiseRationalQuadraticCouplingTransform,
+    alternating masks, ResidualNet(hidden 64, 2 blocks) conditioners, linear tails at 3."""
+    torch.manual_seed(0)
+    layers = []
+    for l in range(LAYERS):
+        layers.append(transforms.PiecewiseRationalQuadraticCouplingTransform(
+            utils.create_alternating_binary_mask(FEATURES, even=(l % 2 == 0)),
+            lambda i, o: nets.ResidualNet(i, o, hidden_features=HIDDEN, num_blocks=BLOCKS),
+            num_bins=BINS, tails="linear", tail_bound=TAIL_BOUND))
+    return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([FEATURES])).eval()
+
+
+def algorithmic_bytes_per_sample_layer():
+    """B = 4*d_t*(P + 2) + 8: params + x_t + y_t + logabsdet r/w."""
+    d_t = FEATURES // 2
+    p = 3 * BINS - 1
+    return 4 * d_t * (p + 2) + 8
+
+
+def cpu_baseline(flow_cpu, sample, chunk):
+    """Time the CPU oracle (torch-CPU restatement of the reference's op sequence) on host cores."""
+    from oracle import torch_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(99)
+    x = torch.randn(sample, FEATURES, generator=gen)
+    with torch.no_grad():
+        O.flow_log_prob(flow_cpu, x[: min(chunk, 1024)].clone())  # warm-up
+        t0 = time.perf_counter()
+        for i in range(0, sample, chunk):
+            O.flow_log_prob(flow_cpu, x[i:i + chunk].clone())
+        dt = time.perf_counter() - t0
+    return {"value": sample / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d samples in chunks of %d through the 32-layer flow, %.1f s" % (sample, chunk, dt)}
+
+
+def parity(flow, flow_cpu, device, rows=2048):
+    """max |delta logabsdet| and max relative sample error, GPU vs CPU oracle, same weights/inputs."""
+    from oracle import torch_oracle as O
+
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(rows, FEATURES, generator=gen)
+    with torch.no_grad():
+        z_ref, lad_ref = O.transform_apply(flow_cpu._transform, x.clone())
+        z, lad = flow._transform(x.to(device))
+    dz = (z.cpu() - z_ref).abs()
+    return {"max_abs_dlogabsdet": float((lad.cpu() - lad_ref).abs().max()),
+            "max_rel_dlogabsdet": float(((lad.cpu() - lad_ref).abs() / lad_ref.abs().clamp_min(1.0)).max()),
+            "max_rel_dsamples": float((dz / z_ref.abs().clamp_min(1.0)).max()), "rows": rows}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-log2", type=int, default=20, help="log2 samples per GPU")
+    ap.add_argument("--chunk-log2", type=int, default=0, help="log2 rows per pass through the stack (0 = whole shard)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log2", type=int, default=15)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from flowconductor_amd import parallel
+
+    flow = build_flow().to(device)
+    n_local = 1 << args.batch_log2
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.randn(n_local, FEATURES, device=device, generator=gen)
+    chunk = (1 << args.chunk_log2) if args.chunk_log2 else None
+
+    def step():
+        with torch.no_grad():
+            return parallel.sharded_log_prob_mean(flow.log_prob, x, chunk=chunk, group=None if world == 1 else dist.group.WORLD)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    timer = ops.KernelTimer("fc_rq_spline")
+    t0 = time.perf_counter()
+    with timer:
+        for _ in range(args.steps):
+            mean_lp = step()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total = n_local * world * args.steps
+        kernel_ms = timer.durations_ms()
+        launches = len(kernel_ms)
+        avg_ms = sum(kernel_ms) / max(launches, 1)
+        rows_per_launch = n_local if chunk is None else min(chunk, n_local)
+        alg_bytes = algorithmic_bytes_per_sample_layer() * rows_per_launch
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        out = {
+            "metric": "log_prob samples/sec, 32xRQ-NSF coupling D=64 K=8",
+            "value": total / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic N(0,I) inputs generated on device; default-init weights under manual_seed(0)",
+            "config": {"workload": "BASELINE.json configs[2]: 32-layer RQ-NSF coupling flow log_prob, "
+                                   "D=64, K=8 bins, linear tails, ResidualNet(64, 2 blocks) conditioners",
+                       "samples_per_gpu": n_local, "global_batch": n_local * world,
+                       "chunk_rows": rows_per_launch, "parallelism": "batch-sharded dp%d" % world,
+                       "mean_log_prob": mean_lp},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "fc_rq_spline (tile_kernel<RQOp<8>>)", "launches_timed": launches,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "bijector_share_of_step": sum(kernel_ms) / (1e3 * elapsed) if elapsed else None},
+        }
+        if world == 1:
+            flow_cpu = build_flow()
+            out["parity"] = parity(flow, flow_cpu, device)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(flow_cpu, 1 << args.cpu_sample_log2, 1 << 14)
+                out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

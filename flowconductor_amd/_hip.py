@@ -1,0 +1,125 @@
+"""ctypes binding of ``libflowcon_hip.so`` (the C ABI declared in ``include/flowcon_hip.h``).
+
+This is the only place the package touches native code.  There is NO CPU or eager-PyTorch
+fallback: if the library is missing, or a tensor is not a contiguous float32 HIP tensor, the
+call raises.  PyTorch is used for device memory and streams only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libflowcon_hip.so")
+
+ABI_VERSION = 1
+
+ERR_OUTSIDE_DOMAIN = 1
+ERR_DISCRIMINANT = 2
+ERR_NONFINITE = 4
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class RQConfig(ctypes.Structure):
+    """Mirror of ``fc_rq_config``."""
+
+    _fields_ = [
+        ("num_bins", ctypes.c_int32),
+        ("tails", ctypes.c_int32),
+        ("inverse", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("left", ctypes.c_float),
+        ("right", ctypes.c_float),
+        ("bottom", ctypes.c_float),
+        ("top", ctypes.c_float),
+        ("min_bin_width", ctypes.c_double),
+        ("min_bin_height", ctypes.c_double),
+        ("min_derivative", ctypes.c_double),
+        ("wh_divisor", ctypes.c_float),
+        ("softplus_beta", ctypes.c_float),
+        ("tail_constant", ctypes.c_float),
+        ("reserved2", ctypes.c_float),
+    ]
+
+
+_P = ctypes.c_void_p
+_I32 = ctypes.c_int32
+_I64 = ctypes.c_int64
+_F = ctypes.c_float
+
+# name -> argtypes; every symbol here must be declared in include/flowcon_hip.h (tests check)
+SIGNATURES = {
+    "fc_abi_version": [],
+    "fc_rq_spline": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32,
+                     ctypes.POINTER(RQConfig), _P],
+    "fc_standard_normal_log_prob": [_P, _P, _P, _I64, _I32, _F, _P],
+    "fc_permute": [_P, _P, _P, _I64, _I32, _I64, _P],
+    "fc_pointwise_affine": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],
+    "fc_affine": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises HipLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            "flowconductor_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C flowconductor_amd/csrc`. There is no CPU fallback." % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    got = lib.fc_abi_version()
+    if got != ABI_VERSION:
+        raise HipLibraryMissing("libflowcon_hip.so ABI %d != expected %d: rebuild" % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def is_built():
+    return os.path.exists(LIB_PATH)
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError("flowconductor_amd: %s failed with hipError %d" % (what, code))
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def dev_f32(t, name):
+    """Validate a tensor for the kernels: float32, on a HIP device, contiguous."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError(
+            "flowconductor_amd: %s lives on %s; the bijector kernels run on a HIP device only "
+            "(no CPU fallback)" % (name, t.device)
+        )
+    if t.dtype != torch.float32:
+        raise TypeError("flowconductor_amd: %s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def require_no_grad(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise RuntimeError(
+            "flowconductor_amd: the HIP bijector kernels implement forward/inverse/logabsdet only; "
+            "autograd through them is not available yet. Wrap the call in torch.no_grad()."
+        )

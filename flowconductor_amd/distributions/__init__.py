@@ -1,0 +1,2 @@
+from flowconductor_amd.distributions.base import Distribution, NoMeanException  # noqa: F401
+from flowconductor_amd.distributions.normal import StandardNormal  # noqa: F401

@@ -1,0 +1,72 @@
+"""Residual MLP conditioner (stays on PyTorch-ROCm; boundary only).
+
+Same constructor arguments, attribute names and ``state_dict`` keys as the reference's
+flowcon/nn/nets/resnet.py:9-100 (``initial_layer``, ``blocks.N.linear_layers.M``,
+``blocks.N.context_layer``, ``final_layer``, attribute ``hidden_features`` that the spline
+coupling layers look for), and the same parameter construction order so that a given
+``torch.manual_seed`` yields the same default initialisation.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+class ResidualBlock(nn.Module):
+    """pre-activation block: x + W1 drop(act(bn(W0 act(bn(x))))) with an optional GLU gate on context."""
+
+    def __init__(self, features, context_features, activation=torch.nn.ReLU(),
+                 dropout_probability=0.0, use_batch_norm=False, zero_initialization=True):
+        super().__init__()
+        self.activation = activation
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList(nn.BatchNorm1d(features, eps=1e-3) for _ in range(2))
+        if context_features is not None:
+            self.context_layer = nn.Linear(context_features, features)
+        self.linear_layers = nn.ModuleList(nn.Linear(features, features) for _ in range(2))
+        self.dropout = nn.Dropout(p=dropout_probability)
+        if zero_initialization:
+            last = self.linear_layers[-1]
+            nn.init.uniform_(last.weight, -1e-3, 1e-3)
+            nn.init.uniform_(last.bias, -1e-3, 1e-3)
+
+    def forward(self, inputs, context=None):
+        h = inputs
+        for i in range(2):
+            if self.use_batch_norm:
+                h = self.batch_norm_layers[i](h)
+            h = self.activation(h)
+            if i == 1:
+                h = self.dropout(h)
+            h = self.linear_layers[i](h)
+        if context is not None:
+            h = F.glu(torch.cat((h, self.context_layer(context)), dim=1), dim=1)
+        return inputs + h
+
+
+class ResidualNet(nn.Module):
+    """Linear -> num_blocks x ResidualBlock -> Linear, for 1-dim feature vectors."""
+
+    def __init__(self, in_features, out_features, hidden_features, context_features=None,
+                 num_blocks=2, activation=torch.nn.ReLU(), dropout_probability=0.0,
+                 use_batch_norm=False):
+        super().__init__()
+        self.hidden_features = hidden_features
+        self.context_features = context_features
+        first_in = in_features if context_features is None else in_features + context_features
+        self.initial_layer = nn.Linear(first_in, hidden_features)
+        self.blocks = nn.ModuleList(
+            ResidualBlock(features=hidden_features, context_features=context_features,
+                          activation=activation, dropout_probability=dropout_probability,
+                          use_batch_norm=use_batch_norm)
+            for _ in range(num_blocks)
+        )
+        self.final_layer = nn.Linear(hidden_features, out_features)
+
+    def forward(self, inputs, context=None):
+        if context is not None:
+            inputs = torch.cat((inputs, context), dim=1)
+        h = self.initial_layer(inputs)
+        for block in self.blocks:
+            h = block(h, context=context)
+        return self.final_layer(h)

@@ -1,0 +1,159 @@
+"""Masked autoregressive transforms (API of flowcon/transforms/autoregressive/autoregressive.py).
+
+``forward`` = one MADE pass (PyTorch-ROCm) + one HIP element-wise kernel; ``inverse`` = D
+sequential MADE passes, each followed by the element-wise inverse kernel on all dims
+(reference autoregressive.py:39-53 -- same fixed-point iteration, same cost model).
+"""
+import numpy as np
+import torch
+from torch.nn import functional as F
+
+from flowconductor_amd import ops
+from flowconductor_amd.transforms import made as made_module
+from flowconductor_amd.transforms.base import Transform
+
+
+class AutoregressiveTransform(Transform):
+    """Element-wise bijector whose parameters for dim i depend on dims < i only.
+
+    NOTE: the inverse costs D conditioner passes (D = number of input features).
+    """
+
+    def __init__(self, autoregressive_net):
+        super().__init__()
+        self.autoregressive_net = autoregressive_net
+
+    def forward(self, inputs, context=None):
+        autoregressive_params = self.autoregressive_net(inputs, context)
+        return self._elementwise_forward(inputs, autoregressive_params)
+
+    def inverse(self, inputs, context=None):
+        num_inputs = int(np.prod(inputs.shape[1:]))
+        outputs = torch.zeros_like(inputs)
+        logabsdet = None
+        with ops.deferred_errors():
+            for _ in range(num_inputs):
+                autoregressive_params = self.autoregressive_net(outputs, context)
+                outputs, logabsdet = self._elementwise_inverse(inputs, autoregressive_params)
+        return outputs, logabsdet
+
+    def _output_dim_multiplier(self):
+        raise NotImplementedError()
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        raise NotImplementedError()
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        raise NotImplementedError()
+
+
+def _made(self, features, hidden_features, context_features, num_blocks, use_residual_blocks,
+          random_mask, activation, dropout_probability, use_batch_norm):
+    return made_module.MADE(
+        features=features, hidden_features=hidden_features, context_features=context_features,
+        num_blocks=num_blocks, output_multiplier=self._output_dim_multiplier(),
+        use_residual_blocks=use_residual_blocks, random_mask=random_mask, activation=activation,
+        dropout_probability=dropout_probability, use_batch_norm=use_batch_norm)
+
+
+class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
+    """MAF layer: scale = softplus(u) + 1e-3, y = scale * x + shift (autoregressive.py:65-129)."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu,
+                 dropout_probability=0.0, use_batch_norm=False):
+        self.features = features
+        made = _made(self, features, hidden_features, context_features, num_blocks,
+                     use_residual_blocks, random_mask, activation, dropout_probability, use_batch_norm)
+        self._epsilon = 1e-3
+        super().__init__(made)
+
+    def _output_dim_multiplier(self):
+        return 2
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        return ops.affine_coupling(inputs, autoregressive_params, None,
+                                   activation=ops.AFFINE_MAF_SOFTPLUS, inverse=False)
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        return ops.affine_coupling(inputs, autoregressive_params, None,
+                                   activation=ops.AFFINE_MAF_SOFTPLUS, inverse=True)
+
+
+class MaskedShiftAutoregressiveTransform(AutoregressiveTransform):
+    """Shift-only AR layer.  As in the reference (autoregressive.py:164-196) ``forward`` adds
+    ``2*tanh(shift)`` while ``inverse`` subtracts the raw ``shift``; logabsdet is 0 both ways."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu,
+                 dropout_probability=0.0, use_batch_norm=False):
+        self.features = features
+        made = _made(self, features, hidden_features, context_features, num_blocks,
+                     use_residual_blocks, random_mask, activation, dropout_probability, use_batch_norm)
+        self._epsilon = 1e-3
+        self.shift_scale = 1.
+        super().__init__(made)
+
+    def _output_dim_multiplier(self):
+        return 1
+
+    def _params(self, autoregressive_params):
+        if self.shift_scale != 1.:
+            return autoregressive_params * self.shift_scale
+        return autoregressive_params
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        return ops.affine_coupling(inputs, self._params(autoregressive_params), None,
+                                   activation=ops.AFFINE_SHIFT_TANH2, inverse=False)
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        return ops.affine_coupling(inputs, self._params(autoregressive_params), None,
+                                   activation=ops.AFFINE_ADDITIVE, inverse=True)
+
+
+class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTransform):
+    """RQ-spline AR layer (autoregressive.py:529-621): identity-init softplus beta, box
+    [-1.2, 1.2]^2 when ``tails`` is None, width/height scaling only if the net exposes
+    ``hidden_features`` (MADE does not)."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_bins=10, tails=None,
+                 tail_bound=1.0, num_blocks=2, use_residual_blocks=True, random_mask=False,
+                 activation=F.relu, dropout_probability=0.0, use_batch_norm=False,
+                 min_bin_width=ops.DEFAULT_MIN_BIN_WIDTH, min_bin_height=ops.DEFAULT_MIN_BIN_HEIGHT,
+                 min_derivative=ops.DEFAULT_MIN_DERIVATIVE):
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tails = tails
+        self.tail_bound = tail_bound
+        made = _made(self, features, hidden_features, context_features, num_blocks,
+                     use_residual_blocks, random_mask, activation, dropout_probability, use_batch_norm)
+        super().__init__(made)
+
+    def _output_dim_multiplier(self):
+        if self.tails == "linear":
+            return self.num_bins * 3 - 1
+        elif self.tails is None:
+            return self.num_bins * 3 + 1
+        else:
+            raise ValueError
+
+    def _elementwise(self, inputs, autoregressive_params, inverse=False):
+        if self.tails not in (None, "linear"):
+            raise ValueError
+        divisor = 1.0
+        if hasattr(self.autoregressive_net, "hidden_features"):
+            divisor = float(np.sqrt(self.autoregressive_net.hidden_features))
+        return ops.rq_spline(
+            inputs, autoregressive_params, None, num_bins=self.num_bins, tails=self.tails,
+            tail_bound=self.tail_bound, left=-1.2, right=1.2, bottom=-1.2, top=1.2,
+            min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+            min_derivative=self.min_derivative, enable_identity_init=True, wh_divisor=divisor,
+            inverse=inverse)
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params)
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params, inverse=True)

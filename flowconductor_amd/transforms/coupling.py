@@ -1,0 +1,238 @@
+"""Coupling layers (API of flowcon/transforms/coupling.py:20-582).
+
+The conditioner (``transform_net``) is whatever ``nn.Module`` the user's
+``transform_net_create_fn(in_features, out_features)`` returns and runs on PyTorch-ROCm.  The
+element-wise bijector, the split / merge of the two halves and the per-sample logabsdet
+reduction are ONE HIP kernel launch per layer: the kernel reads the full ``[N, D]`` input and
+the conditioner's ``[N, d_t * multiplier]`` output once, writes the full output once
+(identity columns copied through LDS) and the ``[N]`` logabsdet once.
+"""
+import warnings
+
+import numpy as np
+import torch
+
+from flowconductor_amd import ops
+from flowconductor_amd.transforms.base import Transform
+
+
+def _rows_from_nchw(t):
+    """[B, C, H, W] -> ([B*H*W, C] contiguous, (B, C, H, W))."""
+    b, c, h, w = t.shape
+    return t.permute(0, 2, 3, 1).reshape(b * h * w, c), (b, c, h, w)
+
+
+def _nchw_from_rows(rows, shape):
+    b, c, h, w = shape
+    return rows.reshape(b, h, w, c).permute(0, 3, 1, 2).contiguous()
+
+
+class CouplingTransform(Transform):
+    """Base class for coupling layers: 2-D ``[N, D]`` inputs, or 4-D ``[N, C, H, W]`` split on C.
+
+    mask[i] > 0: feature i is transformed; mask[i] <= 0: feature i passes unchanged and
+    feeds the conditioner (reference coupling.py:25-63).
+    """
+
+    def __init__(self, mask, transform_net_create_fn, unconditional_transform=None):
+        mask = torch.as_tensor(mask)
+        if mask.dim() != 1:
+            raise ValueError("Mask must be a 1-dim tensor.")
+        if mask.numel() <= 0:
+            raise ValueError("Mask can't be empty.")
+
+        super().__init__()
+        self.features = len(mask)
+        features_vector = torch.arange(self.features)
+        self.register_buffer("identity_features", features_vector.masked_select(mask <= 0))
+        self.register_buffer("transform_features", features_vector.masked_select(mask > 0))
+        assert self.num_identity_features + self.num_transform_features == self.features
+
+        self.transform_net = transform_net_create_fn(
+            self.num_identity_features,
+            self.num_transform_features * self._transform_dim_multiplier(),
+        )
+        if unconditional_transform is None:
+            self.unconditional_transform = None
+        else:
+            self.unconditional_transform = unconditional_transform(features=self.num_identity_features)
+        self._cols_cache = None
+
+    @property
+    def num_identity_features(self):
+        return len(self.identity_features)
+
+    @property
+    def num_transform_features(self):
+        return len(self.transform_features)
+
+    def _cols(self, device):
+        """int32 copy of ``transform_features`` on ``device`` (what the kernel indexes with)."""
+        c = self._cols_cache
+        if c is None or c.device != device or c.numel() != self.num_transform_features:
+            c = self.transform_features.to(device=device, dtype=torch.int32).contiguous()
+            self._cols_cache = c
+        return c
+
+    def _check(self, inputs):
+        if inputs.dim() not in [2, 4]:
+            raise ValueError("Inputs must be a 2D or a 4D tensor.")
+        if inputs.shape[1] != self.features:
+            raise ValueError("Expected features = {}, got {}.".format(self.features, inputs.shape[1]))
+
+    def _run(self, inputs, context, inverse):
+        self._check(inputs)
+        identity_split = inputs[:, self.identity_features, ...]
+        logabsdet_identity = None
+        if inverse and self.unconditional_transform is not None:
+            identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
+
+        transform_params = self.transform_net(identity_split, context)
+
+        if inputs.dim() == 4:
+            rows, shape = _rows_from_nchw(inputs)
+            prows = self._param_rows_nchw(transform_params, shape)
+            out_rows, lad_rows = self._coupling_kernel(rows, prows, inverse)
+            outputs = _nchw_from_rows(out_rows, shape)
+            logabsdet = lad_rows.reshape(shape[0], -1).sum(dim=1)
+        else:
+            outputs, logabsdet = self._coupling_kernel(inputs, transform_params, inverse)
+
+        if self.unconditional_transform is not None:
+            if not inverse:
+                identity_split, logabsdet_identity = self.unconditional_transform(identity_split, context)
+            outputs[:, self.identity_features, ...] = identity_split
+            logabsdet = logabsdet + logabsdet_identity
+        return outputs, logabsdet
+
+    def forward(self, inputs, context=None):
+        return self._run(inputs, context, inverse=False)
+
+    def inverse(self, inputs, context=None):
+        return self._run(inputs, context, inverse=True)
+
+    def _transform_dim_multiplier(self):
+        """Number of features to output for each transform dimension."""
+        raise NotImplementedError()
+
+    def _coupling_kernel(self, inputs, transform_params, inverse):
+        """[N, D] inputs + [N, d_t * multiplier] params -> ([N, D] outputs, [N] logabsdet)."""
+        raise NotImplementedError()
+
+    def _param_rows_nchw(self, transform_params, shape):
+        """Conditioner output [B, d_t*mult, H, W] -> per-pixel rows in the 2-D layout."""
+        raise NotImplementedError()
+
+
+class AffineCouplingTransform(CouplingTransform):
+    """RealNVP affine coupling: y = x * scale + shift on the transformed half.
+
+    ``scale_activation`` follows the reference (coupling.py:212-252): the two predefined
+    class attributes select a fused activation inside the kernel; any other callable is
+    evaluated with torch and handed to the kernel as a ready scale.
+    """
+
+    DEFAULT_SCALE_ACTIVATION = lambda x: torch.sigmoid(x + 2) + 1e-3  # noqa: E731
+    GENERAL_SCALE_ACTIVATION = lambda x: (torch.nn.functional.softplus(x) + 1e-3).clamp(0, 3)  # noqa: E731
+
+    def __init__(self, mask, transform_net_create_fn, unconditional_transform=None,
+                 scale_activation=DEFAULT_SCALE_ACTIVATION):
+        self.scale_activation = scale_activation
+        super().__init__(mask, transform_net_create_fn, unconditional_transform)
+
+    def _transform_dim_multiplier(self):
+        return 2
+
+    def _activation_code(self):
+        if self.scale_activation is AffineCouplingTransform.DEFAULT_SCALE_ACTIVATION:
+            return ops.AFFINE_SIGMOID_PLUS2
+        if self.scale_activation is AffineCouplingTransform.GENERAL_SCALE_ACTIVATION:
+            return ops.AFFINE_SOFTPLUS_CLAMP3
+        return ops.AFFINE_SCALE_GIVEN
+
+    def _coupling_kernel(self, inputs, transform_params, inverse):
+        code = self._activation_code()
+        if code == ops.AFFINE_SCALE_GIVEN:
+            d_t = self.num_transform_features
+            scale = self.scale_activation(transform_params[:, d_t:])
+            transform_params = torch.cat((transform_params[:, :d_t], scale), dim=1)
+        return ops.affine_coupling(inputs, transform_params, self._cols(inputs.device),
+                                   activation=code, inverse=inverse)
+
+    def _param_rows_nchw(self, transform_params, shape):
+        return _rows_from_nchw(transform_params)[0]
+
+
+class AdditiveCouplingTransform(AffineCouplingTransform):
+    """NICE additive coupling: y = x + shift, logabsdet = 0 (coupling.py:255-269)."""
+
+    def _transform_dim_multiplier(self):
+        return 1
+
+    def _coupling_kernel(self, inputs, transform_params, inverse):
+        return ops.affine_coupling(inputs, transform_params, self._cols(inputs.device),
+                                   activation=ops.AFFINE_ADDITIVE, inverse=inverse)
+
+
+class PiecewiseCouplingTransform(CouplingTransform):
+    """Coupling layers whose bijector is a K-bin spline with per-(sample, dim) parameters."""
+
+    def _param_rows_nchw(self, transform_params, shape):
+        b, _, h, w = shape
+        c = self.num_transform_features
+        # [B, c*mult, H, W] -> [B, c, mult, H, W] -> [B, H, W, c, mult] -> rows
+        p = transform_params.reshape(b, c, -1, h, w).permute(0, 3, 4, 1, 2)
+        return p.reshape(b * h * w, -1)
+
+    def _wh_divisor(self):
+        raise NotImplementedError()
+
+
+def _softmax_divisor(net, warn):
+    """sqrt(hidden width) the reference divides unnormalised widths/heights by (coupling.py:554-563)."""
+    if hasattr(net, "hidden_features"):
+        return float(np.sqrt(net.hidden_features))
+    if hasattr(net, "hidden_channels"):
+        return float(np.sqrt(net.hidden_channels))
+    if warn:
+        warnings.warn("Inputs to the softmax are not scaled down: initialization might be bad.")
+    return 1.0
+
+
+class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
+    """Neural-spline-flow coupling layer (coupling.py:502-582); the north-star kernel."""
+
+    def __init__(self, mask, transform_net_create_fn, num_bins=10, tails=None, tail_bound=1.0,
+                 apply_unconditional_transform=False, img_shape=None,
+                 min_bin_width=ops.DEFAULT_MIN_BIN_WIDTH, min_bin_height=ops.DEFAULT_MIN_BIN_HEIGHT,
+                 min_derivative=ops.DEFAULT_MIN_DERIVATIVE):
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tails = tails
+        self.tail_bound = tail_bound
+
+        if apply_unconditional_transform:
+            from flowconductor_amd.transforms.nonlinearities import PiecewiseRationalQuadraticCDF
+
+            def unconditional_transform(features):
+                return PiecewiseRationalQuadraticCDF(
+                    shape=[features] + (img_shape if img_shape else []), num_bins=num_bins,
+                    tails=tails, tail_bound=tail_bound, min_bin_width=min_bin_width,
+                    min_bin_height=min_bin_height, min_derivative=min_derivative)
+        else:
+            unconditional_transform = None
+        super().__init__(mask, transform_net_create_fn, unconditional_transform=unconditional_transform)
+
+    def _transform_dim_multiplier(self):
+        if self.tails == "linear":
+            return self.num_bins * 3 - 1
+        return self.num_bins * 3 + 1
+
+    def _coupling_kernel(self, inputs, transform_params, inverse):
+        return ops.rq_spline(
+            inputs, transform_params, self._cols(inputs.device), num_bins=self.num_bins,
+            tails=self.tails, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
+            min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
+            wh_divisor=_softmax_divisor(self.transform_net, warn=True), inverse=inverse)

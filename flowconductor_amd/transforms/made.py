@@ -1,0 +1,160 @@
+"""MADE conditioner for the autoregressive transforms (PyTorch-ROCm; boundary only).
+
+Constructor arguments, buffers (``mask``, ``degrees``) and ``state_dict`` keys follow
+flowcon/transforms/made.py:17-283.  Masks are the standard MADE degree rule: a hidden unit of
+degree m sees inputs of degree <= m, an output of degree m sees hidden units of degree < m.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from flowconductor_amd.utils import torchutils
+
+
+def _get_input_degrees(in_features):
+    """Degrees 1..in_features of the inputs to MADE."""
+    return torch.arange(1, in_features + 1)
+
+
+class MaskedLinear(nn.Linear):
+    """A linear module with a masked weight matrix."""
+
+    def __init__(self, in_degrees, out_features, autoregressive_features, random_mask, is_output,
+                 bias=True):
+        super().__init__(in_features=len(in_degrees), out_features=out_features, bias=bias)
+        mask, degrees = self._get_mask_and_degrees(
+            in_degrees=in_degrees, out_features=out_features,
+            autoregressive_features=autoregressive_features, random_mask=random_mask,
+            is_output=is_output)
+        self.register_buffer("mask", mask)
+        self.register_buffer("degrees", degrees)
+
+    @classmethod
+    def _get_mask_and_degrees(cls, in_degrees, out_features, autoregressive_features, random_mask,
+                              is_output):
+        if is_output:
+            out_degrees = torchutils.tile(_get_input_degrees(autoregressive_features),
+                                          out_features // autoregressive_features)
+            mask = (out_degrees[..., None] > in_degrees).float()
+        else:
+            if random_mask:
+                low = min(torch.min(in_degrees).item(), autoregressive_features - 1)
+                out_degrees = torch.randint(low=low, high=autoregressive_features,
+                                            size=[out_features], dtype=torch.long)
+            else:
+                hi = max(1, autoregressive_features - 1)
+                lo = min(1, autoregressive_features - 1)
+                out_degrees = torch.arange(out_features) % hi + lo
+            mask = (out_degrees[..., None] >= in_degrees).float()
+        return mask, out_degrees
+
+    def forward(self, x):
+        return F.linear(x, self.weight * self.mask, self.bias)
+
+
+class MaskedFeedforwardBlock(nn.Module):
+    """(batch norm) -> masked linear -> activation -> dropout; width preserved."""
+
+    def __init__(self, in_degrees, autoregressive_features, context_features=None, random_mask=False,
+                 activation=F.relu, dropout_probability=0.0, use_batch_norm=False):
+        super().__init__()
+        features = len(in_degrees)
+        self.batch_norm = nn.BatchNorm1d(features, eps=1e-3) if use_batch_norm else None
+        self.linear = MaskedLinear(in_degrees=in_degrees, out_features=features,
+                                   autoregressive_features=autoregressive_features,
+                                   random_mask=random_mask, is_output=False)
+        self.degrees = self.linear.degrees
+        self.activation = activation
+        self.dropout = nn.Dropout(p=dropout_probability)
+
+    def forward(self, inputs, context=None):
+        h = self.batch_norm(inputs) if self.batch_norm else inputs
+        return self.dropout(self.activation(self.linear(h)))
+
+
+class MaskedResidualBlock(nn.Module):
+    """Residual block of two masked linears; context enters additively after the first."""
+
+    def __init__(self, in_degrees, autoregressive_features, context_features=None, random_mask=False,
+                 activation=F.relu, dropout_probability=0.0, use_batch_norm=False,
+                 zero_initialization=True):
+        if random_mask:
+            raise ValueError("Masked residual block can't be used with random masks.")
+        super().__init__()
+        features = len(in_degrees)
+        if context_features is not None:
+            self.context_layer = nn.Linear(context_features, features)
+        self.use_batch_norm = use_batch_norm
+        if use_batch_norm:
+            self.batch_norm_layers = nn.ModuleList(nn.BatchNorm1d(features, eps=1e-3) for _ in range(2))
+        linear_0 = MaskedLinear(in_degrees=in_degrees, out_features=features,
+                                autoregressive_features=autoregressive_features, random_mask=False,
+                                is_output=False)
+        linear_1 = MaskedLinear(in_degrees=linear_0.degrees, out_features=features,
+                                autoregressive_features=autoregressive_features, random_mask=False,
+                                is_output=False)
+        self.linear_layers = nn.ModuleList([linear_0, linear_1])
+        self.degrees = linear_1.degrees
+        if torch.all(self.degrees >= in_degrees).item() != 1:
+            raise RuntimeError("In a masked residual block, the output degrees can't be"
+                               " less than the corresponding input degrees.")
+        self.activation = activation
+        self.dropout = nn.Dropout(p=dropout_probability)
+        if zero_initialization:
+            nn.init.uniform_(self.linear_layers[-1].weight, a=-1e-3, b=1e-3)
+            nn.init.uniform_(self.linear_layers[-1].bias, a=-1e-3, b=1e-3)
+
+    def forward(self, inputs, context=None):
+        h = inputs
+        if self.use_batch_norm:
+            h = self.batch_norm_layers[0](h)
+        h = self.linear_layers[0](self.activation(h))
+        if context is not None:
+            h = h + self.context_layer(context)
+        if self.use_batch_norm:
+            h = self.batch_norm_layers[1](h)
+        h = self.linear_layers[1](self.dropout(self.activation(h)))
+        return inputs + h
+
+
+class MADE(nn.Module):
+    """Masked autoencoder: masked initial layer, ``num_blocks`` masked blocks, masked output layer
+    producing ``output_multiplier`` values per input feature (feature-major)."""
+
+    def __init__(self, features, hidden_features, context_features=None, num_blocks=2,
+                 output_multiplier=1, use_residual_blocks=True, random_mask=False, activation=F.relu,
+                 dropout_probability=0.0, use_batch_norm=False):
+        if use_residual_blocks and random_mask:
+            raise ValueError("Residual blocks can't be used with random masks.")
+        super().__init__()
+        self.initial_layer = MaskedLinear(in_degrees=_get_input_degrees(features),
+                                          out_features=hidden_features,
+                                          autoregressive_features=features, random_mask=random_mask,
+                                          is_output=False)
+        if context_features is not None:
+            self.context_layer = nn.Linear(context_features, hidden_features)
+        self.use_residual_blocks = use_residual_blocks
+        self.activation = activation
+        block_cls = MaskedResidualBlock if use_residual_blocks else MaskedFeedforwardBlock
+        blocks = []
+        degrees = self.initial_layer.degrees
+        for _ in range(num_blocks):
+            blocks.append(block_cls(in_degrees=degrees, autoregressive_features=features,
+                                    context_features=context_features, random_mask=random_mask,
+                                    activation=activation, dropout_probability=dropout_probability,
+                                    use_batch_norm=use_batch_norm))
+            degrees = blocks[-1].degrees
+        self.blocks = nn.ModuleList(blocks)
+        self.final_layer = MaskedLinear(in_degrees=degrees, out_features=features * output_multiplier,
+                                        autoregressive_features=features, random_mask=random_mask,
+                                        is_output=True)
+
+    def forward(self, inputs, context=None):
+        h = self.initial_layer(inputs)
+        if context is not None:
+            h = h + self.activation(self.context_layer(context))
+        if not self.use_residual_blocks:
+            h = self.activation(h)
+        for block in self.blocks:
+            h = block(h, context)
+        return self.final_layer(h)

@@ -1,0 +1,114 @@
+/* flowcon_hip.h -- C ABI of libflowcon_hip.so: MI355X (gfx950) bijector kernels.
+ *
+ * Every entry point
+ *   - takes raw DEVICE pointers (f32 unless stated) and plain sizes; no torch types,
+ *   - allocates nothing, is asynchronous on `stream` (a hipStream_t passed as void*),
+ *   - returns a hipError_t as int (0 == hipSuccess),
+ *   - never mutates its inputs (x may alias y where stated).
+ * The reference (FlowConductor, pure Python on ATen) has no FFI; each function below names
+ * the reference op sequence it stands in for (file:line under the reference tree).
+ * INTEGRATION.md shows the ctypes binding a maintainer would add on the reference side.
+ *
+ * Common conventions
+ *   x, y        [n, d] row-major; transformed columns are `cols[0..d_t)` (int32) or, when
+ *               cols == NULL, d_t == d and dim j is column j.  Columns not listed in `cols`
+ *               are copied x -> y unchanged (coupling identity half, coupling.py:96-98).
+ *   params      per-sample parameters [n, rowlen]; shared_params != 0 means a single
+ *               [rowlen] row used for the whole batch (nonlinearities.py:246-247).
+ *   logabsdet   [n] or NULL. lad_mode: 0 store, 1 accumulate (+=), 2 store negated,
+ *               3 accumulate negated.
+ *   err_flag    device uint32 word or NULL; kernels OR in FC_ERR_* bits, the host reads it
+ *               to raise the reference's exceptions (transforms/base.py:10-19).
+ */
+#ifndef FLOWCON_HIP_H_
+#define FLOWCON_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FC_ERR_OUTSIDE_DOMAIN 1u /* InputOutsideDomain, splines/rational_quadratic.py:81-82 */
+#define FC_ERR_DISCRIMINANT 2u   /* assert (discriminant >= 0).all(), rational_quadratic.py:142 */
+#define FC_ERR_NONFINITE 4u
+
+/* ABI version of this header; fc_abi_version() must return it. */
+#define FC_ABI_VERSION 1
+
+int fc_abi_version(void);
+
+/* ---- rational-quadratic spline ------------------------------------------------------- */
+typedef struct fc_rq_config {
+  int32_t num_bins;       /* K */
+  int32_t tails;          /* 0: none, 1: "linear" (rational_quadratic.py:32-42) */
+  int32_t inverse;        /* 0 forward, 1 inverse */
+  int32_t reserved;
+  float left, right, bottom, top; /* linear tails: -B, B, -B, B */
+  double min_bin_width, min_bin_height, min_derivative; /* python floats of the reference */
+  float wh_divisor;       /* sqrt(hidden_features) or 1 (coupling.py:554-559) */
+  float softplus_beta;    /* 1, or ln2/(1-min_derivative) (rational_quadratic.py:100-103) */
+  float tail_constant;    /* (float)log(exp(1-min_derivative)-1) (rational_quadratic.py:34) */
+  float reserved2;
+} fc_rq_config;
+
+/* Replaces unconstrained_rational_quadratic_spline / rational_quadratic_spline
+ * (splines/rational_quadratic.py:13-181) together with the reshape + in-place scaling +
+ * sum_except_batch of PiecewiseRationalQuadraticCouplingTransform (coupling.py:279-293,
+ * 549-582), the masked AR variant (autoregressive/autoregressive.py:583-621) and
+ * PiecewiseRationalQuadraticCDF (nonlinearities.py:429-487).
+ * params row layout per transformed dim: [K widths | K heights | K-1 (linear tails) or K+1
+ * derivatives]; rowlen = d_t * (3K -/+ 1). */
+int fc_rq_spline(const float* x, float* y, const float* params, const int32_t* cols,
+                 float* logabsdet, uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t,
+                 int32_t shared_params, int32_t lad_mode, const fc_rq_config* cfg, void* stream);
+
+/* ---- affine / additive with per-sample parameters ------------------------------------------ */
+#define FC_AFFINE_SIGMOID_PLUS2 0   /* row [shift d_t | u d_t], s = sigmoid(u+2)+1e-3 (coupling.py:224) */
+#define FC_AFFINE_SOFTPLUS_CLAMP3 1 /* row [shift | u], s = clamp(softplus(u)+1e-3, 0, 3) (coupling.py:225) */
+#define FC_AFFINE_SCALE_GIVEN 2     /* row [shift | s]: scale already activated by the caller */
+#define FC_AFFINE_ADDITIVE 3        /* row [shift d_t], s = 1, logabsdet = 0 (coupling.py:255-269) */
+#define FC_AFFINE_MAF_SOFTPLUS 4    /* row [d_t, 2] interleaved (u, shift), s = softplus(u)+1e-3
+                                       (autoregressive/autoregressive.py:97-129) */
+
+#define FC_AFFINE_SHIFT_TANH2 5     /* row [p d_t], shift = 2*tanh(p), s = 1 (autoregressive.py:164-175;
+                                       the reference's inverse subtracts raw p: use ADDITIVE) */
+
+/* y = x*s + shift (forward) or (x - shift)/s (inverse) on the `cols` columns, logabsdet =
+ * +/- sum_j log s.  Replaces AffineCouplingTransform / AdditiveCouplingTransform
+ * (coupling.py:212-269) incl. the split/merge of coupling.py:82-98, and
+ * MaskedAffineAutoregressiveTransform._elementwise_{forward,inverse}
+ * (autoregressive/autoregressive.py:97-129). */
+int fc_affine(const float* x, float* y, const float* params, const int32_t* cols,
+              float* logabsdet, int64_t n, int32_t d, int32_t d_t, int32_t activation,
+              int32_t inverse, int32_t shared_params, int32_t lad_mode, void* stream);
+
+/* ---- base-distribution epilogue ---------------------------------------------------------- */
+/* out[i] = -0.5 * sum_j z[i,j]^2 - log_z (+ add[i] when add != NULL).  Replaces
+ * StandardNormal._log_prob (distributions/normal.py:23-33) and the `log_prob + logabsdet` of
+ * Flow._log_prob (flows/base.py:48). */
+int fc_standard_normal_log_prob(const float* z, const float* add, float* out, int64_t n,
+                                int32_t d, float log_z, void* stream);
+
+/* ---- permutation ------------------------------------------------------------------------- */
+/* y[o, j, i] = x[o, perm[j], i] for a tensor viewed as [outer, d, inner]; bit-exact.  x != y.
+ * Replaces Permutation._permute (transforms/permutations.py:27-46, torch.index_select). */
+int fc_permute(const float* x, float* y, const int32_t* perm, int64_t outer, int32_t d,
+               int64_t inner, void* stream);
+
+/* ---- batch-shared point-wise affine maps ---------------------------------------------------- */
+/* x, y viewed as [n, m] (m = elements of one batch item); scale/shift have 1 or m entries.
+ * mode 0: y = x*scale + shift                    (standard.py:54-60, normalization.py:171-187)
+ * mode 1: y = (x - shift)/scale                  (standard.py:62-68, normalization.py:189-204)
+ * mode 2: y = weight*((x - mean)/scale) + shift  (BatchNorm eval forward, normalization.py:98-118;
+ *         scale = sqrt(var + eps), shift = bias; aux_mean/aux_weight have m entries)
+ * mode 3: y = scale*((x - shift)/weight) + mean  (BatchNorm eval inverse, normalization.py:120-141)
+ * The logabsdet of these maps is a per-call constant the host computes, as in the reference. */
+int fc_pointwise_affine(const float* x, float* y, const float* scale, const float* shift,
+                        const float* aux_mean, const float* aux_weight, int64_t n, int64_t m,
+                        int32_t scale_len, int32_t shift_len, int32_t mode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWCON_HIP_H_ */

@@ -1,0 +1,166 @@
+"""Golden-vector case definitions, shared by the generator (run against the imported
+reference, in the build container only) and by the tests (run against flowconductor_amd on
+the GPU and against the CPU oracle).
+
+Each case builds a transform from a library namespace ``L`` exposing ``transforms``, ``nets``,
+``utils``, ``flows``, ``distributions`` -- the reference's ``flowcon`` and this repo's
+``flowconductor_amd`` share those names, which is the drop-in boundary under test.
+"""
+import torch
+
+
+def _resnet(L, hidden=16, blocks=2, context=None):
+    def create(i, o):
+        return L.nets.ResidualNet(i, o, hidden_features=hidden, num_blocks=blocks, context_features=context)
+    return create
+
+
+def _alt_mask(L, d, even=True):
+    return L.utils.create_alternating_binary_mask(d, even=even)
+
+
+# name -> dict(build=fn(L), features=D, context=ctx_dim or None, x_scale=float, inverse=bool,
+#              tol=(fwd_out, fwd_lad, inv_out, inv_lad) absolute tolerances for GPU-vs-golden)
+CASES = {}
+
+
+def case(name, features, context=None, x_scale=1.0, inverse=True, boost=3.0, in_unit=False,
+         clamp=None, tol=(2e-5, 1e-4, 2e-4, 1e-3)):
+    def deco(fn):
+        CASES[name] = dict(build=fn, features=features, context=context, x_scale=x_scale,
+                           inverse=inverse, boost=boost, in_unit=in_unit, clamp=clamp, tol=tol)
+        return fn
+    return deco
+
+
+@case("rq_coupling_linear_tails_d8_k8", 8, x_scale=1.5)
+def _(L):
+    return L.transforms.PiecewiseRationalQuadraticCouplingTransform(
+        _alt_mask(L, 8), _resnet(L), num_bins=8, tails="linear", tail_bound=3.0)
+
+
+@case("rq_coupling_linear_tails_d64_k8_h64", 64, x_scale=1.5)
+def _(L):
+    return L.transforms.PiecewiseRationalQuadraticCouplingTransform(
+        _alt_mask(L, 64, even=False), _resnet(L, hidden=64), num_bins=8, tails="linear", tail_bound=3.0)
+
+
+@case("rq_coupling_linear_tails_d7_k5_ctx", 7, context=3, x_scale=1.5)
+def _(L):
+    return L.transforms.PiecewiseRationalQuadraticCouplingTransform(
+        L.utils.create_mid_split_binary_mask(7), _resnet(L, hidden=10, context=3), num_bins=5,
+        tails="linear", tail_bound=2.0)
+
+
+@case("rq_coupling_no_tails_d6_k10", 6, in_unit=True)
+def _(L):
+    return L.transforms.PiecewiseRationalQuadraticCouplingTransform(
+        _alt_mask(L, 6), _resnet(L), num_bins=10, tails=None)
+
+
+@case("rq_coupling_uncond_d8_k8", 8, x_scale=1.5)
+def _(L):
+    return L.transforms.PiecewiseRationalQuadraticCouplingTransform(
+        _alt_mask(L, 8), _resnet(L), num_bins=8, tails="linear", tail_bound=3.0,
+        apply_unconditional_transform=True)
+
+
+@case("affine_coupling_d32", 32, tol=(1e-5, 2e-5, 2e-5, 2e-5))
+def _(L):
+    return L.transforms.AffineCouplingTransform(_alt_mask(L, 32), _resnet(L, hidden=64))
+
+
+@case("affine_coupling_general_act_d9", 9, tol=(1e-5, 2e-5, 2e-5, 2e-5))
+def _(L):
+    return L.transforms.AffineCouplingTransform(
+        _alt_mask(L, 9), _resnet(L),
+        scale_activation=L.transforms.AffineCouplingTransform.GENERAL_SCALE_ACTIVATION)
+
+
+@case("additive_coupling_d10_ctx", 10, context=4, tol=(1e-5, 1e-7, 1e-5, 1e-7))
+def _(L):
+    return L.transforms.AdditiveCouplingTransform(_alt_mask(L, 10), _resnet(L, context=4))
+
+
+@case("maf_affine_d2_h4", 2, tol=(1e-5, 2e-5, 2e-5, 2e-5))
+def _(L):
+    return L.transforms.MaskedAffineAutoregressiveTransform(features=2, hidden_features=4)
+
+
+@case("maf_affine_d12_h32_ctx", 12, context=5, tol=(1e-5, 2e-5, 5e-5, 5e-5))
+def _(L):
+    return L.transforms.MaskedAffineAutoregressiveTransform(features=12, hidden_features=32, context_features=5)
+
+
+@case("maf_shift_d6", 6, inverse=True, tol=(1e-5, 1e-7, 1e-5, 1e-7))
+def _(L):
+    return L.transforms.MaskedShiftAutoregressiveTransform(features=6, hidden_features=16)
+
+
+@case("maf_rq_linear_tails_d6_k8", 6, x_scale=1.5, boost=10.0)
+def _(L):
+    return L.transforms.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+        features=6, hidden_features=32, num_bins=8, tails="linear", tail_bound=3.0)
+
+
+@case("maf_rq_box_d5_k10", 5, x_scale=0.6, boost=10.0, clamp=(-1.2, 1.2))
+def _(L):
+    return L.transforms.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+        features=5, hidden_features=32, num_bins=10, tails=None)
+
+
+@case("rq_cdf_linear_tails_d5", 5, x_scale=1.5, boost=1.0)
+def _(L):
+    return L.transforms.PiecewiseRationalQuadraticCDF(shape=[5], num_bins=8, tails="linear", tail_bound=2.5)
+
+
+@case("random_permutation_d11", 11, tol=(0, 0, 0, 0))
+def _(L):
+    return L.transforms.RandomPermutation(11)
+
+
+@case("reverse_permutation_d64", 64, tol=(0, 0, 0, 0))
+def _(L):
+    return L.transforms.ReversePermutation(64)
+
+
+@case("pointwise_affine_vec_d6", 6, tol=(1e-6, 1e-6, 1e-6, 1e-6))
+def _(L):
+    return L.transforms.PointwiseAffineTransform(
+        shift=torch.tensor([0.5, -1.0, 0.0, 2.0, 3.0, -0.25]),
+        scale=torch.tensor([2.0, -1.0, -2.0, 0.5, 1.5, 3.0]))
+
+
+@case("readme_maf_flow_d2", 2, tol=(1e-5, 2e-5, 2e-5, 2e-5))
+def _(L):
+    # README usage snippet of the reference (README.md:85-98) = BASELINE.json config 1
+    return L.transforms.CompositeTransform([
+        L.transforms.MaskedAffineAutoregressiveTransform(features=2, hidden_features=4),
+        L.transforms.RandomPermutation(features=2),
+    ])
+
+
+@case("rq_nsf_stack_d16_l4", 16, x_scale=1.2, tol=(1e-4, 5e-4, 1e-3, 5e-3))
+def _(L):
+    # scaled-down BASELINE.json config 3: alternating-mask RQ-NSF coupling stack
+    layers = []
+    for l in range(4):
+        layers.append(L.transforms.PiecewiseRationalQuadraticCouplingTransform(
+            _alt_mask(L, 16, even=(l % 2 == 0)), _resnet(L, hidden=32), num_bins=8, tails="linear",
+            tail_bound=3.0))
+    return L.transforms.CompositeTransform(layers)
+
+
+def boost_parameters(module, factor, seed):
+    """Make default-initialised conditioners produce non-trivial spline/affine parameters.
+
+    The reference initialises the last layer of every residual block to U(-1e-3, 1e-3), which
+    gives near-identity bijectors.  Scaling every ``final_layer`` / last residual layer makes the
+    fixtures exercise all bins.  Deterministic and applied identically wherever cases are built.
+    """
+    if factor == 1.0:
+        return
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            if "final_layer" in name or "linear_layers.1" in name:
+                p.mul_(factor)

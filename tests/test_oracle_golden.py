@@ -1,0 +1,31 @@
+"""Pins the CPU oracle against golden vectors produced by the imported reference
+(tests/golden/make_golden.py).  Also proves state_dict-name compatibility: the reference's
+state_dict loads strictly into flowconductor_amd's modules."""
+import pytest
+import torch
+
+import cases
+from _util import SIZES, build_case, golden, maxdiff
+from oracle import torch_oracle as O
+
+# the oracle runs the same ATen ops as the reference: expect agreement to float32 rounding
+TOL = 2e-6
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_oracle_matches_reference_golden(name):
+    g = golden(name)
+    t, spec = build_case(name, g)
+    for n in SIZES:
+        x = torch.from_numpy(g["x_%d" % n])
+        ctx = torch.from_numpy(g["ctx_%d" % n]) if spec["context"] else None
+        with torch.no_grad():
+            y, lad = O.transform_apply(t, x.clone(), None if ctx is None else ctx.clone())
+        assert maxdiff(y, g["y_%d" % n]) <= TOL, (name, n)
+        assert maxdiff(lad, g["lad_%d" % n]) <= TOL * 10, (name, n)
+        if spec["inverse"]:
+            with torch.no_grad():
+                xi, ladi = O.transform_apply(t, torch.from_numpy(g["y_%d" % n]).clone(),
+                                             None if ctx is None else ctx.clone(), inverse=True)
+            assert maxdiff(xi, g["xinv_%d" % n]) <= TOL * 5, (name, n)
+            assert maxdiff(ladi, g["ladinv_%d" % n]) <= TOL * 50, (name, n)
