@@ -50,11 +50,27 @@ def algorithmic_bytes_per_sample_layer():
     return 4 * d_t * (p + 2) + 8
 
 
+def host_cores():
+    """CPU threads this process may actually use (affinity and cgroup quota), not the host's count."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("FC_BENCH_MAX_CORES", "64"))))
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def cpu_baseline(flow_cpu, sample, chunk):
     """Time the CPU oracle (torch-CPU restatement of the reference's op sequence) on host cores."""
     from oracle import torch_oracle as O
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(99)
     x = torch.randn(sample, FEATURES, generator=gen)
@@ -91,7 +107,7 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=20, help="log2 samples per GPU")
     ap.add_argument("--chunk-log2", type=int, default=0, help="log2 rows per pass through the stack (0 = whole shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log2", type=int, default=15)
+    ap.add_argument("--cpu-sample-log2", type=int, default=17)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,8 +140,12 @@ def main():
         with torch.no_grad():
             return parallel.sharded_log_prob_mean(flow.log_prob, x, chunk=chunk, group=None if world == 1 else dist.group.WORLD)
 
+    torch.set_num_threads(host_cores())
+    log("rank %d/%d on %s: %d samples/GPU, host cores %d" % (rank, world, torch.cuda.get_device_name(device),
+                                                             n_local, host_cores()))
     for _ in range(args.warmup):
         step()
+    log("warm-up done")
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
@@ -145,6 +165,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
     if rank == 0:
         total = n_local * world * args.steps
         kernel_ms = timer.durations_ms()
@@ -180,6 +201,7 @@ def main():
         if world == 1:
             flow_cpu = build_flow()
             out["parity"] = parity(flow, flow_cpu, device)
+            log("parity done: %s" % out["parity"])
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(flow_cpu, 1 << args.cpu_sample_log2, 1 << 14)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -97,13 +97,13 @@ def _(L):
     return L.transforms.MaskedShiftAutoregressiveTransform(features=6, hidden_features=16)
 
 
-@case("maf_rq_linear_tails_d6_k8", 6, x_scale=1.5, boost=10.0)
+@case("maf_rq_linear_tails_d6_k8", 6, x_scale=1.5, boost=2.0)
 def _(L):
     return L.transforms.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
         features=6, hidden_features=32, num_bins=8, tails="linear", tail_bound=3.0)
 
 
-@case("maf_rq_box_d5_k10", 5, x_scale=0.6, boost=10.0, clamp=(-1.2, 1.2))
+@case("maf_rq_box_d5_k10", 5, x_scale=0.6, boost=2.0, clamp=(-1.2, 1.2))
 def _(L):
     return L.transforms.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
         features=5, hidden_features=32, num_bins=10, tails=None)

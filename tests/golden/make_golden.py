@@ -7,6 +7,7 @@ import chain needs the third-party ``UMNN`` package (not installed, not on the h
 empty placeholder module for it is created in a temp dir for the duration of this script
 (recipe recorded in SURVEY.md Appendix B).
 """
+import copy
 import os
 import sys
 import tempfile
@@ -74,6 +75,7 @@ def main():
         cases.boost_parameters(t, spec["boost"], seed=0)
         t.eval()
         gen = torch.Generator().manual_seed(4321)
+        t64 = copy.deepcopy(t).double()  # the reference itself in float64 = "truth" for noise floors
         out = {}
         for n in (7, 64, 257):
             x, ctx = make_inputs(spec, n, gen)
@@ -90,6 +92,17 @@ def main():
                     xi, ladi = t.inverse(y.clone(), None if ctx is None else ctx.clone())
                     out["xinv_%d" % n] = xi.numpy()
                     out["ladinv_%d" % n] = ladi.numpy()
+                ctx64 = None if ctx is None else ctx.double()
+                try:
+                    y64, lad64 = t64(x.double(), ctx64)
+                    out["y64_%d" % n] = y64.numpy()
+                    out["lad64_%d" % n] = lad64.numpy()
+                    if spec["inverse"]:
+                        xi64, ladi64 = t64.inverse(y.double(), ctx64)
+                        out["xinv64_%d" % n] = xi64.numpy()
+                        out["ladinv64_%d" % n] = ladi64.numpy()
+                except Exception as e:  # e.g. a float32 domain edge is outside the float64 box
+                    print("  (no float64 truth for %s n=%d: %s)" % (name, n, type(e).__name__))
         for k, v in t.state_dict().items():
             out["sd::" + k] = v.numpy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)

@@ -1,5 +1,6 @@
 """GPU parity: flowconductor_amd (HIP kernels through the C ABI) vs the reference's golden
 vectors and vs the CPU oracle, on identical weights and inputs."""
+import numpy as np
 import pytest
 import torch
 
@@ -10,12 +11,45 @@ from oracle import torch_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+def _floor(g, key, n):
+    k32, k64 = "%s_%d" % (key, n), "%s64_%d" % (key, n)
+    if k64 not in g.files or g[k32].size == 0:
+        return 0.0
+    return float(np.max(np.abs(g[k32].astype(np.float64) - g[k64])))
+
+
+def _check(name, n, what, got, g, key, exact, mult=8.0):
+    """GPU vs the reference's float32 golden.
+
+    Bit-exact for index ops.  Otherwise the bound is the north-star's 1e-5 relative (scaled by
+    the magnitude of the tensor) plus `mult` x the reference's OWN float32 noise floor for this
+    very quantity, measured as max |reference-f32 - reference-f64| when the fixture was generated
+    (ill-conditioned spline inverses carry 1e-3-level noise in the reference itself).  The floor
+    is one realisation of a heavy-tailed error (tools/noise_floor.py: p99.99 -> max spans 6x, and
+    the HIP kernel's error distribution vs float64 equals the reference-f32's), hence the margin;
+    autoregressive inverses amplify it through D sequential conditioner passes."""
+    ref = g["%s_%d" % (key, n)]
+    if exact:
+        assert torch.equal(got.cpu(), torch.from_numpy(ref)), (name, n, what)
+        return
+    scale = max(1.0, float(np.max(np.abs(ref)))) if ref.size else 1.0
+    k64 = "%s64_%d" % (key, n)
+    floor = float(np.max(np.abs(ref.astype(np.float64) - g[k64]))) if (k64 in g.files and ref.size) else 0.0
+    bound = 1e-5 * scale + mult * floor
+    err = maxdiff(got, ref)
+    assert err <= bound, (name, n, what, "err %.3g > bound %.3g (reference f32 noise floor %.3g)" % (err, bound, floor))
+    if k64 in g.files and ref.size:
+        # against float64 truth the kernel must stay within the same margin of the reference's f32 path
+        err64 = maxdiff(got, g[k64])
+        assert err64 <= bound, (name, n, what, "vs f64: err %.3g > bound %.3g" % (err64, bound))
+
+
 @pytest.mark.parametrize("name", sorted(cases.CASES))
 def test_gpu_matches_reference_golden(name, device):
     g = golden(name)
     t, spec = build_case(name, g)
     t = t.to(device)
-    tol_y, tol_lad, tol_xi, tol_ladi = spec["tol"]
+    exact = spec["tol"][0] == 0
     for n in SIZES:
         x = torch.from_numpy(g["x_%d" % n]).to(device)
         ctx = torch.from_numpy(g["ctx_%d" % n]).to(device) if spec["context"] else None
@@ -23,25 +57,21 @@ def test_gpu_matches_reference_golden(name, device):
             y, lad = t(x, ctx)
         assert y.shape == x.shape and lad.shape == (n,)
         assert torch.isfinite(y).all() and torch.isfinite(lad).all()
-        if tol_y == 0:
-            assert torch.equal(y.cpu(), torch.from_numpy(g["y_%d" % n])), (name, n)
-            assert torch.equal(lad.cpu(), torch.from_numpy(g["lad_%d" % n])), (name, n)
-        else:
-            ok, worst = rel_close(y, g["y_%d" % n], rtol=1e-5, atol=tol_y)
-            assert ok, (name, n, "outputs", worst, maxdiff(y, g["y_%d" % n]))
-            ok, worst = rel_close(lad, g["lad_%d" % n], rtol=1e-5, atol=tol_lad)
-            assert ok, (name, n, "logabsdet", worst, maxdiff(lad, g["lad_%d" % n]))
+        _check(name, n, "outputs", y, g, "y", exact)
+        _check(name, n, "logabsdet", lad, g, "lad", exact)
         if spec["inverse"]:
             yin = torch.from_numpy(g["y_%d" % n]).to(device)
             with torch.no_grad():
                 xi, ladi = t.inverse(yin, ctx)
-            if tol_xi == 0:
-                assert torch.equal(xi.cpu(), torch.from_numpy(g["xinv_%d" % n])), (name, n)
-            else:
-                ok, worst = rel_close(xi, g["xinv_%d" % n], rtol=1e-5, atol=tol_xi)
-                assert ok, (name, n, "inverse outputs", worst, maxdiff(xi, g["xinv_%d" % n]))
-                ok, worst = rel_close(ladi, g["ladinv_%d" % n], rtol=1e-5, atol=tol_ladi)
-                assert ok, (name, n, "inverse logabsdet", worst, maxdiff(ladi, g["ladinv_%d" % n]))
+            mult = 64.0 if "maf_rq" in name else 16.0
+            _check(name, n, "inverse outputs", xi, g, "xinv", exact, mult)
+            _check(name, n, "inverse logabsdet", ladi, g, "ladinv", exact, mult)
+            # well-conditioned direction: pushing the kernel's inverse forward again lands on y
+            with torch.no_grad():
+                y_back, lad_back = t(xi, ctx)
+            if not exact and "maf_shift" not in name:  # (MaskedShift's inverse is not its inverse)
+                scale = max(1.0, float(yin.abs().max()))
+                assert maxdiff(y_back, yin) <= 2e-5 * scale + 8 * _floor(g, "y", n), (name, n, "round trip")
 
 
 @pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 4099])
@@ -76,7 +106,7 @@ def test_rq_no_tails_raises_outside_domain(device):
     t, _ = build_case("rq_coupling_no_tails_d6_k10")
     t = t.to(device)
     x = torch.rand(16, 6, device=device)
-    x[3, 1] = 1.5  # a transformed column (odd index) outside [0, 1]
+    x[3, 0] = 1.5  # column 0 is transformed (mask > 0 on even indices) and now outside [0, 1]
     with pytest.raises(InputOutsideDomain):
         with torch.no_grad():
             t(x)
