@@ -17,6 +17,8 @@
 namespace fc {
 
 struct AffineOp {
+  static constexpr bool kHasPrepare = false;
+  __device__ void prepare(float*, int, int) const {}
   int act;      // FC_AFFINE_*
   int inverse;
 

@@ -1,0 +1,323 @@
+// Row-per-wavefront bijectors with batch-shared (or per-sample) dense parameters, gfx950.
+//
+// One 64-lane wave owns one sample row; lane l holds elements l, l+64, l+128, ... of the row in
+// registers (E <= 8 registers, D <= 512).  Dot products are 64-lane butterflies (__shfl_xor),
+// mat-vecs broadcast x_j with v_readlane and FMA a contiguous weight column per lane, so the row
+// never leaves registers between the fused stages.  HBM traffic is the minimum: the row in, the
+// row out, one logabsdet word -- parameters are a few KB and live in L1/L2.
+//
+// Restates (not copies):
+//   flowcon/transforms/orthogonal.py:144-194       K Householder reflections
+//   flowcon/transforms/no_analytic_inv/planar.py:30-69     planar flow + constrained u
+//   flowcon/transforms/no_analytic_inv/planar.py:144-166   Sylvester flow (Householder Q, tanh)
+//   flowcon/transforms/lu.py:56-91                 LU linear forward / triangular-solve inverse
+//   flowcon/transforms/linear.py:45-76             cached dense weight / inverse path
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/flowcon_hip.h"
+
+namespace fc {
+
+constexpr int kWavesPerBlock = 4;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int E>
+struct Row {
+  float v[E];
+};
+
+template <int E>
+__device__ __forceinline__ void load_row(Row<E>& r, const float* __restrict__ p, int d, int lane) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = lane + 64 * e;
+    r.v[e] = i < d ? p[i] : 0.f;
+  }
+}
+
+template <int E>
+__device__ __forceinline__ void store_row(const Row<E>& r, float* __restrict__ p, int d, int lane) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = lane + 64 * e;
+    if (i < d) p[i] = r.v[e];
+  }
+}
+
+template <int E>
+__device__ __forceinline__ float dot_rows(const Row<E>& a, const Row<E>& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) s += a.v[e] * b.v[e];
+  return wave_sum(s);
+}
+
+// x_j for a wave-uniform j: element j lives in register j/64 of lane j%64
+template <int E>
+__device__ __forceinline__ float bcast(const Row<E>& r, int j) {
+  float out = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    // j is wave-uniform: v_readlane, no LDS traffic
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.v[e]), j & 63));
+    if ((j >> 6) == e) out = c;
+  }
+  return out;
+}
+
+// out -= (out . q) * (2 / |q|^2) * q, K times (orthogonal.py:144-171).
+// q: [K, d] shared, or this row's [K, d] block when per-sample.  order: 0..K-1 or reversed.
+template <int E>
+__device__ __forceinline__ void householder(Row<E>& x, const float* __restrict__ q, int k_count, int d,
+                                            int lane, bool reverse) {
+  for (int t = 0; t < k_count; ++t) {
+    const int k = reverse ? k_count - 1 - t : t;
+    Row<E> qv;
+    load_row<E>(qv, q + (int64_t)k * d, d, lane);
+    const float sq = dot_rows<E>(qv, qv);
+    const float ip = dot_rows<E>(x, qv);
+    const float c = 2.f / sq;
+#pragma unroll
+    for (int e = 0; e < E; ++e) x.v[e] = x.v[e] - ip * (c * qv.v[e]);
+  }
+}
+
+// y_i = sum_j W[i][j] x_j with Wt = W^T stored [d_in][d_out] (lane i reads a contiguous column)
+template <int E>
+__device__ __forceinline__ void matvec(Row<E>& y, const Row<E>& x, const float* __restrict__ wt, int d,
+                                       int lane, int j_lo_is_i /*1: upper-triangular W (skip j<i)*/) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) y.v[e] = 0.f;
+  for (int j = 0; j < d; ++j) {
+    const float xj = bcast<E>(x, j);
+    const float* col = wt + (int64_t)j * d;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = lane + 64 * e;
+      if (i < d) y.v[e] += col[i] * xj;
+    }
+  }
+}
+
+// ---- kernels ----------------------------------------------------------------------------
+
+template <int E>
+__global__ __launch_bounds__(256) void householder_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const float* __restrict__ q, int64_t n, int d,
+                                                          int k_count, int per_sample, int reverse) {
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < n; row += stride) {
+    Row<E> r;
+    load_row<E>(r, x + row * d, d, lane);
+    const float* qr = per_sample ? q + row * (int64_t)k_count * d : q;
+    householder<E>(r, qr, k_count, d, lane, reverse != 0);
+    store_row<E>(r, y + row * d, d, lane);
+  }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void planar_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                     float* __restrict__ lad, const float* __restrict__ w,
+                                                     const float* __restrict__ u_hat, const float* __restrict__ b_ptr,
+                                                     int64_t n, int d) {
+  const float b = b_ptr[0];
+  const int lane = threadIdx.x & 63;
+  Row<E> wv, uv;
+  load_row<E>(wv, w, d, lane);
+  load_row<E>(uv, u_hat, d, lane);
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < n; row += stride) {
+    Row<E> r;
+    load_row<E>(r, x + row * d, d, lane);
+    const float a = dot_rows<E>(r, wv) + b;   // mm(inputs, w.T) + b
+    const float t = tanhf(a);
+    const float dt = 1.f - t * t;
+    // abs_det = |1 + sum_j u_j * ((1 - tanh^2 a) * w_j)|  (planar.py:43-48)
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      s += uv.v[e] * (dt * wv.v[e]);
+      r.v[e] = r.v[e] + uv.v[e] * t;
+    }
+    s = wave_sum(s);
+    store_row<E>(r, y + row * d, d, lane);
+    if (lane == 0 && lad) lad[row] = logf(1e-7f + fabsf(1.f + s));
+  }
+}
+
+// mode 0: y = W x + bias (Wt given)               -- linear.py:45-52 cached path, lu.py:56-68
+// mode 1: y = L (U x) + bias (Ut, Lt given)        -- lu.py:56-68 (two F.linear)
+// mode 2: y = U^-1 L^-1 (x - bias), L unit-lower   -- lu.py:70-91 (two solve_triangular)
+template <int E>
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                     const float* __restrict__ at, const float* __restrict__ bt,
+                                                     const float* __restrict__ bias, int64_t n, int d, int mode) {
+  const int lane = threadIdx.x & 63;
+  Row<E> bv;
+  if (bias) load_row<E>(bv, bias, d, lane);
+  else {
+#pragma unroll
+    for (int e = 0; e < E; ++e) bv.v[e] = 0.f;
+  }
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < n; row += stride) {
+    Row<E> r, t;
+    load_row<E>(r, x + row * d, d, lane);
+    if (mode == 0) {
+      matvec<E>(t, r, at, d, lane, 0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) r.v[e] = t.v[e] + bv.v[e];
+    } else if (mode == 1) {
+      matvec<E>(t, r, at, d, lane, 1);   // U x
+      matvec<E>(r, t, bt, d, lane, 0);   // L (U x)
+#pragma unroll
+      for (int e = 0; e < E; ++e) r.v[e] = r.v[e] + bv.v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) r.v[e] = r.v[e] - bv.v[e];
+      // forward substitution with unit-lower L: bt = L^T, i.e. bt[j*d + i] = L[i][j]
+      for (int j = 0; j < d; ++j) {
+        const float xj = bcast<E>(r, j);
+        const float* col = bt + (int64_t)j * d;  // column j of L
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = lane + 64 * e;
+          if (i > j && i < d) r.v[e] -= col[i] * xj;
+        }
+      }
+      // back substitution with U: column j of U
+      for (int j = d - 1; j >= 0; --j) {
+        const float* col = at + (int64_t)j * d;
+        const float ujj = col[j];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = lane + 64 * e;
+          if (i == j) r.v[e] = r.v[e] / ujj;
+        }
+        const float xj = bcast<E>(r, j);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = lane + 64 * e;
+          if (i < j) r.v[e] -= col[i] * xj;
+        }
+      }
+    }
+    store_row<E>(r, y + row * d, d, lane);
+  }
+}
+
+// Sylvester flow, fused (planar.py:144-166):
+//   Qtz = Householder^-1(z); pre = R1 Qtz + b; act = tanh(pre); out = z + Householder(R2 act)
+//   logdet = sum_j log(1 + (1 - act_j^2) * diag(R1)_j * diag(R2)_j)
+template <int E>
+__global__ __launch_bounds__(256) void sylvester_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        float* __restrict__ lad, const float* __restrict__ q,
+                                                        const float* __restrict__ r1t, const float* __restrict__ r2t,
+                                                        const float* __restrict__ bias, const float* __restrict__ rdiag,
+                                                        int64_t n, int d, int m, int per_sample) {
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < n; row += stride) {
+    Row<E> z, t, a;
+    load_row<E>(z, x + row * d, d, lane);
+    const float* qr = per_sample ? q + row * (int64_t)m * d : q;
+    const float* r1 = per_sample ? r1t + row * (int64_t)d * d : r1t;
+    const float* r2 = per_sample ? r2t + row * (int64_t)d * d : r2t;
+    const float* bb = per_sample ? bias + row * (int64_t)d : bias;
+    const float* rd = per_sample ? rdiag + row * (int64_t)d : rdiag;
+    t = z;
+    householder<E>(t, qr, m, d, lane, true);          // Q^T z
+    matvec<E>(a, t, r1, d, lane, 1);                   // R1 Q^T z
+    float ld = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = lane + 64 * e;
+      if (i < d) {
+        const float act = tanhf(a.v[e] + bb[i]);
+        a.v[e] = act;
+        ld += logf(1.f + (1.f - act * act) * rd[i]);
+      } else {
+        a.v[e] = 0.f;
+      }
+    }
+    ld = wave_sum(ld);
+    matvec<E>(t, a, r2, d, lane, 1);                   // R2 act
+    householder<E>(t, qr, m, d, lane, false);          // Q R2 act
+#pragma unroll
+    for (int e = 0; e < E; ++e) z.v[e] = z.v[e] + t.v[e];
+    store_row<E>(z, y + row * d, d, lane);
+    if (lane == 0 && lad) lad[row] = ld;
+  }
+}
+
+inline unsigned row_grid(int64_t n) {
+  int64_t g = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t cap = 256 * 8;
+  if (g > cap) g = cap;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+inline int elems_for(int d) { return d <= 64 ? 1 : d <= 128 ? 2 : d <= 256 ? 4 : 8; }
+
+}  // namespace fc
+
+#define FC_ROW_DISPATCH(D, CALL)                  \
+  switch (fc::elems_for(D)) {                     \
+    case 1: { constexpr int E = 1; CALL; break; } \
+    case 2: { constexpr int E = 2; CALL; break; } \
+    case 4: { constexpr int E = 4; CALL; break; } \
+    default: { constexpr int E = 8; CALL; break; } \
+  }
+
+extern "C" int fc_householder(const float* x, float* y, const float* q, int64_t n, int32_t d,
+                              int32_t num_transforms, int32_t per_sample, int32_t reverse, void* stream) {
+  if (n < 0 || d <= 0 || d > 512 || num_transforms < 0) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!x || !y || (!q && num_transforms > 0)) return hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::householder_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x, y,
+                                        q, n, d, num_transforms, per_sample, reverse));
+  return hipGetLastError();
+}
+
+extern "C" int fc_planar(const float* x, float* y, float* logabsdet, const float* w, const float* u_hat,
+                         const float* b, int64_t n, int32_t d, void* stream) {
+  if (n < 0 || d <= 0 || d > 512) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!x || !y || !w || !u_hat || !b) return hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::planar_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x, y,
+                                        logabsdet, w, u_hat, b, n, d));
+  return hipGetLastError();
+}
+
+extern "C" int fc_linear(const float* x, float* y, const float* a_t, const float* b_t, const float* bias,
+                         int64_t n, int32_t d, int32_t mode, void* stream) {
+  if (n < 0 || d <= 0 || d > 512 || mode < 0 || mode > 2) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!x || !y || !a_t || (mode != 0 && !b_t)) return hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::linear_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x, y, a_t,
+                                        b_t, bias, n, d, mode));
+  return hipGetLastError();
+}
+
+extern "C" int fc_sylvester(const float* x, float* y, float* logabsdet, const float* q, const float* r1_t,
+                            const float* r2_t, const float* bias, const float* r_diag_prod, int64_t n,
+                            int32_t d, int32_t num_householder, int32_t per_sample, void* stream) {
+  if (n < 0 || d <= 0 || d > 512 || num_householder < 0) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!x || !y || !r1_t || !r2_t || !bias || !r_diag_prod || (!q && num_householder > 0))
+    return hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::sylvester_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x, y,
+                                        logabsdet, q, r1_t, r2_t, bias, r_diag_prod, n, d, num_householder,
+                                        per_sample));
+  return hipGetLastError();
+}

@@ -108,6 +108,8 @@ __device__ __forceinline__ void walk_axis(const float* __restrict__ u, int K, fl
 
 template <int KS>
 struct RQOp {
+  static constexpr bool kHasPrepare = false;
+  __device__ void prepare(float*, int, int) const {}
   RQParams q;
   float inv_div;
   bool mul_exact;

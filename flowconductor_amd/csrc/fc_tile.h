@@ -87,6 +87,8 @@ __device__ __forceinline__ void emit_lad(float* p, float v, int mode) {
 // ---- the tile kernel ------------------------------------------------------------------
 //
 // Op interface:
+//   static constexpr bool kHasPrepare;
+//   __device__ void prepare(float* prow, int j, int d_t) const;      (only if kHasPrepare)
 //   __device__ void eval(const float* prow, int j, int d_t, float x,
 //                        float& y, float& lad, uint32_t& err) const;
 // prow = this sample's parameter row in LDS; the op knows its own layout.
@@ -114,6 +116,16 @@ __global__ __launch_bounds__(kMaxBlock) void tile_kernel(Op op, TileArgs a) {
   }
   copy_in<kVec>(xs, a.x + n0 * D, s_eff * D);
   __syncthreads();
+
+  if (Op::kHasPrepare) {
+    // once per staged (row, dim): turn raw parameters into derived ones in place (LDS)
+    const int rows = a.shared_params ? 1 : s_eff;
+    for (int e = threadIdx.x; e < rows * d_t; e += blockDim.x) {
+      const int s = e / d_t, j = e - s * d_t;
+      op.prepare(ps + s * rowlen, j, d_t);
+    }
+    __syncthreads();
+  }
 
   const int total = s_eff * d_t;
   const bool pow2 = (d_t & (d_t - 1)) == 0 && d_t <= 64;

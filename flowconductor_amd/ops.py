@@ -353,3 +353,164 @@ def batchnorm_eval(inputs, mean, std, weight, bias, inverse=False):
           _hip.ptr(vecs[0]), _hip.ptr(vecs[1]), _hip.ptr(vecs[2]), _hip.ptr(vecs[3]), n, m, m, m,
           3 if inverse else 2, _hip.stream_ptr(x.device))
     return y
+
+
+# ---- row-per-wavefront bijectors with dense parameters --------------------------------------------
+
+MAX_ROW_FEATURES = 512
+
+
+def _rows(inputs, name="inputs"):
+    x = _prep_2d(inputs, name)
+    if x.shape[1] > MAX_ROW_FEATURES:
+        raise ValueError("flowconductor_amd: %d features exceed the %d supported by the row kernels"
+                         % (x.shape[1], MAX_ROW_FEATURES))
+    return x
+
+
+def _param(t, device, name):
+    return _hip.dev_f32(torch.as_tensor(t).detach().to(device), name)
+
+
+def householder(inputs, q_vectors, reverse=False):
+    """Apply K Householder reflections (reference orthogonal.py:144-194).
+
+    ``q_vectors``: ``[K, D]`` shared across the batch or ``[N, K, D]`` per sample."""
+    lib = _hip.load()
+    x = _rows(inputs)
+    _hip.require_no_grad(inputs, q_vectors)
+    q = _param(q_vectors, x.device, "q_vectors")
+    n, d = x.shape
+    per_sample = q.dim() == 3
+    if q.shape[-1] != d or (per_sample and q.shape[0] != n) or q.dim() not in (2, 3):
+        raise ValueError("q_vectors of shape %s do not match inputs %s" % (tuple(q.shape), tuple(x.shape)))
+    y = torch.empty_like(x)
+    _call("fc_householder", lib.fc_householder, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(q), n, d,
+          q.shape[-2], 1 if per_sample else 0, 1 if reverse else 0, _hip.stream_ptr(x.device))
+    return y
+
+
+def planar(inputs, w, u_hat, b):
+    """Planar flow forward + logabsdet (reference no_analytic_inv/planar.py:30-49)."""
+    lib = _hip.load()
+    x = _rows(inputs)
+    _hip.require_no_grad(inputs)
+    n, d = x.shape
+    wv = _param(w, x.device, "w").reshape(-1)
+    uv = _param(u_hat, x.device, "u").reshape(-1)
+    bv = _param(b, x.device, "b").reshape(-1)
+    if wv.numel() != d or uv.numel() != d or bv.numel() != 1:
+        raise ValueError("planar parameters do not match %d features" % d)
+    y = torch.empty_like(x)
+    lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    _call("fc_planar", lib.fc_planar, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(lad), _hip.ptr(wv),
+          _hip.ptr(uv), _hip.ptr(bv), n, d, _hip.stream_ptr(x.device))
+    return y, lad
+
+
+LINEAR_DENSE, LINEAR_LU_FORWARD, LINEAR_LU_INVERSE = 0, 1, 2
+
+
+def linear(inputs, a, b=None, bias=None, mode=LINEAR_DENSE):
+    """Dense [D, D] maps on rows: ``A x + bias``; ``B (A x) + bias``; ``A^-1 B^-1 (x - bias)``
+    (reference linear.py:45-76, lu.py:56-91).  ``a``/``b`` are given untransposed."""
+    lib = _hip.load()
+    x = _rows(inputs)
+    _hip.require_no_grad(inputs)
+    n, d = x.shape
+    at = _param(a, x.device, "weight").t().contiguous()
+    bt = _param(b, x.device, "weight").t().contiguous() if b is not None else None
+    if at.shape != (d, d) or (bt is not None and bt.shape != (d, d)):
+        raise ValueError("weights must be [%d, %d]" % (d, d))
+    bv = _param(bias, x.device, "bias").reshape(-1) if bias is not None else None
+    y = torch.empty_like(x)
+    _call("fc_linear", lib.fc_linear, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(at), _hip.ptr(bt),
+          _hip.ptr(bv), n, d, mode, _hip.stream_ptr(x.device))
+    return y
+
+
+def sylvester(inputs, q_vectors, r1, r2, bias):
+    """Sylvester flow forward + logabsdet (reference no_analytic_inv/planar.py:144-166).
+
+    Shared parameters: ``q [M, D]``, ``r1``/``r2`` ``[D, D]`` upper triangular, ``bias [D]``;
+    per-sample: ``q [N, M, D]``, ``r1``/``r2`` ``[N, D, D]``, ``bias [N, D]``."""
+    lib = _hip.load()
+    x = _rows(inputs)
+    _hip.require_no_grad(inputs)
+    n, d = x.shape
+    q = _param(q_vectors, x.device, "q_vectors")
+    r1 = _param(r1, x.device, "R1")
+    r2 = _param(r2, x.device, "R2")
+    bv = _param(bias, x.device, "bias")
+    per_sample = r1.dim() == 3
+    if per_sample != (q.dim() == 3) or per_sample != (bv.dim() == 2):
+        raise ValueError("q, R1, R2 and bias must all be shared or all be per-sample")
+    rdiag = (torch.diagonal(r1, dim1=-2, dim2=-1) * torch.diagonal(r2, dim1=-2, dim2=-1)).contiguous()
+    r1t = r1.transpose(-1, -2).contiguous()
+    r2t = r2.transpose(-1, -2).contiguous()
+    y = torch.empty_like(x)
+    lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    _call("fc_sylvester", lib.fc_sylvester, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(lad), _hip.ptr(q),
+          _hip.ptr(r1t), _hip.ptr(r2t), _hip.ptr(bv), _hip.ptr(rdiag), n, d, q.shape[-2],
+          1 if per_sample else 0, _hip.stream_ptr(x.device))
+    return y, lad
+
+
+# ---- element-wise non-linearities -----------------------------------------------------------------
+
+EW_EXP, EW_TANH, EW_LOGTANH, EW_LEAKY_RELU, EW_SIGMOID, EW_SOFTPLUS, EW_CAUCHY_CDF = range(7)
+EW_EXTENDED_SOFTPLUS, EW_GLU = 7, 8
+
+
+def elementwise(inputs, kind, inverse=False, aux=None, p=(0.0, 0.0, 0.0, 0.0), row_sum=True,
+                elem_lad=False, may_raise=False):
+    """Element-wise bijector ``kind`` (``FC_EW_*``) over ``[N, ...]`` inputs.
+
+    Returns ``(outputs, logabsdet)`` with ``logabsdet`` summed over everything but the batch dim
+    (``row_sum``) or left per element (``elem_lad``)."""
+    lib = _hip.load()
+    x = _hip.dev_f32(inputs, "inputs")
+    _hip.require_no_grad(inputs)
+    n = x.shape[0]
+    m = 1
+    for s in x.shape[1:]:
+        m *= s
+    if aux is not None:
+        aux = _hip.dev_f32(torch.as_tensor(aux).detach().to(x.device), "parameter")
+    y = torch.empty_like(x)
+    lad_row = torch.empty(n, dtype=torch.float32, device=x.device) if row_sum else None
+    lad_el = torch.empty_like(x) if elem_lad else None
+    err = _err_word(x.device, may_raise)
+    p = tuple(float(v) for v in p) + (0.0,) * (4 - len(p))
+    _call("fc_elementwise", lib.fc_elementwise, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(lad_row),
+          _hip.ptr(lad_el), _hip.ptr(aux), _hip.ptr(err), n, m, kind, 1 if inverse else 0, p[0], p[1], p[2],
+          p[3], _hip.stream_ptr(x.device))
+    _finish(may_raise)
+    return y, (lad_el if elem_lad else lad_row)
+
+
+# ---- sum of sigmoids ------------------------------------------------------------------------------
+
+def sum_of_sigmoids(inputs, raw_params, n_sigmoids, inverse=False, offset=0.0, iterations=50, lim=120.0,
+                    log_scale_postact=0.0, shared_params=False):
+    """Sum-of-sigmoids bijector (reference adaptive_sigmoids.py:108-142; inverse base.py:23-83).
+
+    ``raw_params``: ``[N, D, 3S+1]`` per-sample rows, or ``[D, 3S+1]`` with ``shared_params``."""
+    lib = _hip.load()
+    x = _prep_2d(inputs)
+    p = _hip.dev_f32(raw_params, "raw_params")
+    _hip.require_no_grad(inputs, raw_params)
+    n, d = x.shape
+    rowlen = d * (3 * n_sigmoids + 1)
+    want = rowlen if shared_params else n * rowlen
+    if p.numel() != want:
+        raise ValueError("raw_params has %d elements, expected %d" % (p.numel(), want))
+    y = torch.empty_like(x)
+    lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    err = _err_word(x.device, inverse)
+    _call("fc_sum_of_sigmoids", lib.fc_sum_of_sigmoids, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(p), None,
+          _hip.ptr(lad), _hip.ptr(err), n, d, d, n_sigmoids, 1 if inverse else 0, int(iterations), float(lim),
+          float(offset), float(log_scale_postact), 1 if shared_params else 0, LAD_STORE,
+          _hip.stream_ptr(x.device))
+    _finish(inverse)
+    return y, lad

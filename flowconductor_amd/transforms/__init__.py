@@ -3,6 +3,7 @@ from flowconductor_amd.transforms.autoregressive import (  # noqa: F401
     MaskedAffineAutoregressiveTransform,
     MaskedPiecewiseRationalQuadraticAutoregressiveTransform,
     MaskedShiftAutoregressiveTransform,
+    MaskedSumOfSigmoidsTransform,
 )
 from flowconductor_amd.transforms.base import (  # noqa: F401
     CompositeTransform,
@@ -17,10 +18,31 @@ from flowconductor_amd.transforms.coupling import (  # noqa: F401
     CouplingTransform,
     PiecewiseRationalQuadraticCouplingTransform,
 )
-from flowconductor_amd.transforms.nonlinearities import (  # noqa: F401
-    CompositeCDFTransform,
-    PiecewiseRationalQuadraticCDF,
+from flowconductor_amd.transforms.adaptive_sigmoids import SumOfSigmoids  # noqa: F401
+from flowconductor_amd.transforms.linear import Linear  # noqa: F401
+from flowconductor_amd.transforms.lu import LULinear  # noqa: F401
+from flowconductor_amd.transforms.no_analytic_inv import (  # noqa: F401
+    MonotonicTransform,
+    PlanarTransform,
+    SylvesterTransform,
 )
+from flowconductor_amd.transforms.nonlinearities import (  # noqa: F401
+    CauchyCDF,
+    CauchyCDFInverse,
+    CompositeCDFTransform,
+    Exp,
+    ExtendedSoftplus,
+    GatedLinearUnit,
+    LeakyReLU,
+    Logit,
+    LogTanh,
+    PiecewiseRationalQuadraticCDF,
+    Sigmoid,
+    Softplus,
+    Tanh,
+)
+from flowconductor_amd.transforms.normalization import ActNorm, BatchNorm  # noqa: F401
+from flowconductor_amd.transforms.orthogonal import HouseholderSequence, ParametrizedHouseHolder  # noqa: F401
 from flowconductor_amd.transforms.permutations import (  # noqa: F401
     Permutation,
     RandomPermutation,

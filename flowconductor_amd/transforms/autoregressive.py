@@ -157,3 +157,26 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
 
     def _elementwise_inverse(self, inputs, autoregressive_params):
         return self._elementwise(inputs, autoregressive_params, inverse=True)
+
+
+class MaskedSumOfSigmoidsTransform(AutoregressiveTransform):
+    """Sum-of-sigmoids AR layer (autoregressive.py:266-318): MADE emits 3S+1 raw values per feature;
+    forward returns z - 0.5, the inverse first adds 0.5 back."""
+
+    def __init__(self, features, hidden_features, n_sigmoids=30, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu, dropout_probability=0.0,
+                 use_batch_norm=False):
+        self.features = features
+        self.n_sigmoids = n_sigmoids
+        made = _made(self, features, hidden_features, context_features, num_blocks, use_residual_blocks,
+                     random_mask, activation, dropout_probability, use_batch_norm)
+        super().__init__(made)
+
+    def _output_dim_multiplier(self):
+        return 3 * self.n_sigmoids + 1
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        return ops.sum_of_sigmoids(inputs, autoregressive_params, self.n_sigmoids, inverse=False, offset=0.5)
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        return ops.sum_of_sigmoids(inputs, autoregressive_params, self.n_sigmoids, inverse=True, offset=0.5)

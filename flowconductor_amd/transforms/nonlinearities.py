@@ -7,6 +7,135 @@ from flowconductor_amd import ops
 from flowconductor_amd.transforms.base import CompositeTransform, InverseTransform, Transform
 
 
+class Exp(Transform):
+    def forward(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_EXP)
+
+    def inverse(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_EXP, inverse=True, may_raise=True)
+
+
+class Tanh(Transform):
+    def forward(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_TANH)
+
+    def inverse(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_TANH, inverse=True, may_raise=True)
+
+
+class LogTanh(Transform):
+    """Tanh with unbounded output: beyond +-cut_point it continues as +-alpha*log(beta*|x|), with
+    alpha, beta matching value and slope of tanh at the cut point (nonlinearities.py:51-112)."""
+
+    def __init__(self, cut_point=1):
+        if cut_point <= 0:
+            raise ValueError("Cut point must be positive.")
+        super().__init__()
+        self.cut_point = cut_point
+        self.inv_cut_point = np.tanh(cut_point)
+        self.alpha = (1 - np.tanh(np.tanh(cut_point))) / cut_point
+        self.beta = np.exp((np.tanh(cut_point) - self.alpha * np.log(cut_point)) / self.alpha)
+
+    def _p(self):
+        return (self.cut_point, self.alpha, self.beta, self.inv_cut_point)
+
+    def forward(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_LOGTANH, p=self._p())
+
+    def inverse(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_LOGTANH, inverse=True, p=self._p())
+
+
+class LeakyReLU(Transform):
+    def __init__(self, negative_slope=1e-2):
+        if negative_slope <= 0:
+            raise ValueError("Slope must be positive.")
+        super().__init__()
+        self.negative_slope = negative_slope
+        self.log_negative_slope = torch.nn.Parameter(torch.log(torch.as_tensor(self.negative_slope)))
+
+    def _p(self):
+        return (self.negative_slope, 1 / self.negative_slope)
+
+    def forward(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_LEAKY_RELU, aux=self.log_negative_slope.reshape(1), p=self._p())
+
+    def inverse(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_LEAKY_RELU, inverse=True, aux=self.log_negative_slope.reshape(1),
+                               p=self._p())
+
+
+class Sigmoid(Transform):
+    def __init__(self, temperature=1, eps=1e-6, learn_temperature=False):
+        super().__init__()
+        self.eps = eps
+        if learn_temperature:
+            self.temperature = nn.Parameter(torch.Tensor([temperature]))
+        else:
+            self.register_buffer("temperature", torch.Tensor([temperature]))
+
+    def forward(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_SIGMOID, aux=self.temperature, p=(self.eps,))
+
+    def inverse(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_SIGMOID, inverse=True, aux=self.temperature, p=(self.eps,),
+                               may_raise=True)
+
+
+class Softplus(Transform):
+    """softplus(x) + eps; logabsdet = sum logsigmoid(x) (nonlinearities.py:172-189)."""
+
+    def __init__(self, threshold=20, eps=0.):
+        super().__init__()
+        self.eps = eps
+        self.softplus = torch.nn.Softplus(beta=1, threshold=threshold)
+        self.log_sigmoid = torch.nn.LogSigmoid()
+
+    def forward(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_SOFTPLUS, p=(self.softplus.threshold, self.eps))
+
+    def inverse(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_SOFTPLUS, inverse=True, p=(self.softplus.threshold, self.eps))
+
+
+class Logit(InverseTransform):
+    def __init__(self, temperature=1, eps=1e-6):
+        super().__init__(Sigmoid(temperature=temperature, eps=eps))
+
+
+class GatedLinearUnit(Transform):
+    """y = x * sigmoid(context); logabsdet = log sigmoid(context) flattened (1-feature inputs)."""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, inputs, context=None):
+        y, lad = ops.elementwise(inputs, ops.EW_GLU, aux=context.expand_as(inputs).contiguous(), row_sum=False,
+                                 elem_lad=True)
+        return y, lad.reshape(-1)
+
+    def inverse(self, inputs, context=None):
+        y, lad = ops.elementwise(inputs, ops.EW_GLU, inverse=True, aux=context.expand_as(inputs).contiguous(),
+                                 row_sum=False, elem_lad=True)
+        return y, lad.reshape(-1)
+
+
+class CauchyCDF(Transform):
+    def __init__(self, location=None, scale=None, features=None):
+        super().__init__()
+
+    def forward(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_CAUCHY_CDF)
+
+    def inverse(self, inputs, context=None):
+        return ops.elementwise(inputs, ops.EW_CAUCHY_CDF, inverse=True, may_raise=True)
+
+
+class CauchyCDFInverse(InverseTransform):
+    def __init__(self, location=None, scale=None, features=None):
+        super().__init__(CauchyCDF(location=location, scale=scale, features=features))
+
+
 class CompositeCDFTransform(CompositeTransform):
     """squash -> cdf -> unsquash (nonlinearities.py:239-243)."""
 
@@ -65,3 +194,30 @@ class PiecewiseRationalQuadraticCDF(Transform):
 
     def inverse(self, inputs, context=None):
         return self._spline(inputs, inverse=True)
+
+
+class ExtendedSoftplus(torch.nn.Module):
+    """softplus(x - s) - softplus(-(x + s)) with s = softplus(shift) + 0.1: linear far from the
+    origin, flat around it.  ``forward`` returns (outputs, element-wise log-derivative)
+    (nonlinearities.py:490-552).  Helper of SumOfSigmoids, which fuses it into its own kernel."""
+
+    def __init__(self, features, shift=None):
+        self.features = features
+        super().__init__()
+        if shift is None:
+            self.shift = torch.nn.Parameter(torch.ones(1, features) * 3, requires_grad=True)
+        elif torch.is_tensor(shift):
+            self.shift = shift.reshape(-1, features)
+        else:
+            self.shift = torch.nn.Parameter(torch.tensor(shift), requires_grad=True)
+        self._softplus = torch.nn.Softplus()
+
+    def get_shift(self):
+        return self._softplus(self.shift) + 1e-1
+
+    def forward(self, inputs):
+        shift = self.shift.detach()
+        if shift.shape[0] != 1:
+            raise NotImplementedError("per-sample ExtendedSoftplus runs inside the SumOfSigmoids kernel")
+        return ops.elementwise(inputs, ops.EW_EXTENDED_SOFTPLUS, aux=shift.reshape(-1), row_sum=False,
+                               elem_lad=True)

@@ -1,0 +1,117 @@
+"""Normalisation transforms (API of flowcon/transforms/normalization.py:72-218).
+
+The point-wise maps run in ``fc_pointwise_affine``; batch statistics (BatchNorm in training
+mode, ActNorm's one-off data-dependent initialisation) are cross-batch reductions outside the
+bijector hot path and use torch reductions on the device.
+"""
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from flowconductor_amd import ops
+from flowconductor_amd.transforms.base import InverseNotAvailable, Transform
+from flowconductor_amd.utils import typechecks as check
+
+
+class BatchNorm(Transform):
+    """Batch normalisation for 1-dim inputs; the inverse exists in eval mode only."""
+
+    def __init__(self, features, eps=1e-5, momentum=0.1, affine=True):
+        if not check.is_positive_int(features):
+            raise TypeError("Number of features must be a positive integer.")
+        super().__init__()
+        self.momentum = momentum
+        self.eps = eps
+        constant = np.log(np.exp(1 - eps) - 1)
+        self.unconstrained_weight = nn.Parameter(constant * torch.ones(features))
+        self.bias = nn.Parameter(torch.zeros(features))
+        self.register_buffer("running_mean", torch.zeros(features))
+        self.register_buffer("running_var", torch.zeros(features))
+
+    @property
+    def weight(self):
+        return F.softplus(self.unconstrained_weight) + self.eps
+
+    @staticmethod
+    def _check(inputs):
+        if inputs.dim() != 2:
+            raise ValueError("Expected 2-dim inputs, got inputs of shape: {}".format(inputs.shape))
+
+    def forward(self, inputs, context=None):
+        self._check(inputs)
+        if self.training:
+            with torch.no_grad():
+                mean, var = inputs.mean(0), inputs.var(0)
+                self.running_mean.mul_(1 - self.momentum).add_(mean * self.momentum)
+                self.running_var.mul_(1 - self.momentum).add_(var * self.momentum)
+        else:
+            mean, var = self.running_mean, self.running_var
+        weight = self.weight.detach()
+        outputs = ops.batchnorm_eval(inputs, mean, torch.sqrt(var + self.eps), weight, self.bias.detach())
+        logabsdet_ = torch.log(weight) - 0.5 * torch.log(var + self.eps)
+        return outputs, torch.sum(logabsdet_) * inputs.new_ones(inputs.shape[0])
+
+    def inverse(self, inputs, context=None):
+        if self.training:
+            raise InverseNotAvailable(
+                "Batch norm inverse is only available in eval mode, not in training mode.")
+        self._check(inputs)
+        weight = self.weight.detach()
+        outputs = ops.batchnorm_eval(inputs, self.running_mean, torch.sqrt(self.running_var + self.eps),
+                                     weight, self.bias.detach(), inverse=True)
+        logabsdet_ = -torch.log(weight) + 0.5 * torch.log(self.running_var + self.eps)
+        return outputs, torch.sum(logabsdet_) * inputs.new_ones(inputs.shape[0])
+
+
+class ActNorm(Transform):
+    """Activation normalisation (Glow) for [N, D] and [N, C, H, W] inputs, per feature/channel.
+
+    The first forward call in training mode initialises ``log_scale``/``shift`` from the batch so
+    that outputs have zero mean and unit variance, and flips the ``initialized`` buffer."""
+
+    def __init__(self, features):
+        if not check.is_positive_int(features):
+            raise TypeError("Number of features must be a positive integer.")
+        super().__init__()
+        self.register_buffer("initialized", torch.tensor(False, dtype=torch.bool))
+        self.log_scale = nn.Parameter(torch.zeros(features))
+        self.shift = nn.Parameter(torch.zeros(features))
+
+    @property
+    def scale(self):
+        return torch.exp(self.log_scale)
+
+    def _broadcastable_scale_shift(self, inputs):
+        if inputs.dim() == 4:
+            return self.scale.view(1, -1, 1, 1), self.shift.view(1, -1, 1, 1)
+        return self.scale.view(1, -1), self.shift.view(1, -1)
+
+    def _run(self, inputs, inverse):
+        if inputs.dim() not in [2, 4]:
+            raise ValueError("Expecting inputs to be a 2D or a 4D tensor.")
+        if not inverse and self.training and not self.initialized:
+            self._initialize(inputs)
+        scale, shift = self._broadcastable_scale_shift(inputs)
+        outputs = ops.pointwise_affine(inputs, scale.detach()[0], shift.detach()[0], inverse=inverse)
+        total = torch.sum(self.log_scale.detach())
+        if inputs.dim() == 4:
+            total = inputs.shape[2] * inputs.shape[3] * total
+        logabsdet = total * outputs.new_ones(inputs.shape[0])
+        return outputs, (-logabsdet if inverse else logabsdet)
+
+    def forward(self, inputs, context=None):
+        return self._run(inputs, inverse=False)
+
+    def inverse(self, inputs, context=None):
+        return self._run(inputs, inverse=True)
+
+    def _initialize(self, inputs):
+        if inputs.dim() == 4:
+            inputs = inputs.permute(0, 2, 3, 1).reshape(-1, inputs.shape[1])
+        with torch.no_grad():
+            std = inputs.std(dim=0)
+            mu = (inputs / std).mean(dim=0)
+            self.log_scale.data = -torch.log(std)
+            self.shift.data = -mu
+            self.initialized.data = torch.tensor(True, dtype=torch.bool)

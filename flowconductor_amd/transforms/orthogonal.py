@@ -1,0 +1,79 @@
+"""Orthogonal transforms built from Householder reflections (API of flowcon/transforms/orthogonal.py)."""
+import torch
+from torch import nn
+
+from flowconductor_amd import ops
+from flowconductor_amd.transforms.base import Transform
+from flowconductor_amd.utils import typechecks as check
+
+
+def _paired_unit_vectors(num_transforms, features):
+    """Initial q-vectors of the reference (orthogonal.py:40-61): e_0, e_0, e_1, e_1, ... (each unit
+    vector twice, so the product of reflections starts as the identity), plus e_{K//2} when K is odd."""
+    half = num_transforms // 2
+    qv = torch.eye(half, features).repeat_interleave(2, dim=0) if half > 0 else torch.zeros(0, features)
+    if num_transforms % 2 != 0:
+        last = torch.zeros(1, features)
+        last[0, half] = 1
+        qv = torch.cat((qv, last))
+    return qv
+
+
+def _apply(inputs, q_vectors, reverse):
+    outputs = ops.householder(inputs, q_vectors, reverse=reverse)
+    return outputs, inputs.new_zeros(inputs.shape[0])
+
+
+class HouseholderSequence(Transform):
+    """A sequence of Householder transforms with a learnable ``q_vectors [K, D]`` parameter."""
+
+    def __init__(self, features, num_transforms):
+        if not check.is_positive_int(features):
+            raise TypeError("Number of features must be a positive integer.")
+        if not check.is_positive_int(num_transforms):
+            raise TypeError("Number of transforms must be a positive integer.")
+        super().__init__()
+        self.features = features
+        self.num_transforms = num_transforms
+        self.q_vectors = nn.Parameter(_paired_unit_vectors(num_transforms, features))
+
+    def forward(self, inputs, context=None):
+        return _apply(inputs, self.q_vectors, reverse=False)
+
+    def inverse(self, inputs, context=None):
+        # each reflection is its own inverse: apply them in reverse order
+        return _apply(inputs, self.q_vectors, reverse=True)
+
+    def matrix(self):
+        """The [D, D] orthogonal matrix of the whole sequence (inverse applied to the identity)."""
+        identity = torch.eye(self.features, self.features, device=self.q_vectors.device)
+        outputs, _ = self.inverse(identity)
+        return outputs
+
+
+class ParametrizedHouseHolder(Transform):
+    """Householder sequence with externally supplied q-vectors: ``[K, D]`` or per-sample ``[N, K, D]``."""
+
+    def __init__(self, q_vectors):
+        super().__init__()
+        self.features = q_vectors.shape[-1]
+        self.num_transforms = q_vectors.shape[-2]
+        self.q_vectors = q_vectors
+        self.reverse_idx = torch.arange(self.num_transforms - 1, -1, -1).to(q_vectors.device)
+
+    def forward(self, inputs, context=None):
+        return _apply(inputs, self.q_vectors, reverse=False)
+
+    def inverse(self, inputs, context=None):
+        return _apply(inputs, self.q_vectors, reverse=True)
+
+    def matrix(self):
+        """[D, D] (or per-sample [N, D, D]) matrix: row i is the inverse applied to e_i."""
+        identity = torch.eye(self.features, self.features).to(self.q_vectors.device)
+        if len(self.q_vectors.shape) > 2:
+            identity = torch.repeat_interleave(identity[None, ...], self.q_vectors.shape[0], 0)
+        rows = []
+        for i in range(self.features):
+            out, _ = self.inverse(identity[..., i, :].reshape(-1, self.features))
+            rows.append(out.reshape(identity[..., i, :].shape).unsqueeze(-2))
+        return torch.cat(rows, -2)

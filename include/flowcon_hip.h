@@ -108,6 +108,69 @@ int fc_pointwise_affine(const float* x, float* y, const float* scale, const floa
                         const float* aux_mean, const float* aux_weight, int64_t n, int64_t m,
                         int32_t scale_len, int32_t shift_len, int32_t mode, void* stream);
 
+/* ---- element-wise non-linearities -------------------------------------------------------------- */
+#define FC_EW_EXP 0              /* nonlinearities.py:18-32 */
+#define FC_EW_TANH 1             /* :35-48 */
+#define FC_EW_LOGTANH 2          /* :51-112   p0 cut_point, p1 alpha, p2 beta, p3 tanh(cut_point) */
+#define FC_EW_LEAKY_RELU 3       /* :115-136  p0 slope, p1 1/slope, aux[0] = log_negative_slope */
+#define FC_EW_SIGMOID 4          /* :139-169  p0 eps, aux[0] = temperature */
+#define FC_EW_SOFTPLUS 5         /* :172-189  p0 threshold, p1 eps */
+#define FC_EW_CAUCHY_CDF 6       /* :212-231 */
+#define FC_EW_EXTENDED_SOFTPLUS 7 /* :519-552 aux[m] = raw shift; logabsdet_elem = log diag-jacobian */
+#define FC_EW_GLU 8              /* :197-209  aux[n, m] = context; gate = sigmoid(context) */
+
+/* x, y viewed as [n, m].  logabsdet_row[i] = sum over the m elements of row i (NULL to skip);
+ * logabsdet_elem [n, m] receives the un-summed values (NULL to skip).  Domain violations of the
+ * inverses OR FC_ERR_OUTSIDE_DOMAIN into err_flag (InputOutsideDomain, nonlinearities.py:26,43,158,224). */
+int fc_elementwise(const float* x, float* y, float* logabsdet_row, float* logabsdet_elem,
+                   const float* aux, uint32_t* err_flag, int64_t n, int64_t m, int32_t kind,
+                   int32_t inverse, float p0, float p1, float p2, float p3, void* stream);
+
+/* ---- sum of sigmoids ------------------------------------------------------------------------ */
+/* Monotone bijector y = sum_k w_k sigmoid(a_k (x - s_k)) / sum_k w_k + extended_softplus(x) - offset
+ * with per-(sample, dim) raw rows [S shift | S log_scale | S raw_softmax | 1 softplus shift]
+ * (rowlen = d_t * (3S + 1)); logabsdet = sum_j logaddexp(log-jac sigmoids, log-jac softplus).
+ * inverse != 0: x = f^-1(y + offset) by per-element bracket + `bisection_iterations` bisection
+ * steps from [-lim, lim] + 2 Newton steps, logabsdet = -log f'(x).
+ * Replaces SumOfSigmoids.forward (adaptive_sigmoids.py:108-142) with ExtendedSoftplus
+ * (nonlinearities.py:519-552), MonotonicTransform.inverse (no_analytic_inv/base.py:23-103) and
+ * MaskedSumOfSigmoidsTransform._elementwise_{forward,inverse} (autoregressive.py:301-318). */
+int fc_sum_of_sigmoids(const float* x, float* y, const float* params, const int32_t* cols,
+                       float* logabsdet, uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t,
+                       int32_t n_sigmoids, int32_t inverse, int32_t bisection_iterations,
+                       float bisection_lim, float offset, float log_scale_postact,
+                       int32_t shared_params, int32_t lad_mode, void* stream);
+
+/* ---- row-per-wavefront bijectors with dense parameters (d <= 512) ------------------------------ */
+/* K Householder reflections out -= (out.q_k)(2/|q_k|^2) q_k, k = 0..K-1 (reverse != 0: K-1..0).
+ * q: [K, d] shared, or [n, K, d] when per_sample != 0.  logabsdet is identically 0.
+ * Replaces _apply_batchwise_transforms[_nodet] (transforms/orthogonal.py:144-194) behind
+ * HouseholderSequence / ParametrizedHouseHolder forward/inverse (orthogonal.py:63-141). */
+int fc_householder(const float* x, float* y, const float* q, int64_t n, int32_t d,
+                   int32_t num_transforms, int32_t per_sample, int32_t reverse, void* stream);
+
+/* y = x + u_hat * tanh(x.w + b); logabsdet = log(1e-7 + |1 + sum_j u_hat_j (1 - tanh^2) w_j|).
+ * u_hat is the constrained u (host computes it from w, u: a [1, d] expression); b is a device scalar.
+ * Replaces PlanarTransform.forward / forward_logabsdet (no_analytic_inv/planar.py:30-49). */
+int fc_planar(const float* x, float* y, float* logabsdet, const float* w, const float* u_hat,
+              const float* b, int64_t n, int32_t d, void* stream);
+
+/* Dense linear maps with batch-shared [d, d] matrices given TRANSPOSED (a_t[j*d + i] = A[i][j]).
+ * mode 0: y = A x + bias                        (linear.py:45-52 cached weight; bias may be NULL)
+ * mode 1: y = B (A x) + bias, A = U, B = L      (lu.py:56-68, two F.linear)
+ * mode 2: y = A^-1 B^-1 (x - bias), A = U upper, B = L unit-lower (lu.py:70-91, solve_triangular) */
+int fc_linear(const float* x, float* y, const float* a_t, const float* b_t, const float* bias,
+              int64_t n, int32_t d, int32_t mode, void* stream);
+
+/* Sylvester flow, fused: y = z + Q R2 tanh(R1 Q^T z + bias), Q = num_householder reflections q,
+ * logabsdet = sum_j log(1 + (1 - tanh^2(.)_j) * r_diag_prod_j), r_diag_prod = diag(R1)*diag(R2).
+ * r1_t / r2_t are the upper-triangular matrices TRANSPOSED.  per_sample != 0: q [n, M, d],
+ * r1_t/r2_t [n, d, d], bias/r_diag_prod [n, d] (the D-general conditional form, conditional.py:936-953).
+ * Replaces SylvesterTransform.forward (no_analytic_inv/planar.py:144-166). */
+int fc_sylvester(const float* x, float* y, float* logabsdet, const float* q, const float* r1_t,
+                 const float* r2_t, const float* bias, const float* r_diag_prod, int64_t n, int32_t d,
+                 int32_t num_householder, int32_t per_sample, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -375,6 +375,360 @@ def _inverse_transform(t, inputs, context, inverse):
     return transform_apply(t._transform, inputs, context, not inverse)
 
 
+
+# ---- orthogonal.py ---------------------------------------------------------------------------------
+
+def householder_apply(inputs, q_vectors):
+    """orthogonal.py:144-171: K sequential reflections; q_vectors [K, D] or per-sample [N, K, D]."""
+    squared_norms = torch.sum(q_vectors ** 2, dim=-1)
+    outputs = inputs
+    for i in range(q_vectors.shape[-2]):
+        q = q_vectors[..., i, :]
+        sq = squared_norms[..., i].unsqueeze(-1)
+        ip = (outputs * q).sum(-1)
+        outputs = outputs - ip.unsqueeze(-1) * ((2.0 / sq) * q)
+    return outputs
+
+
+def _householder(t, inputs, context, inverse):
+    """orthogonal.py:63-72 / :111-117."""
+    q = t.q_vectors.detach() if isinstance(t.q_vectors, torch.nn.Parameter) else t.q_vectors
+    if inverse:
+        q = q.flip(-2)
+    return householder_apply(inputs, q), inputs.new_zeros(inputs.shape[0])
+
+
+# ---- no_analytic_inv/planar.py -------------------------------------------------------------------------
+
+def _planar(t, inputs, context, inverse):
+    """planar.py:30-69 (no inverse)."""
+    if inverse:
+        raise NotImplementedError("PlanarTransform has no inverse")
+    w, u, b = t.w.detach(), t.u.detach(), t.b.detach()
+    wtu = torch.mm(u, w.T)
+    m_wtu = -1 + F.softplus(wtu)
+    u_hat = u + (m_wtu - wtu) * (w / (torch.norm(w, p=2, dim=1) ** 2))
+    a = torch.mm(inputs, w.T) + b
+    outputs = inputs + u_hat * torch.tanh(a)
+    psi = (1 - torch.tanh(a) ** 2) * w
+    abs_det = (1 + torch.mm(u_hat, psi.T)).abs()
+    return outputs, torch.log(1e-7 + abs_det).squeeze()
+
+
+def _upper_from(entries, diag, features):
+    iu = np.triu_indices(features, k=1)
+    m = entries.new_zeros(features, features)
+    m[iu[0], iu[1]] = entries
+    m[range(features), range(features)] = diag
+    return m
+
+
+def sylvester_forward(inputs, q_vectors, r1, r2, bias):
+    """planar.py:144-166 with Q applied as reflections (orthogonal.py:63-72)."""
+    qtz = householder_apply(inputs, q_vectors.flip(-2))
+    rqtz = r1.unsqueeze(0) @ qtz.unsqueeze(-1) if r1.dim() == 2 else r1 @ qtz.unsqueeze(-1)
+    preact = rqtz.squeeze(-1) + (bias.unsqueeze(0) if bias.dim() == 1 else bias)
+    act = torch.tanh(preact)
+    ract = r2.unsqueeze(0) @ act.unsqueeze(-1) if r2.dim() == 2 else r2 @ act.unsqueeze(-1)
+    qract = householder_apply(ract.squeeze(-1), q_vectors)
+    outputs = inputs + qract
+    r_sq = torch.diagonal(r1, dim1=-2, dim2=-1) * torch.diagonal(r2, dim1=-2, dim2=-1)
+    diag = 1 + (1 - act ** 2) * (r_sq.unsqueeze(0) if r_sq.dim() == 1 else r_sq)
+    return outputs, torch.log(diag).sum(-1)
+
+
+def _sylvester(t, inputs, context, inverse):
+    if inverse:
+        raise NotImplementedError("SylvesterTransform has no inverse")
+    f = t.features
+    r1 = _upper_from(t.upper_entries1.detach(), torch.tanh(t.log_upper_diag1.detach()), f)
+    r2 = _upper_from(t.upper_entries2.detach(), torch.tanh(t.log_upper_diag2.detach()), f)
+    return sylvester_forward(inputs, t.Q_orth.q_vectors.detach(), r1, r2, t.bias.detach())
+
+
+# ---- lu.py / linear.py ---------------------------------------------------------------------------------
+
+def lu_matrices(t):
+    """lu.py:44-54."""
+    f = t.features
+    il = np.tril_indices(f, k=-1)
+    lower = t.lower_entries.detach().new_zeros(f, f)
+    lower[il[0], il[1]] = t.lower_entries.detach()
+    lower[range(f), range(f)] = 1.0
+    upper_diag = F.softplus(t.unconstrained_upper_diag.detach()) + t.eps
+    upper = _upper_from(t.upper_entries.detach(), upper_diag, f)
+    return lower, upper, upper_diag
+
+
+def _lu_linear(t, inputs, context, inverse):
+    """lu.py:56-91 (no-cache path) and linear.py:45-76 (eval-mode cache path)."""
+    lower, upper, upper_diag = lu_matrices(t)
+    logabsdet = torch.sum(torch.log(upper_diag))
+    bias = t.bias.detach()
+    ones = inputs.new_ones(inputs.shape[0])
+    if not t.training and t.using_cache:
+        if not inverse:
+            return F.linear(inputs, lower @ upper, bias), logabsdet * ones
+        eye = torch.eye(t.features, dtype=inputs.dtype)
+        linv = torch.linalg.solve_triangular(lower, eye, upper=False, unitriangular=True)
+        winv = torch.linalg.solve_triangular(upper, linv, upper=True, unitriangular=False)
+        return F.linear(inputs - bias, winv), (-logabsdet) * ones
+    if not inverse:
+        outputs = F.linear(inputs, upper)
+        return F.linear(outputs, lower, bias), logabsdet * ones
+    outputs = inputs - bias
+    outputs = torch.linalg.solve_triangular(lower, outputs.t(), upper=False, unitriangular=True)
+    outputs = torch.linalg.solve_triangular(upper, outputs, upper=True, unitriangular=False)
+    return outputs.t(), -logabsdet * ones
+
+
+# ---- normalization.py ---------------------------------------------------------------------------------
+
+def _actnorm(t, inputs, context, inverse):
+    """normalization.py:171-204 (initialised / eval mode)."""
+    if inputs.dim() not in (2, 4):
+        raise ValueError("Expecting inputs to be a 2D or a 4D tensor.")
+    log_scale, shift = t.log_scale.detach(), t.shift.detach()
+    scale = torch.exp(log_scale)
+    if inputs.dim() == 4:
+        scale, shift = scale.view(1, -1, 1, 1), shift.view(1, -1, 1, 1)
+        mult = inputs.shape[2] * inputs.shape[3]
+    else:
+        scale, shift = scale.view(1, -1), shift.view(1, -1)
+        mult = 1
+    lad = mult * torch.sum(log_scale) * inputs.new_ones(inputs.shape[0])
+    if inverse:
+        return (inputs - shift) / scale, -lad
+    return scale * inputs + shift, lad
+
+
+def _batchnorm(t, inputs, context, inverse):
+    """normalization.py:98-141 in eval mode."""
+    if inputs.dim() != 2:
+        raise ValueError("Expected 2-dim inputs, got inputs of shape: {}".format(inputs.shape))
+    weight = F.softplus(t.unconstrained_weight.detach()) + t.eps
+    bias, mean, var = t.bias.detach(), t.running_mean, t.running_var
+    ones = inputs.new_ones(inputs.shape[0])
+    if inverse:
+        outputs = torch.sqrt(var + t.eps) * ((inputs - bias) / weight) + mean
+        return outputs, torch.sum(-torch.log(weight) + 0.5 * torch.log(var + t.eps)) * ones
+    outputs = weight * ((inputs - mean) / torch.sqrt(var + t.eps)) + bias
+    return outputs, torch.sum(torch.log(weight) - 0.5 * torch.log(var + t.eps)) * ones
+
+
+# ---- nonlinearities.py (element-wise) -------------------------------------------------------------------
+
+def _exp(t, x, c, inverse):
+    """nonlinearities.py:18-32."""
+    if inverse:
+        if torch.min(x) <= 0.:
+            raise OracleInputOutsideDomain()
+        y = torch.log(x)
+        return y, -sum_except_batch(y)
+    return torch.exp(x), sum_except_batch(x)
+
+
+def _tanh(t, x, c, inverse):
+    """nonlinearities.py:35-48."""
+    if inverse:
+        if torch.min(x) <= -1 or torch.max(x) >= 1:
+            raise OracleInputOutsideDomain()
+        return 0.5 * torch.log((1 + x) / (1 - x)), sum_except_batch(-torch.log(1 - x ** 2))
+    y = torch.tanh(x)
+    return y, sum_except_batch(torch.log(1 - y ** 2))
+
+
+def _logtanh(t, x, c, inverse):
+    """nonlinearities.py:51-112."""
+    alpha, beta = t.alpha, t.beta
+    y = torch.zeros_like(x)
+    lad = torch.zeros_like(x)
+    if not inverse:
+        right, left = x > t.cut_point, x < -t.cut_point
+        mid = ~(right | left)
+        y[mid] = torch.tanh(x[mid])
+        y[right] = alpha * torch.log(beta * x[right])
+        y[left] = alpha * -torch.log(-beta * x[left])
+        lad[mid] = torch.log(1 - y[mid] ** 2)
+        lad[right] = torch.log(alpha / x[right])
+        lad[left] = torch.log(-alpha / x[left])
+    else:
+        right, left = x > t.inv_cut_point, x < -t.inv_cut_point
+        mid = ~(right | left)
+        y[mid] = 0.5 * torch.log((1 + x[mid]) / (1 - x[mid]))
+        y[right] = torch.exp(x[right] / alpha) / beta
+        y[left] = -torch.exp(-x[left] / alpha) / beta
+        lad[mid] = -torch.log(1 - x[mid] ** 2)
+        lad[right] = -np.log(alpha * beta) + x[right] / alpha
+        lad[left] = -np.log(alpha * beta) - x[left] / alpha
+    return y, sum_except_batch(lad)
+
+
+def _leaky_relu(t, x, c, inverse):
+    """nonlinearities.py:115-136."""
+    mask = (x < 0).to(x.dtype)
+    ls = t.log_negative_slope.detach()
+    if inverse:
+        return F.leaky_relu(x, negative_slope=(1 / t.negative_slope)), sum_except_batch(-ls * mask)
+    return F.leaky_relu(x, negative_slope=t.negative_slope), sum_except_batch(ls * mask)
+
+
+def _sigmoid(t, x, c, inverse):
+    """nonlinearities.py:139-169."""
+    temp = t.temperature.detach()
+    if inverse:
+        if torch.min(x) < 0 or torch.max(x) > 1:
+            raise OracleInputOutsideDomain()
+        x = torch.clamp(x, t.eps, 1 - t.eps)
+        y = (1 / temp) * (torch.log(x) - torch.log1p(-x))
+        return y, -sum_except_batch(torch.log(temp) - F.softplus(-temp * y) - F.softplus(temp * y))
+    x = temp * x
+    return torch.sigmoid(x), sum_except_batch(torch.log(temp) - F.softplus(-x) - F.softplus(x))
+
+
+def _softplus_t(t, x, c, inverse):
+    """nonlinearities.py:172-189."""
+    thr = t.softplus.threshold
+    if inverse:
+        x = x - t.eps
+        return torch.where(x > thr, x, x.expm1().log()), -torch.log(-torch.expm1(-x)).sum(-1)
+    return F.softplus(x, beta=1, threshold=thr) + t.eps, F.logsigmoid(x).sum(-1)
+
+
+def _cauchy(t, x, c, inverse):
+    """nonlinearities.py:212-231."""
+    if inverse:
+        if torch.min(x) < 0 or torch.max(x) > 1:
+            raise OracleInputOutsideDomain()
+        y = torch.tan(np.pi * (x - 0.5))
+        return y, -sum_except_batch(-np.log(np.pi) - torch.log(1 + y ** 2))
+    return (1 / np.pi) * torch.atan(x) + 0.5, sum_except_batch(-np.log(np.pi) - torch.log(1 + x ** 2))
+
+
+def _glu(t, x, c, inverse):
+    """nonlinearities.py:197-209."""
+    gate = torch.sigmoid(c)
+    if inverse:
+        return x / gate, -torch.log(gate).reshape(-1)
+    return x * gate, torch.log(gate).reshape(-1)
+
+
+# ---- adaptive_sigmoids.py + ExtendedSoftplus + MonotonicTransform ------------------------------------------
+
+def extended_softplus(x, raw_shift):
+    """nonlinearities.py:519-552."""
+    shift = F.softplus(raw_shift) + 1e-1
+    out = F.softplus(x - shift) + (-F.softplus(-(x + shift)))
+    lj = torch.logaddexp(-torch.logaddexp(shift, x) + x, -F.softplus(shift + x))
+    return out, lj
+
+
+def sos_forward(x, shift_preact, log_scale_preact, raw_softmax, esp_shift, log_scale_postact=0.0, eps=1e-6):
+    """adaptive_sigmoids.py:108-142.  Parameter tensors broadcast against x[..., None]."""
+    soft_max = F.softmax(raw_softmax, dim=-1) + eps
+    soft_max = soft_max / soft_max.sum(-1).unsqueeze(-1)
+    scale_postact = math.exp(log_scale_postact) * soft_max
+    scale_preact = torch.sigmoid(log_scale_preact) * (10. - .1) + .1
+    shift = torch.tanh(shift_preact) * 10
+    pre = scale_preact * (x.unsqueeze(-1) - shift)
+    sig = scale_postact * torch.sigmoid(pre)
+    log_jac = torch.log(scale_postact) + torch.log(scale_preact) + (pre - 2 * F.softplus(pre))
+    y_sos = sig.sum(-1) / scale_postact.sum(-1)
+    lj_sos = torch.logsumexp(log_jac, -1)
+    y_esp, lj_esp = extended_softplus(x, esp_shift)
+    return y_sos + y_esp, torch.logaddexp(lj_sos, lj_esp).sum(-1)
+
+
+def monotonic_inverse(forward_fn, z, lim, num_iterations, ratio_multiplier=1.5, atol=1e-7):
+    """no_analytic_inv/base.py:23-83: batch-global bracket expansion, bisection, 2 Newton steps whose
+    derivative comes from autograd through ``forward_fn`` (x -> (f(x), logabsdet))."""
+    def diffs(z_max, z_min):
+        d = z - z_max
+        imax = torch.argmax(d)
+        e = z - z_min
+        imin = torch.argmin(e)
+        return imax, imin, d.flatten()[imax], e.flatten()[imin]
+
+    x_max = torch.ones_like(z) * lim
+    x_min = -torch.ones_like(z) * lim
+    z_max, _ = forward_fn(x_max)
+    z_min, _ = forward_fn(x_min)
+    imax, imin, maxdiff, mindiff = diffs(z_max, z_min)
+    while maxdiff > 0:
+        ratio = (maxdiff + z_max.flatten()[imax]) / z_max.flatten()[imax]
+        x_max = x_max * ratio_multiplier * ratio
+        z_max, _ = forward_fn(x_max)
+        imax, imin, maxdiff, mindiff = diffs(z_max, z_min)
+    x_max = x_max + 1
+    while mindiff < 0:
+        ratio = (mindiff + z_min.flatten()[imin]) / z_min.flatten()[imin]
+        x_min = x_min * ratio_multiplier * ratio
+        z_min, _ = forward_fn(x_min)
+        imax, imin, maxdiff, mindiff = diffs(z_max, z_min)
+    x_min = x_min - 1
+    i = 0
+    x_middle = (x_max + x_min) / 2
+    while i < num_iterations and (x_middle - z).abs().max() > atol:
+        x_middle = (x_max + x_min) / 2
+        z_middle, _ = forward_fn(x_middle)
+        left = (z_middle > z).to(z.dtype)
+        right = (z_middle < z).to(z.dtype)
+        equal = 1 - (left + right)
+        x_max = left * x_middle + right * x_max + equal * x_middle
+        x_min = right * x_middle + left * x_min + equal * x_middle
+        i += 1
+    x_guess = ((x_max + x_min) / 2).detach()
+    with torch.enable_grad():
+        x_guess = x_guess.requires_grad_(True)
+        for _ in range(2):
+            f = forward_fn(x_guess)[0] - z
+            df_dx = torch.autograd.grad(f.sum(), x_guess, create_graph=False)[0].view(f.shape)
+            x_guess = (x_guess - f / (df_dx + 1e-7)).detach().requires_grad_(True)
+    x_guess = x_guess.detach()
+    return x_guess, -forward_fn(x_guess)[1].reshape(-1)
+
+
+def _sos_params(t):
+    def val(p):
+        return p.detach() if isinstance(p, torch.nn.Parameter) else p
+    esp = t.extended_softplus.shift
+    return (val(t.shift_preact), val(t.log_scale_preact), val(t.raw_softmax), val(esp),
+            float(val(t.log_scale_postact).reshape(-1)[0]))
+
+
+def _sum_of_sigmoids(t, x, c, inverse):
+    sp, ls, rs, es, lp = _sos_params(t)
+
+    def fwd(v):
+        return sos_forward(v, sp, ls, rs, es, lp)
+
+    if inverse:
+        return monotonic_inverse(fwd, x, t.lim, t.num_iterations, t.ratio_multiplier, t.atol)
+    return fwd(x)
+
+
+def _ew_sos_ar(t, x, params, inverse):
+    """autoregressive.py:301-318."""
+    s = t.n_sigmoids
+    raw = params.view(x.shape[0], t.features, 3 * s + 1)
+    sp, ls, rs, es = torch.split(raw, [s, s, s, 1], dim=-1)
+    es = es.reshape(-1, t.features)
+
+    def fwd(v):
+        return sos_forward(v, sp, ls, rs, es)
+
+    if inverse:
+        return monotonic_inverse(fwd, x + 0.5, 120, 50)
+    z, lad = fwd(x)
+    return z - 0.5, lad
+
+
+def _named_inverse(inner_factory):
+    """Logit / CauchyCDFInverse are InverseTransform subclasses (nonlinearities.py:192-194, 234-236)."""
+    def fn(t, x, c, inverse):
+        return transform_apply(t._transform, x, c, not inverse)
+    return fn
+
 _DISPATCH = {
     "CompositeTransform": _composite,
     "CompositeCDFTransform": _composite,
@@ -395,6 +749,25 @@ _DISPATCH = {
     "MaskedPiecewiseRationalQuadraticAutoregressiveTransform":
         lambda t, x, c, inv: _autoregressive(t, x, c, inv, _ew_rq_ar),
     "PiecewiseRationalQuadraticCDF": _rq_cdf,
+    "HouseholderSequence": _householder,
+    "ParametrizedHouseHolder": _householder,
+    "PlanarTransform": _planar,
+    "SylvesterTransform": _sylvester,
+    "LULinear": _lu_linear,
+    "ActNorm": _actnorm,
+    "BatchNorm": _batchnorm,
+    "Exp": _exp,
+    "Tanh": _tanh,
+    "LogTanh": _logtanh,
+    "LeakyReLU": _leaky_relu,
+    "Sigmoid": _sigmoid,
+    "Softplus": _softplus_t,
+    "CauchyCDF": _cauchy,
+    "GatedLinearUnit": _glu,
+    "Logit": _named_inverse(None),
+    "CauchyCDFInverse": _named_inverse(None),
+    "SumOfSigmoids": _sum_of_sigmoids,
+    "MaskedSumOfSigmoidsTransform": lambda t, x, c, inv: _autoregressive(t, x, c, inv, _ew_sos_ar),
 }
 
 

@@ -25,10 +25,10 @@ CASES = {}
 
 
 def case(name, features, context=None, x_scale=1.0, inverse=True, boost=3.0, in_unit=False,
-         clamp=None, tol=(2e-5, 1e-4, 2e-4, 1e-3)):
+         clamp=None, init=None, tol=(2e-5, 1e-4, 2e-4, 1e-3)):
     def deco(fn):
         CASES[name] = dict(build=fn, features=features, context=context, x_scale=x_scale,
-                           inverse=inverse, boost=boost, in_unit=in_unit, clamp=clamp, tol=tol)
+                           inverse=inverse, boost=boost, in_unit=in_unit, clamp=clamp, init=init, tol=tol)
         return fn
     return deco
 
@@ -149,6 +149,130 @@ def _(L):
             _alt_mask(L, 16, even=(l % 2 == 0)), _resnet(L, hidden=32), num_bins=8, tails="linear",
             tail_bound=3.0))
     return L.transforms.CompositeTransform(layers)
+
+
+def _randomize(std, names=None):
+    """Generator-side hook: overwrite (selected) parameters with N(0, std) values."""
+    def init(module):
+        g = torch.Generator().manual_seed(77)
+        with torch.no_grad():
+            for name, p in module.named_parameters():
+                if names is None or any(k in name for k in names):
+                    p.copy_(torch.randn(p.shape, generator=g) * std)
+    return init
+
+
+@case("householder_sequence_d16_k6", 16, boost=1.0, init=_randomize(1.0), tol=(1e-5, 0, 1e-5, 0))
+def _(L):
+    return L.transforms.HouseholderSequence(features=16, num_transforms=6)
+
+
+@case("householder_sequence_d130_k3", 130, boost=1.0, init=_randomize(1.0), tol=(1e-5, 0, 1e-5, 0))
+def _(L):
+    return L.transforms.HouseholderSequence(features=130, num_transforms=3)
+
+
+@case("planar_d8", 8, boost=1.0, inverse=False, init=_randomize(0.7))
+def _(L):
+    return L.transforms.PlanarTransform(features=8)
+
+
+@case("sylvester_d12_m5", 12, boost=1.0, inverse=False, init=_randomize(0.4))
+def _(L):
+    return L.transforms.SylvesterTransform(features=12, num_householder=5, device="cpu")
+
+
+@case("sylvester_d128_m32", 128, boost=1.0, inverse=False, init=_randomize(0.15))
+def _(L):
+    # BASELINE.json config 5 (non-conditional class; the conditional one is D == 2 only upstream)
+    return L.transforms.SylvesterTransform(features=128, num_householder=32, device="cpu")
+
+
+@case("lu_linear_d9", 9, boost=1.0)
+def _(L):
+    return L.transforms.LULinear(features=9, identity_init=False)
+
+
+@case("lu_linear_cached_d70", 70, boost=1.0)
+def _(L):
+    return L.transforms.LULinear(features=70, using_cache=True, identity_init=False)
+
+
+def _init_actnorm(module):
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        module.log_scale.copy_(torch.randn(module.log_scale.shape, generator=g) * 0.5)
+        module.shift.copy_(torch.randn(module.shift.shape, generator=g))
+        module.initialized.data = torch.tensor(True, dtype=torch.bool)
+
+
+@case("actnorm_d6", 6, boost=1.0, init=_init_actnorm, tol=(1e-5, 1e-5, 1e-5, 1e-5))
+def _(L):
+    return L.transforms.ActNorm(features=6)
+
+
+def _init_batchnorm(module):
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        module.unconstrained_weight.copy_(torch.randn(module.bias.shape, generator=g))
+        module.bias.copy_(torch.randn(module.bias.shape, generator=g))
+        module.running_mean.copy_(torch.randn(module.bias.shape, generator=g))
+        module.running_var.copy_(torch.rand(module.bias.shape, generator=g) + 0.2)
+
+
+@case("batchnorm_eval_d5", 5, boost=1.0, init=_init_batchnorm, tol=(1e-5, 1e-5, 1e-5, 1e-5))
+def _(L):
+    return L.transforms.BatchNorm(features=5)
+
+
+@case("exp_d7", 7, boost=1.0)
+def _(L):
+    return L.transforms.Exp()
+
+
+@case("tanh_d7", 7, boost=1.0)
+def _(L):
+    return L.transforms.Tanh()
+
+
+@case("logtanh_d7", 7, boost=1.0, x_scale=2.0)
+def _(L):
+    return L.transforms.LogTanh(cut_point=1)
+
+
+@case("leaky_relu_d7", 7, boost=1.0)
+def _(L):
+    return L.transforms.LeakyReLU(negative_slope=0.1)
+
+
+@case("sigmoid_d7_temp", 7, boost=1.0)
+def _(L):
+    return L.transforms.Sigmoid(temperature=1.7)
+
+
+@case("logit_d7", 7, boost=1.0, in_unit=True)
+def _(L):
+    return L.transforms.Logit()
+
+
+@case("softplus_d7", 7, boost=1.0, x_scale=3.0)
+def _(L):
+    return L.transforms.Softplus()
+
+
+@case("cauchy_cdf_d7", 7, boost=1.0, x_scale=2.0)
+def _(L):
+    return L.transforms.nonlinearities.CauchyCDF()
+
+
+@case("sum_of_sigmoids_d4_s10", 4, boost=1.0, x_scale=3.0, init=_randomize(1.0, names=("shift_preact", "log_scale_preact", "raw_softmax")))
+def _(L):
+    return L.transforms.SumOfSigmoids(features=4, n_sigmoids=10)
+
+
+@case("maf_sum_of_sigmoids_d5_s30", 5, boost=2.0, x_scale=2.0)
+def _(L):
+    return L.transforms.MaskedSumOfSigmoidsTransform(features=5, hidden_features=32, n_sigmoids=30)
 
 
 def boost_parameters(module, factor, seed):

@@ -73,6 +73,8 @@ def main():
         torch.manual_seed(1234)
         t = spec["build"](L)
         cases.boost_parameters(t, spec["boost"], seed=0)
+        if spec["init"] is not None:
+            spec["init"](t)
         t.eval()
         gen = torch.Generator().manual_seed(4321)
         t64 = copy.deepcopy(t).double()  # the reference itself in float64 = "truth" for noise floors

@@ -1,0 +1,127 @@
+"""Row-per-wavefront kernels with PER-SAMPLE parameters (the conditional forms of SURVEY.md 8f #1)
+and misc. element-wise ops that the golden cases do not reach: HIP vs CPU oracle."""
+import pytest
+import torch
+
+from _util import maxdiff
+from flowconductor_amd import ops
+from flowconductor_amd import transforms as T
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,k,d", [(5, 3, 7), (300, 4, 64), (64, 32, 128), (33, 2, 200)])
+def test_householder_per_sample_q(n, k, d, device):
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn(n, d, generator=gen)
+    q = torch.randn(n, k, d, generator=gen)
+    ref = O.householder_apply(x, q)
+    ref_rev = O.householder_apply(x, q.flip(-2))
+    with torch.no_grad():
+        got = ops.householder(x.to(device), q.to(device))
+        got_rev = ops.householder(x.to(device), q.to(device), reverse=True)
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxdiff(got, ref) <= 2e-5 * scale
+    assert maxdiff(got_rev, ref_rev) <= 2e-5 * scale
+    # orthogonality: norms are preserved; applying forward then reverse is the identity
+    assert maxdiff(got.norm(dim=1), x.norm(dim=1)) <= 1e-4 * scale
+    with torch.no_grad():
+        back = ops.householder(got, q.to(device), reverse=True)
+    assert maxdiff(back, x) <= 5e-5 * scale
+
+
+def test_householder_matrix_is_orthogonal(device):
+    h = T.HouseholderSequence(features=24, num_transforms=7)
+    with torch.no_grad():
+        h.q_vectors.copy_(torch.randn(7, 24))
+    h = h.to(device)
+    with torch.no_grad():
+        q = h.matrix()
+        x = torch.randn(50, 24, device=device)
+        y, lad = h(x)
+    assert maxdiff(q @ q.T, torch.eye(24)) <= 1e-5
+    assert maxdiff(y, x @ q.T.T if False else x @ q) <= 2e-5 or maxdiff(y, x @ q.T) <= 2e-5
+    assert float(lad.abs().max()) == 0.0
+    # det = (-1)^K
+    assert abs(float(torch.linalg.det(q.double().cpu())) - (-1.0) ** 7) <= 1e-4
+
+
+@pytest.mark.parametrize("n,d,m", [(17, 6, 3), (128, 128, 32)])
+def test_sylvester_per_sample_parameters(n, d, m, device):
+    gen = torch.Generator().manual_seed(d)
+    x = torch.randn(n, d, generator=gen)
+    q = torch.randn(n, m, d, generator=gen)
+    r1 = torch.triu(torch.randn(n, d, d, generator=gen) / d ** 0.5)
+    r2 = torch.triu(torch.randn(n, d, d, generator=gen) / d ** 0.5)
+    idx = torch.arange(d)
+    r1[:, idx, idx] = torch.tanh(r1[:, idx, idx])
+    r2[:, idx, idx] = torch.tanh(r2[:, idx, idx])
+    bias = torch.randn(n, d, generator=gen) * 0.1
+    y_ref, lad_ref = O.sylvester_forward(x, q, r1, r2, bias)
+    with torch.no_grad():
+        y, lad = ops.sylvester(x.to(device), q.to(device), r1.to(device), r2.to(device), bias.to(device))
+    scale = max(1.0, float(y_ref.abs().max()))
+    assert maxdiff(y, y_ref) <= 3e-5 * scale
+    assert maxdiff(lad, lad_ref) <= 1e-4 * max(1.0, float(lad_ref.abs().max()))
+
+
+def test_gated_linear_unit(device):
+    x = torch.randn(40, 1)
+    c = torch.randn(40, 1)
+    glu = T.GatedLinearUnit()
+    y_ref, lad_ref = O.transform_apply(glu, x, c)
+    with torch.no_grad():
+        y, lad = glu(x.to(device), c.to(device))
+        xb, ladb = glu.inverse(y, c.to(device))
+    assert maxdiff(y, y_ref) <= 1e-6 and maxdiff(lad, lad_ref) <= 1e-6
+    assert maxdiff(xb, x) <= 1e-5 and maxdiff(ladb, -lad_ref) <= 1e-6
+
+
+def test_extended_softplus_module(device):
+    esp = T.ExtendedSoftplus(features=5).to(device)
+    x = torch.randn(30, 5) * 4
+    ref_y, ref_lj = O.extended_softplus(x, esp.shift.detach().cpu())
+    with torch.no_grad():
+        y, lj = esp(x.to(device))
+    assert maxdiff(y, ref_y) <= 1e-5 and maxdiff(lj, ref_lj) <= 1e-5
+
+
+@pytest.mark.parametrize("kind", ["Exp", "Tanh", "Sigmoid", "CauchyCDF"])
+def test_inverse_domain_errors(kind, device):
+    cls = getattr(T, kind)
+    t = cls().to(device)
+    bad = torch.full((4, 3), 0.5, device=device)
+    bad[2, 1] = {"Exp": -0.1, "Tanh": 1.0, "Sigmoid": 1.2, "CauchyCDF": -0.01}[kind]
+    with pytest.raises(T.InputOutsideDomain):
+        with torch.no_grad():
+            t.inverse(bad)
+
+
+def test_sum_of_sigmoids_inverse_far_from_origin(device):
+    """Reference test adaptive_sigmoid_test.py:64-79: inverse at |x| ~ 200 (outside the initial bracket)."""
+    torch.manual_seed(0)
+    t = T.SumOfSigmoids(features=3, n_sigmoids=10).to(device)
+    x = torch.tensor([[-200.0, 0.3, 190.0], [150.0, -175.0, 0.0]], device=device)
+    with torch.no_grad():
+        z, lad = t(x)
+        xb, ladb = t.inverse(z)
+    assert maxdiff(xb, x) <= 2e-3  # float32 resolution at |x| = 200 is 1.5e-5; f' ~ 1
+    assert maxdiff(lad + ladb, torch.zeros(2)) <= 1e-4
+
+
+def test_lu_linear_matches_dense_weight(device):
+    """Reference lu_test.py:24-65: outputs == x @ (L U)^T + b, inverse via weight_inverse()."""
+    torch.manual_seed(1)
+    t = T.LULinear(features=11, identity_init=False).to(device)
+    x = torch.randn(20, 11, device=device)
+    with torch.no_grad():
+        w = t.weight()
+        y, lad = t(x)
+        xb, ladb = t.inverse(y)
+        winv = t.weight_inverse()
+    assert maxdiff(y, x @ w.T + t.bias.detach()) <= 1e-5
+    assert maxdiff(xb, x) <= 1e-4
+    assert maxdiff(winv @ w, torch.eye(11)) <= 1e-4
+    assert maxdiff(lad, torch.full((20,), float(torch.linalg.slogdet(w.double().cpu())[1]))) <= 1e-5
+    assert maxdiff(lad + ladb, torch.zeros(20)) == 0.0
