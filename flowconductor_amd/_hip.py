@@ -45,6 +45,27 @@ class RQConfig(ctypes.Structure):
     ]
 
 
+class SplineConfig(ctypes.Structure):
+    """Mirror of ``fc_spline_config``."""
+
+    _fields_ = [
+        ("kind", ctypes.c_int32),
+        ("num_bins", ctypes.c_int32),
+        ("tails", ctypes.c_int32),
+        ("inverse", ctypes.c_int32),
+        ("left", ctypes.c_float),
+        ("right", ctypes.c_float),
+        ("bottom", ctypes.c_float),
+        ("top", ctypes.c_float),
+        ("min_bin_width", ctypes.c_double),
+        ("min_bin_height", ctypes.c_double),
+        ("width_divisor", ctypes.c_float),
+        ("height_divisor", ctypes.c_float),
+        ("cubic_eps", ctypes.c_float),
+        ("cubic_quadratic_threshold", ctypes.c_float),
+    ]
+
+
 _P = ctypes.c_void_p
 _I32 = ctypes.c_int32
 _I64 = ctypes.c_int64
@@ -65,6 +86,8 @@ SIGNATURES = {
     "fc_sum_of_sigmoids": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _F, _F, _F,
                            _I32, _I32, _P],
     "fc_elementwise": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _F, _P],
+    "fc_piecewise_spline": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32,
+                            ctypes.POINTER(SplineConfig), _P],
     "fc_affine": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P],
 }
 

@@ -514,3 +514,61 @@ def sum_of_sigmoids(inputs, raw_params, n_sigmoids, inverse=False, offset=0.0, i
           _hip.stream_ptr(x.device))
     _finish(inverse)
     return y, lad
+
+
+# ---- linear / quadratic / cubic splines -----------------------------------------------------------
+
+SPLINE_LINEAR, SPLINE_QUADRATIC, SPLINE_CUBIC = 0, 1, 2
+
+
+def spline_multiplier(kind, num_bins, tails):
+    if kind == SPLINE_LINEAR:
+        return num_bins
+    if kind == SPLINE_QUADRATIC:
+        return num_bins * 2 - 1 if tails == "linear" else num_bins * 2 + 1
+    return num_bins * 2 + 2
+
+
+def piecewise_spline(inputs, params, cols=None, *, kind, num_bins, tails=None, tail_bound=1.0,
+                     left=0.0, right=1.0, bottom=0.0, top=1.0, min_bin_width=DEFAULT_MIN_BIN_WIDTH,
+                     min_bin_height=DEFAULT_MIN_BIN_HEIGHT, width_divisor=1.0, height_divisor=1.0,
+                     inverse=False, shared_params=False):
+    """Linear / quadratic / cubic spline over ``inputs[:, cols]`` (reference splines/{linear,
+    quadratic,cubic}.py).  Row layouts: ``FC_SPLINE_*`` in include/flowcon_hip.h."""
+    lib = _hip.load()
+    x = _prep_2d(inputs)
+    p = _hip.dev_f32(params, "params")
+    _hip.require_no_grad(inputs, params)
+    n, d = x.shape
+    cols = _as_cols(cols, x.device)
+    d_t = d if cols is None else cols.numel()
+    if tails not in (None, "linear"):
+        raise RuntimeError("{} tails are not implemented.".format(tails))
+    if kind != SPLINE_LINEAR:
+        if min_bin_width * num_bins > 1.0:
+            raise ValueError("Minimal bin width too large for the number of bins")
+        if min_bin_height * num_bins > 1.0:
+            raise ValueError("Minimal bin height too large for the number of bins")
+    rowlen = d_t * spline_multiplier(kind, num_bins, tails)
+    want = rowlen if shared_params else n * rowlen
+    if p.numel() != want:
+        raise ValueError("params has %d elements, expected %d" % (p.numel(), want))
+    cfg = _hip.SplineConfig()
+    cfg.kind, cfg.num_bins = kind, num_bins
+    cfg.tails = 0 if tails is None else 1
+    cfg.inverse = 1 if inverse else 0
+    if tails == "linear":
+        cfg.left, cfg.right, cfg.bottom, cfg.top = -tail_bound, tail_bound, -tail_bound, tail_bound
+    else:
+        cfg.left, cfg.right, cfg.bottom, cfg.top = left, right, bottom, top
+    cfg.min_bin_width, cfg.min_bin_height = min_bin_width, min_bin_height
+    cfg.width_divisor, cfg.height_divisor = width_divisor, height_divisor
+    cfg.cubic_eps, cfg.cubic_quadratic_threshold = 1e-5, 1e-3
+    y = torch.empty_like(x)
+    lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    err = _err_word(x.device, True)
+    _call("fc_piecewise_spline", lib.fc_piecewise_spline, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(p),
+          _hip.ptr(cols), _hip.ptr(lad), _hip.ptr(err), n, d, d_t, 1 if shared_params else 0, LAD_STORE, cfg,
+          _hip.stream_ptr(x.device))
+    _finish(True)
+    return y, lad

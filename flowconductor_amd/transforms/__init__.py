@@ -1,6 +1,9 @@
 from flowconductor_amd.transforms.autoregressive import (  # noqa: F401
     AutoregressiveTransform,
     MaskedAffineAutoregressiveTransform,
+    MaskedPiecewiseCubicAutoregressiveTransform,
+    MaskedPiecewiseLinearAutoregressiveTransform,
+    MaskedPiecewiseQuadraticAutoregressiveTransform,
     MaskedPiecewiseRationalQuadraticAutoregressiveTransform,
     MaskedShiftAutoregressiveTransform,
     MaskedSumOfSigmoidsTransform,
@@ -16,6 +19,9 @@ from flowconductor_amd.transforms.coupling import (  # noqa: F401
     AdditiveCouplingTransform,
     AffineCouplingTransform,
     CouplingTransform,
+    PiecewiseCubicCouplingTransform,
+    PiecewiseLinearCouplingTransform,
+    PiecewiseQuadraticCouplingTransform,
     PiecewiseRationalQuadraticCouplingTransform,
 )
 from flowconductor_amd.transforms.adaptive_sigmoids import SumOfSigmoids  # noqa: F401
@@ -36,6 +42,9 @@ from flowconductor_amd.transforms.nonlinearities import (  # noqa: F401
     LeakyReLU,
     Logit,
     LogTanh,
+    PiecewiseCubicCDF,
+    PiecewiseLinearCDF,
+    PiecewiseQuadraticCDF,
     PiecewiseRationalQuadraticCDF,
     Sigmoid,
     Softplus,

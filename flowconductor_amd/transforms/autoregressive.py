@@ -180,3 +180,100 @@ class MaskedSumOfSigmoidsTransform(AutoregressiveTransform):
 
     def _elementwise_inverse(self, inputs, autoregressive_params):
         return ops.sum_of_sigmoids(inputs, autoregressive_params, self.n_sigmoids, inverse=True, offset=0.5)
+
+
+def _ar_divisor(net):
+    return float(np.sqrt(net.hidden_features)) if hasattr(net, "hidden_features") else 1.0
+
+
+class MaskedPiecewiseLinearAutoregressiveTransform(AutoregressiveTransform):
+    """Piecewise-linear AR layer on [0, 1] (autoregressive.py:321-372)."""
+
+    def __init__(self, num_bins, features, hidden_features, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu, dropout_probability=0.0,
+                 use_batch_norm=False):
+        self.num_bins = num_bins
+        self.features = features
+        made = _made(self, features, hidden_features, context_features, num_blocks, use_residual_blocks,
+                     random_mask, activation, dropout_probability, use_batch_norm)
+        super().__init__(made)
+
+    def _output_dim_multiplier(self):
+        return self.num_bins
+
+    def _elementwise(self, inputs, autoregressive_params, inverse=False):
+        return ops.piecewise_spline(inputs, autoregressive_params, None, kind=ops.SPLINE_LINEAR,
+                                    num_bins=self.num_bins, inverse=inverse)
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params)
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params, inverse=True)
+
+
+class MaskedPiecewiseQuadraticAutoregressiveTransform(AutoregressiveTransform):
+    """Piecewise-quadratic AR layer (autoregressive.py:375-460); only the widths are scaled, and only
+    when the net exposes ``hidden_features``."""
+
+    def __init__(self, num_bins, features, hidden_features, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu, dropout_probability=0.0,
+                 use_batch_norm=False, tails=None, tail_bound=1.0, min_bin_width=ops.DEFAULT_MIN_BIN_WIDTH,
+                 min_bin_height=ops.DEFAULT_MIN_BIN_HEIGHT, min_derivative=ops.DEFAULT_MIN_DERIVATIVE):
+        self.num_bins = num_bins
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.min_derivative = min_derivative
+        self.tails = tails
+        self.tail_bound = tail_bound
+        self.features = features
+        made = _made(self, features, hidden_features, context_features, num_blocks, use_residual_blocks,
+                     random_mask, activation, dropout_probability, use_batch_norm)
+        super().__init__(made)
+
+    def _output_dim_multiplier(self):
+        if self.tails == "linear":
+            return self.num_bins * 2 - 1
+        return self.num_bins * 2 + 1
+
+    def _elementwise(self, inputs, autoregressive_params, inverse=False):
+        if self.tails not in (None, "linear"):
+            raise ValueError
+        return ops.piecewise_spline(inputs, autoregressive_params, None, kind=ops.SPLINE_QUADRATIC,
+                                    num_bins=self.num_bins, tails=self.tails, tail_bound=self.tail_bound,
+                                    min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                                    width_divisor=_ar_divisor(self.autoregressive_net), inverse=inverse)
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params)
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params, inverse=True)
+
+
+class MaskedPiecewiseCubicAutoregressiveTransform(AutoregressiveTransform):
+    """Piecewise-cubic AR layer on [0, 1] (autoregressive.py:463-526)."""
+
+    def __init__(self, num_bins, features, hidden_features, context_features=None, num_blocks=2,
+                 use_residual_blocks=True, random_mask=False, activation=F.relu, dropout_probability=0.0,
+                 use_batch_norm=False):
+        self.num_bins = num_bins
+        self.features = features
+        made = _made(self, features, hidden_features, context_features, num_blocks, use_residual_blocks,
+                     random_mask, activation, dropout_probability, use_batch_norm)
+        super().__init__(made)
+
+    def _output_dim_multiplier(self):
+        return self.num_bins * 2 + 2
+
+    def _elementwise(self, inputs, autoregressive_params, inverse=False):
+        div = _ar_divisor(self.autoregressive_net)
+        return ops.piecewise_spline(inputs, autoregressive_params, None, kind=ops.SPLINE_CUBIC,
+                                    num_bins=self.num_bins, width_divisor=div, height_divisor=div,
+                                    inverse=inverse)
+
+    def _elementwise_forward(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params)
+
+    def _elementwise_inverse(self, inputs, autoregressive_params):
+        return self._elementwise(inputs, autoregressive_params, inverse=True)

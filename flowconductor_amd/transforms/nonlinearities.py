@@ -196,6 +196,92 @@ class PiecewiseRationalQuadraticCDF(Transform):
         return self._spline(inputs, inverse=True)
 
 
+class _SharedSplineCDF(Transform):
+    """Common part of the batch-shared spline CDFs: concatenate the learnable per-dim parameters into
+    one ``[prod(shape), multiplier]`` row set and run the spline kernel with ``shared_params``."""
+
+    _kind = None
+
+    def _rows(self):
+        raise NotImplementedError()
+
+    def _spline(self, inputs, inverse=False):
+        flat = _flatten_items(inputs)
+        outputs, logabsdet = ops.piecewise_spline(
+            flat, self._rows(), None, kind=self._kind, num_bins=self.num_bins, tails=self.tails,
+            tail_bound=self.tail_bound, min_bin_width=getattr(self, "min_bin_width", ops.DEFAULT_MIN_BIN_WIDTH),
+            min_bin_height=getattr(self, "min_bin_height", ops.DEFAULT_MIN_BIN_HEIGHT), inverse=inverse,
+            shared_params=True)
+        return outputs.reshape(inputs.shape), logabsdet
+
+    def forward(self, inputs, context=None):
+        return self._spline(inputs, inverse=False)
+
+    def inverse(self, inputs, context=None):
+        return self._spline(inputs, inverse=True)
+
+
+class PiecewiseLinearCDF(_SharedSplineCDF):
+    """nonlinearities.py:250-284."""
+
+    _kind = ops.SPLINE_LINEAR
+
+    def __init__(self, shape, num_bins=10, tails=None, tail_bound=1.0):
+        super().__init__()
+        self.tail_bound = tail_bound
+        self.tails = tails
+        self.num_bins = num_bins
+        self.unnormalized_pdf = nn.Parameter(torch.randn(*shape, num_bins))
+
+    def _rows(self):
+        return self.unnormalized_pdf.detach().reshape(-1)
+
+
+class PiecewiseQuadraticCDF(_SharedSplineCDF):
+    """nonlinearities.py:287-339."""
+
+    _kind = ops.SPLINE_QUADRATIC
+
+    def __init__(self, shape, num_bins=10, tails=None, tail_bound=1.0,
+                 min_bin_width=ops.DEFAULT_MIN_BIN_WIDTH, min_bin_height=ops.DEFAULT_MIN_BIN_HEIGHT):
+        super().__init__()
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.tail_bound = tail_bound
+        self.tails = tails
+        self.num_bins = num_bins
+        self.unnormalized_widths = nn.Parameter(torch.randn(*shape, num_bins))
+        n_heights = num_bins + 1 if tails is None else num_bins - 1
+        self.unnormalized_heights = nn.Parameter(torch.randn(*shape, n_heights))
+
+    def _rows(self):
+        return torch.cat((self.unnormalized_widths.detach(), self.unnormalized_heights.detach()), dim=-1).reshape(-1)
+
+
+class PiecewiseCubicCDF(_SharedSplineCDF):
+    """nonlinearities.py:342-426."""
+
+    _kind = ops.SPLINE_CUBIC
+
+    def __init__(self, shape, num_bins=10, tails=None, tail_bound=1.0,
+                 min_bin_width=ops.DEFAULT_MIN_BIN_WIDTH, min_bin_height=ops.DEFAULT_MIN_BIN_HEIGHT):
+        super().__init__()
+        self.min_bin_width = min_bin_width
+        self.min_bin_height = min_bin_height
+        self.tail_bound = tail_bound
+        self.tails = tails
+        self.num_bins = num_bins
+        self.unnormalized_widths = nn.Parameter(torch.randn(*shape, num_bins))
+        self.unnormalized_heights = nn.Parameter(torch.randn(*shape, num_bins))
+        self.unnorm_derivatives_left = nn.Parameter(torch.randn(*shape, 1))
+        self.unnorm_derivatives_right = nn.Parameter(torch.randn(*shape, 1))
+
+    def _rows(self):
+        return torch.cat((self.unnormalized_widths.detach(), self.unnormalized_heights.detach(),
+                          self.unnorm_derivatives_left.detach(), self.unnorm_derivatives_right.detach()),
+                         dim=-1).reshape(-1)
+
+
 class ExtendedSoftplus(torch.nn.Module):
     """softplus(x - s) - softplus(-(x + s)) with s = softplus(shift) + 0.1: linear far from the
     origin, flat around it.  ``forward`` returns (outputs, element-wise log-derivative)

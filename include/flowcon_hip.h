@@ -63,6 +63,34 @@ int fc_rq_spline(const float* x, float* y, const float* params, const int32_t* c
                  float* logabsdet, uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t,
                  int32_t shared_params, int32_t lad_mode, const fc_rq_config* cfg, void* stream);
 
+/* ---- linear / quadratic / cubic splines ------------------------------------------------------ */
+#define FC_SPLINE_LINEAR 0    /* row per dim: [K pdf]                          (splines/linear.py:38-105) */
+#define FC_SPLINE_QUADRATIC 1 /* row per dim: [K widths | K-1 or K+1 heights]  (splines/quadratic.py:55-159) */
+#define FC_SPLINE_CUBIC 2     /* row per dim: [K widths | K heights | dl | dr] (splines/cubic.py:63-267) */
+
+typedef struct fc_spline_config {
+  int32_t kind;           /* FC_SPLINE_* */
+  int32_t num_bins;
+  int32_t tails;          /* 0 none, 1 "linear" */
+  int32_t inverse;
+  float left, right, bottom, top;      /* linear tails: -B, B, -B, B */
+  double min_bin_width, min_bin_height; /* python floats of the reference */
+  float width_divisor, height_divisor;  /* sqrt(hidden_features) or 1 (coupling.py:438-440,
+                                           autoregressive.py:430-432: AR quadratic scales widths only) */
+  float cubic_eps;                      /* 1e-5 */
+  float cubic_quadratic_threshold;      /* 1e-3 */
+} fc_spline_config;
+
+/* Sibling piecewise bijectors of the RQ spline, same conventions as fc_rq_spline.  Replaces
+ * {linear,quadratic,cubic}_spline and their unconstrained_* wrappers behind
+ * Piecewise{Linear,Quadratic,Cubic}CouplingTransform (coupling.py:299-499),
+ * MaskedPiecewise{Linear,Quadratic,Cubic}AutoregressiveTransform (autoregressive.py:321-526) and
+ * Piecewise{Linear,Quadratic,Cubic}CDF (nonlinearities.py:250-427). */
+int fc_piecewise_spline(const float* x, float* y, const float* params, const int32_t* cols,
+                        float* logabsdet, uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t,
+                        int32_t shared_params, int32_t lad_mode, const fc_spline_config* cfg,
+                        void* stream);
+
 /* ---- affine / additive with per-sample parameters ------------------------------------------ */
 #define FC_AFFINE_SIGMOID_PLUS2 0   /* row [shift d_t | u d_t], s = sigmoid(u+2)+1e-3 (coupling.py:224) */
 #define FC_AFFINE_SOFTPLUS_CLAMP3 1 /* row [shift | u], s = clamp(softplus(u)+1e-3, 0, 3) (coupling.py:225) */

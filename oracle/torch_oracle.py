@@ -729,6 +729,267 @@ def _named_inverse(inner_factory):
         return transform_apply(t._transform, x, c, not inverse)
     return fn
 
+
+# ---- splines/linear.py, quadratic.py, cubic.py -------------------------------------------------------------
+
+def _unconstrained(spline_fn, inputs, tail_bound, tails, param_list, **kw):
+    """Shared shape of the unconstrained_* wrappers (linear.py:8-35, quadratic.py:11-52, cubic.py:14-60)."""
+    inside = (inputs >= -tail_bound) & (inputs <= tail_bound)
+    outside = ~inside
+    outputs = torch.zeros_like(inputs)
+    logabsdet = torch.zeros_like(inputs)
+    if tails != "linear":
+        raise RuntimeError("{} tails are not implemented.".format(tails))
+    outputs[outside] = inputs[outside]
+    logabsdet[outside] = 0
+    if torch.any(inside):
+        outputs[inside], logabsdet[inside] = spline_fn(
+            inputs[inside], *[p[inside, :] for p in param_list], left=-tail_bound, right=tail_bound,
+            bottom=-tail_bound, top=tail_bound, **kw)
+    return outputs, logabsdet
+
+
+def linear_spline(inputs, unnormalized_pdf, inverse=False, left=0.0, right=1.0, bottom=0.0, top=1.0):
+    """splines/linear.py:38-105."""
+    if torch.min(inputs) < left or torch.max(inputs) > right:
+        raise OracleInputOutsideDomain()
+    inputs = (inputs - bottom) / (top - bottom) if inverse else (inputs - left) / (right - left)
+    num_bins = unnormalized_pdf.size(-1)
+    pdf = F.softmax(unnormalized_pdf, dim=-1)
+    cdf = torch.cumsum(pdf, dim=-1)
+    cdf[..., -1] = 1.0
+    cdf = F.pad(cdf, pad=(1, 0), mode="constant", value=0.0)
+    if inverse:
+        k = searchsorted(cdf, inputs).unsqueeze(-1)
+        edges = torch.linspace(0, 1, num_bins + 1).view([1] * inputs.dim() + [-1]).expand(*inputs.shape, -1)
+        slopes = (cdf[..., 1:] - cdf[..., :-1]) / (edges[..., 1:] - edges[..., :-1])
+        offsets = cdf[..., 1:] - slopes * edges[..., 1:]
+        slope_k = slopes.gather(-1, k)[..., 0]
+        outputs = torch.clamp((inputs - offsets.gather(-1, k)[..., 0]) / slope_k, 0, 1)
+        logabsdet = -torch.log(slope_k)
+        return outputs * (right - left) + left, logabsdet
+    bin_pos = inputs * num_bins
+    k = torch.floor(bin_pos).long()
+    k[k >= num_bins] = num_bins - 1
+    alpha = bin_pos - k.float()
+    pdf_k = pdf.gather(-1, k[..., None])[..., 0]
+    outputs = cdf.gather(-1, k[..., None])[..., 0]
+    outputs += alpha * pdf_k
+    outputs = torch.clamp(outputs, 0, 1)
+    logabsdet = torch.log(pdf_k) - np.log(1.0 / num_bins)
+    return outputs * (top - bottom) + bottom, logabsdet
+
+
+def quadratic_spline(inputs, unnormalized_widths, unnormalized_heights, inverse=False, left=0.0, right=1.0,
+                     bottom=0.0, top=1.0, min_bin_width=1e-3, min_bin_height=1e-3):
+    """splines/quadratic.py:55-159."""
+    if torch.min(inputs) < left or torch.max(inputs) > right:
+        raise OracleInputOutsideDomain()
+    inputs = (inputs - bottom) / (top - bottom) if inverse else (inputs - left) / (right - left)
+    num_bins = unnormalized_widths.shape[-1]
+    if min_bin_width * num_bins > 1.0:
+        raise ValueError("Minimal bin width too large for the number of bins")
+    if min_bin_height * num_bins > 1.0:
+        raise ValueError("Minimal bin height too large for the number of bins")
+    widths = F.softmax(unnormalized_widths, dim=-1)
+    widths = min_bin_width + (1 - min_bin_width * num_bins) * widths
+    uh = F.softplus(unnormalized_heights) + 1e-3
+    if uh.shape[-1] == num_bins - 1:
+        first_w = 0.5 * widths[..., 0]
+        last_w = 0.5 * widths[..., -1]
+        numerator = (0.5 * first_w * uh[..., 0] + 0.5 * last_w * uh[..., -1]
+                     + torch.sum(((uh[..., :-1] + uh[..., 1:]) / 2) * widths[..., 1:-1], dim=-1))
+        constant = (numerator / (1 - 0.5 * first_w - 0.5 * last_w))[..., None]
+        uh = torch.cat([constant, uh, constant], dim=-1)
+    area = torch.sum(((uh[..., :-1] + uh[..., 1:]) / 2) * widths, dim=-1)[..., None]
+    heights = uh / area
+    heights = min_bin_height + (1 - min_bin_height) * heights
+    left_cdf = torch.cumsum(((heights[..., :-1] + heights[..., 1:]) / 2) * widths, dim=-1)
+    left_cdf[..., -1] = 1.0
+    left_cdf = F.pad(left_cdf, pad=(1, 0), mode="constant", value=0.0)
+    locations = torch.cumsum(widths, dim=-1)
+    locations[..., -1] = 1.0
+    locations = F.pad(locations, pad=(1, 0), mode="constant", value=0.0)
+    k = searchsorted(left_cdf if inverse else locations, inputs)[..., None]
+    loc_k = locations.gather(-1, k)[..., 0]
+    w_k = widths.gather(-1, k)[..., 0]
+    cdf_k = left_cdf.gather(-1, k)[..., 0]
+    hl = heights.gather(-1, k)[..., 0]
+    hr = heights.gather(-1, k + 1)[..., 0]
+    a = 0.5 * (hr - hl) * w_k
+    b = hl * w_k
+    c = cdf_k
+    if inverse:
+        c_ = c - inputs
+        alpha = (-b + torch.sqrt(b.pow(2) - 4 * a * c_)) / (2 * a)
+        outputs = torch.clamp(alpha * w_k + loc_k, 0, 1)
+        logabsdet = -torch.log(alpha * (hr - hl) + hl)
+        return outputs * (right - left) + left, logabsdet
+    alpha = (inputs - loc_k) / w_k
+    outputs = torch.clamp(a * alpha.pow(2) + b * alpha + c, 0, 1)
+    logabsdet = torch.log(alpha * (hr - hl) + hl)
+    return outputs * (top - bottom) + bottom, logabsdet
+
+
+def cubic_spline(inputs, unnormalized_widths, unnormalized_heights, unnorm_derivatives_left,
+                 unnorm_derivatives_right, inverse=False, left=0.0, right=1.0, bottom=0.0, top=1.0,
+                 min_bin_width=1e-3, min_bin_height=1e-3, eps=1e-5, quadratic_threshold=1e-3):
+    """splines/cubic.py:63-267 (Blinn's closed-form inverse)."""
+    if torch.min(inputs) < left or torch.max(inputs) > right:
+        raise OracleInputOutsideDomain()
+    num_bins = unnormalized_widths.shape[-1]
+    if min_bin_width * num_bins > 1.0:
+        raise ValueError("Minimal bin width too large for the number of bins")
+    if min_bin_height * num_bins > 1.0:
+        raise ValueError("Minimal bin height too large for the number of bins")
+    inputs = (inputs - bottom) / (top - bottom) if inverse else (inputs - left) / (right - left)
+
+    def normalise(u, floor):
+        v = F.softmax(u, dim=-1)
+        v = floor + (1 - floor * num_bins) * v
+        cum = torch.cumsum(v, dim=-1)
+        cum[..., -1] = 1
+        return v, F.pad(cum, pad=(1, 0), mode="constant", value=0.0)
+
+    widths, cumwidths = normalise(unnormalized_widths, min_bin_width)
+    heights, cumheights = normalise(unnormalized_heights, min_bin_height)
+    slopes = heights / widths
+    m1 = torch.min(torch.abs(slopes[..., :-1]), torch.abs(slopes[..., 1:]))
+    m2 = 0.5 * (widths[..., 1:] * slopes[..., :-1] + widths[..., :-1] * slopes[..., 1:]) / (
+        widths[..., :-1] + widths[..., 1:])
+    d_left = torch.sigmoid(unnorm_derivatives_left) * 3 * slopes[..., 0][..., None]
+    d_right = torch.sigmoid(unnorm_derivatives_right) * 3 * slopes[..., -1][..., None]
+    derivs = torch.min(m1, m2) * (torch.sign(slopes[..., :-1]) + torch.sign(slopes[..., 1:]))
+    derivs = torch.cat([d_left, derivs, d_right], dim=-1)
+    a = (derivs[..., :-1] + derivs[..., 1:] - 2 * slopes) / widths.pow(2)
+    b = (3 * slopes - 2 * derivs[..., :-1] - derivs[..., 1:]) / widths
+    c = derivs[..., :-1]
+    d = cumheights[..., :-1]
+    k = searchsorted(cumheights if inverse else cumwidths, inputs)[..., None]
+    ia, ib, ic, id_ = (t.gather(-1, k)[..., 0] for t in (a, b, c, d))
+    lw = cumwidths.gather(-1, k)[..., 0]
+    rw = cumwidths.gather(-1, k + 1)[..., 0]
+    if not inverse:
+        s = inputs - lw
+        outputs = ia * s.pow(3) + ib * s.pow(2) + ic * s + id_
+        logabsdet = torch.log(3 * ia * s.pow(2) + 2 * ib * s + ic)
+        return outputs * (top - bottom) + bottom, logabsdet
+    b_ = (ib / ia) / 3.0
+    c_ = (ic / ia) / 3.0
+    d_ = (id_ - inputs) / ia
+    delta_1 = -b_.pow(2) + c_
+    delta_2 = -c_ * b_ + d_
+    delta_3 = b_ * d_ - c_.pow(2)
+    disc = 4.0 * delta_1 * delta_3 - delta_2.pow(2)
+    dep1 = -2.0 * b_ * delta_1 + delta_2
+    dep2 = delta_1
+    three = disc >= 0
+    one = disc < 0
+    outputs = torch.zeros_like(inputs)
+
+    def cbrt(v):
+        return torch.sign(v) * torch.exp(torch.log(torch.abs(v)) / 3.0)
+
+    p = cbrt((-dep1[one] + torch.sqrt(-disc[one])) / 2.0)
+    q = cbrt((-dep1[one] - torch.sqrt(-disc[one])) / 2.0)
+    outputs[one] = (p + q) - b_[one] + lw[one]
+    theta = torch.atan2(torch.sqrt(disc[three]), -dep1[three])
+    theta /= 3.0
+    cr1, cr2 = torch.cos(theta), torch.sin(theta)
+    r1 = cr1
+    r2 = -0.5 * cr1 - 0.5 * math.sqrt(3) * cr2
+    r3 = -0.5 * cr1 + 0.5 * math.sqrt(3) * cr2
+    scale = 2 * torch.sqrt(-dep2[three])
+    shift = -b_[three] + lw[three]
+    r1, r2, r3 = r1 * scale + shift, r2 * scale + shift, r3 * scale + shift
+
+    def in_bin(r):
+        m = ((lw[three] - eps) < r).float()
+        m *= (r < (rw[three] + eps)).float()
+        return m
+
+    roots = torch.stack([r1, r2, r3], dim=-1)
+    masks = torch.stack([in_bin(r1), in_bin(r2), in_bin(r3)], dim=-1)
+    pick = torch.argsort(masks, dim=-1, descending=True)[..., 0][..., None]
+    outputs[three] = torch.gather(roots, dim=-1, index=pick).view(-1)
+    quad = ia.abs() < quadratic_threshold
+    qa, qb, qc = ib[quad], ic[quad], id_[quad] - inputs[quad]
+    alpha = (-qb + torch.sqrt(qb.pow(2) - 4 * qa * qc)) / (2 * qa)
+    outputs[quad] = alpha + lw[quad]
+    s = outputs - lw
+    logabsdet = -torch.log(3 * ia * s.pow(2) + 2 * ib * s + ic)
+    return outputs * (right - left) + left, logabsdet
+
+
+def _spline_rows(t, x, params, net, kind):
+    """Slice the [.., multiplier] rows per spline kind, scaling as the coupling / AR classes do."""
+    k = t.num_bins
+    is_ar = hasattr(t, "autoregressive_net")
+    has_h = hasattr(net, "hidden_features") if net is not None else False
+    div = np.sqrt(net.hidden_features) if has_h else None
+    if kind == "linear":
+        return [params]
+    if kind == "quadratic":
+        uw, uh = params[..., :k], params[..., k:]
+        if div is not None:
+            uw /= div
+            if not is_ar:  # autoregressive.py:430-432 scales the widths only
+                uh /= div
+        return [uw, uh]
+    uw, uh = params[..., :k], params[..., k:2 * k]
+    dl, dr = params[..., 2 * k][..., None], params[..., 2 * k + 1][..., None]
+    if div is not None:
+        uw /= div
+        uh /= div
+    return [uw, uh, dl, dr]
+
+
+def _apply_sibling(t, x, plist, kind, inverse):
+    fn = {"linear": linear_spline, "quadratic": quadratic_spline, "cubic": cubic_spline}[kind]
+    kw = {}
+    if kind != "linear":
+        kw = dict(min_bin_width=getattr(t, "min_bin_width", 1e-3), min_bin_height=getattr(t, "min_bin_height", 1e-3))
+    tails = getattr(t, "tails", None)
+    if tails is None:
+        return fn(x, *plist, inverse=inverse, **kw)
+    return _unconstrained(fn, x, t.tail_bound, tails, plist, inverse=inverse, **kw)
+
+
+def _make_sibling_coupling(kind):
+    def ew(t, x, params, inverse):
+        rows = _piecewise_rows(x, params)
+        y, lad = _apply_sibling(t, x, _spline_rows(t, x, rows, t.transform_net, kind), kind, inverse)
+        return y, sum_except_batch(lad)
+    return lambda t, x, c, inv: _coupling(t, x, c, inv, ew)
+
+
+def _make_sibling_ar(kind):
+    def ew(t, x, params, inverse):
+        rows = params.view(x.shape[0], t.features, -1)
+        y, lad = _apply_sibling(t, x, _spline_rows(t, x, rows, t.autoregressive_net, kind), kind, inverse)
+        return y, sum_except_batch(lad)
+    return lambda t, x, c, inv: _autoregressive(t, x, c, inv, ew)
+
+
+def _make_sibling_cdf(kind):
+    def fn(t, x, c, inverse):
+        n = x.shape[0]
+
+        def share(p):
+            return p.detach()[None, ...].expand(n, *p.shape).clone()
+
+        if kind == "linear":
+            plist = [share(t.unnormalized_pdf)]
+            t_num_bins = t.unnormalized_pdf.shape[-1]
+        elif kind == "quadratic":
+            plist = [share(t.unnormalized_widths), share(t.unnormalized_heights)]
+        else:
+            plist = [share(t.unnormalized_widths), share(t.unnormalized_heights),
+                     share(t.unnorm_derivatives_left), share(t.unnorm_derivatives_right)]
+        y, lad = _apply_sibling(t, x, plist, kind, inverse)
+        return y, sum_except_batch(lad)
+    return fn
+
 _DISPATCH = {
     "CompositeTransform": _composite,
     "CompositeCDFTransform": _composite,
@@ -766,6 +1027,15 @@ _DISPATCH = {
     "GatedLinearUnit": _glu,
     "Logit": _named_inverse(None),
     "CauchyCDFInverse": _named_inverse(None),
+    "PiecewiseLinearCouplingTransform": _make_sibling_coupling("linear"),
+    "PiecewiseQuadraticCouplingTransform": _make_sibling_coupling("quadratic"),
+    "PiecewiseCubicCouplingTransform": _make_sibling_coupling("cubic"),
+    "MaskedPiecewiseLinearAutoregressiveTransform": _make_sibling_ar("linear"),
+    "MaskedPiecewiseQuadraticAutoregressiveTransform": _make_sibling_ar("quadratic"),
+    "MaskedPiecewiseCubicAutoregressiveTransform": _make_sibling_ar("cubic"),
+    "PiecewiseLinearCDF": _make_sibling_cdf("linear"),
+    "PiecewiseQuadraticCDF": _make_sibling_cdf("quadratic"),
+    "PiecewiseCubicCDF": _make_sibling_cdf("cubic"),
     "SumOfSigmoids": _sum_of_sigmoids,
     "MaskedSumOfSigmoidsTransform": lambda t, x, c, inv: _autoregressive(t, x, c, inv, _ew_sos_ar),
 }

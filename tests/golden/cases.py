@@ -25,10 +25,10 @@ CASES = {}
 
 
 def case(name, features, context=None, x_scale=1.0, inverse=True, boost=3.0, in_unit=False,
-         clamp=None, init=None, tol=(2e-5, 1e-4, 2e-4, 1e-3)):
+         clamp=None, init=None, inv_clamp=None, tol=(2e-5, 1e-4, 2e-4, 1e-3)):
     def deco(fn):
         CASES[name] = dict(build=fn, features=features, context=context, x_scale=x_scale,
-                           inverse=inverse, boost=boost, in_unit=in_unit, clamp=clamp, init=init, tol=tol)
+                           inverse=inverse, boost=boost, in_unit=in_unit, clamp=clamp, init=init, inv_clamp=inv_clamp, tol=tol)
         return fn
     return deco
 
@@ -273,6 +273,70 @@ def _(L):
 @case("maf_sum_of_sigmoids_d5_s30", 5, boost=2.0, x_scale=2.0)
 def _(L):
     return L.transforms.MaskedSumOfSigmoidsTransform(features=5, hidden_features=32, n_sigmoids=30)
+
+
+@case("linear_coupling_tails_d8_k8", 8, x_scale=1.5)
+def _(L):
+    return L.transforms.PiecewiseLinearCouplingTransform(_alt_mask(L, 8), _resnet(L), num_bins=8, tails="linear",
+                                                         tail_bound=3.0)
+
+
+@case("linear_coupling_unit_d6_k10", 6, in_unit=True)
+def _(L):
+    return L.transforms.PiecewiseLinearCouplingTransform(_alt_mask(L, 6), _resnet(L), num_bins=10)
+
+
+@case("quadratic_coupling_tails_d8_k8", 8, x_scale=1.5)
+def _(L):
+    return L.transforms.PiecewiseQuadraticCouplingTransform(_alt_mask(L, 8), _resnet(L), num_bins=8,
+                                                            tails="linear", tail_bound=3.0)
+
+
+@case("quadratic_coupling_unit_d6_k5", 6, in_unit=True)
+def _(L):
+    return L.transforms.PiecewiseQuadraticCouplingTransform(_alt_mask(L, 6), _resnet(L), num_bins=5)
+
+
+@case("cubic_coupling_tails_d8_k8", 8, x_scale=1.5)
+def _(L):
+    return L.transforms.PiecewiseCubicCouplingTransform(_alt_mask(L, 8), _resnet(L), num_bins=8, tails="linear",
+                                                        tail_bound=3.0)
+
+
+@case("cubic_coupling_unit_d6_k6", 6, in_unit=True, inv_clamp=(0.0, 1.0))
+def _(L):
+    return L.transforms.PiecewiseCubicCouplingTransform(_alt_mask(L, 6), _resnet(L), num_bins=6)
+
+
+@case("maf_linear_d5_k8", 5, in_unit=True, boost=2.0)
+def _(L):
+    return L.transforms.MaskedPiecewiseLinearAutoregressiveTransform(num_bins=8, features=5, hidden_features=16)
+
+
+@case("maf_quadratic_tails_d5_k8", 5, x_scale=1.5, boost=2.0)
+def _(L):
+    return L.transforms.MaskedPiecewiseQuadraticAutoregressiveTransform(
+        num_bins=8, features=5, hidden_features=16, tails="linear", tail_bound=3.0)
+
+
+@case("maf_cubic_d5_k8", 5, in_unit=True, boost=2.0, inv_clamp=(0.0, 1.0))
+def _(L):
+    return L.transforms.MaskedPiecewiseCubicAutoregressiveTransform(num_bins=8, features=5, hidden_features=16)
+
+
+@case("linear_cdf_d5", 5, in_unit=True, boost=1.0)
+def _(L):
+    return L.transforms.PiecewiseLinearCDF(shape=[5], num_bins=7)
+
+
+@case("quadratic_cdf_tails_d5", 5, x_scale=1.5, boost=1.0)
+def _(L):
+    return L.transforms.PiecewiseQuadraticCDF(shape=[5], num_bins=6, tails="linear", tail_bound=2.0)
+
+
+@case("cubic_cdf_d5", 5, in_unit=True, boost=1.0, inv_clamp=(0.0, 1.0))
+def _(L):
+    return L.transforms.PiecewiseCubicCDF(shape=[5], num_bins=9)
 
 
 def boost_parameters(module, factor, seed):

@@ -90,8 +90,13 @@ def main():
                 out["y_%d" % n] = y.numpy()
                 out["lad_%d" % n] = lad.numpy()
                 if spec["inverse"]:
-                    # invert the forward outputs (always inside the inverse's domain)
-                    xi, ladi = t.inverse(y.clone(), None if ctx is None else ctx.clone())
+                    # invert the forward outputs (clamped into the inverse's domain where the
+                    # reference's own forward can overshoot it by rounding, e.g. the cubic spline)
+                    yin = y.clone()
+                    if spec["inv_clamp"]:
+                        yin = yin.clamp(*spec["inv_clamp"])
+                    out["yin_%d" % n] = yin.numpy()
+                    xi, ladi = t.inverse(yin.clone(), None if ctx is None else ctx.clone())
                     out["xinv_%d" % n] = xi.numpy()
                     out["ladinv_%d" % n] = ladi.numpy()
                 ctx64 = None if ctx is None else ctx.double()
@@ -100,7 +105,7 @@ def main():
                     out["y64_%d" % n] = y64.numpy()
                     out["lad64_%d" % n] = lad64.numpy()
                     if spec["inverse"]:
-                        xi64, ladi64 = t64.inverse(y.double(), ctx64)
+                        xi64, ladi64 = t64.inverse(yin.double(), ctx64)
                         out["xinv64_%d" % n] = xi64.numpy()
                         out["ladinv64_%d" % n] = ladi64.numpy()
                 except Exception as e:  # e.g. a float32 domain edge is outside the float64 box

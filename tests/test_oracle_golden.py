@@ -25,7 +25,7 @@ def test_oracle_matches_reference_golden(name):
         assert maxdiff(lad, g["lad_%d" % n]) <= TOL * 10, (name, n)
         if spec["inverse"]:
             with torch.no_grad():
-                xi, ladi = O.transform_apply(t, torch.from_numpy(g["y_%d" % n]).clone(),
+                xi, ladi = O.transform_apply(t, torch.from_numpy(g["yin_%d" % n]).clone(),
                                              None if ctx is None else ctx.clone(), inverse=True)
             assert maxdiff(xi, g["xinv_%d" % n]) <= TOL * 5, (name, n)
             assert maxdiff(ladi, g["ladinv_%d" % n]) <= TOL * 50, (name, n)
