@@ -1,0 +1,216 @@
+"""Flow-level behaviour and the BASELINE.json configurations at (or near) their full sizes,
+checked through size-independent properties plus oracle spot-checks on row subsets."""
+import numpy as np
+import pytest
+import torch
+
+from _util import Lib, maxdiff
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+T, nets, utils, flows, distributions = Lib.transforms, Lib.nets, Lib.utils, Lib.flows, Lib.distributions
+
+
+def _rq_stack(d, layers, hidden, bins=8, context=None):
+    return T.CompositeTransform([
+        T.PiecewiseRationalQuadraticCouplingTransform(
+            utils.create_alternating_binary_mask(d, even=(l % 2 == 0)),
+            lambda i, o: nets.ResidualNet(i, o, hidden_features=hidden, num_blocks=2, context_features=context),
+            num_bins=bins, tails="linear", tail_bound=3.0)
+        for l in range(layers)])
+
+
+def test_flow_shapes_and_sample_consistency(device):
+    """reference tests/flows/base_test.py:13-127."""
+    torch.manual_seed(0)
+    d, ctx = 6, 3
+    flow = flows.Flow(_rq_stack(d, 3, 16, context=ctx), distributions.StandardNormal([d]),
+                      embedding_net=torch.nn.Linear(4, ctx)).to(device).eval()
+    x = torch.randn(10, d, device=device)
+    c = torch.randn(10, 4, device=device)
+    with torch.no_grad():
+        lp = flow.log_prob(x, context=c)
+        assert lp.shape == (10,)
+        s = flow.sample(5, context=c)
+        assert s.shape == (10, 5, d)
+        samples, lps = flow.sample_and_log_prob(4, context=c)
+        assert samples.shape == (10, 4, d) and lps.shape == (10, 4)
+        lp_again = flow.log_prob(samples.reshape(40, d), context=c.repeat_interleave(4, dim=0)).reshape(10, 4)
+        noise = flow.transform_to_noise(x, context=c)
+        assert noise.shape == (10, d)
+    assert maxdiff(lps, lp_again) <= 2e-3
+    with pytest.raises(ValueError):
+        flow.log_prob(x, context=c[:5])
+    # without context
+    flow2 = flows.Flow(_rq_stack(d, 2, 16), distributions.StandardNormal([d])).to(device).eval()
+    with torch.no_grad():
+        assert flow2.log_prob(x).shape == (10,)
+        assert flow2.sample(7).shape == (7, d)
+        assert flow2.sample(7, batch_size=3).shape == (7, d)
+        s2, l2 = flow2.sample_and_log_prob(9)
+        assert maxdiff(l2, flow2.log_prob(s2)) <= 2e-3
+
+
+def test_canned_flows_match_oracle(device):
+    torch.manual_seed(1)
+    maf = flows.MaskedAutoregressiveFlow(features=4, hidden_features=16, num_layers=2, num_blocks_per_layer=2).eval()
+    nvp = flows.SimpleRealNVP(features=6, hidden_features=16, num_layers=3, num_blocks_per_layer=1).eval()
+    for flow, d in ((maf, 4), (nvp, 6)):
+        x = torch.randn(33, d)
+        with torch.no_grad():
+            ref = O.flow_log_prob(flow, x.clone())
+            got = flow.to(device).log_prob(x.to(device))
+        assert maxdiff(got, ref) <= 1e-4
+        flow.cpu()
+
+
+def test_coupling_4d_inputs_match_oracle(device):
+    """coupling layers on [N, C, H, W] inputs split on C (reference coupling_test.py 4-D shape [2, 4, 4])."""
+    torch.manual_seed(2)
+
+    class ConvNet(torch.nn.Module):
+        def __init__(self, i, o):
+            super().__init__()
+            self.hidden_channels = 8
+            self.a = torch.nn.Conv2d(i, 8, 3, padding=1)
+            self.b = torch.nn.Conv2d(8, o, 3, padding=1)
+
+        def forward(self, x, context=None):
+            return self.b(torch.relu(self.a(x)))
+
+    mask = utils.create_alternating_binary_mask(4)
+    cases = [
+        T.AffineCouplingTransform(mask, ConvNet),
+        T.AdditiveCouplingTransform(mask, ConvNet),
+        T.PiecewiseRationalQuadraticCouplingTransform(mask, ConvNet, num_bins=5, tails="linear", tail_bound=3.0),
+        T.PiecewiseQuadraticCouplingTransform(mask, ConvNet, num_bins=5, tails="linear", tail_bound=3.0),
+    ]
+    x = torch.randn(3, 4, 4, 4)
+    for t in cases:
+        t.eval()
+        with torch.no_grad():
+            y_ref, lad_ref = O.transform_apply(t, x.clone())
+            y, lad = t.to(device)(x.to(device))
+            xb, ladb = t.inverse(y)
+        assert y.shape == x.shape and lad.shape == (3,)
+        assert maxdiff(y, y_ref) <= 2e-5 * max(1.0, float(y_ref.abs().max())), type(t).__name__
+        assert maxdiff(lad, lad_ref) <= 2e-4, type(t).__name__
+        assert maxdiff(xb, x) <= 1e-3 and maxdiff(lad + ladb, torch.zeros(3)) <= 2e-3
+        # identity half untouched (reference coupling_test.py:50)
+        assert torch.equal(y[:, t.identity_features].cpu(), x[:, t.identity_features.cpu()])
+
+
+def test_actnorm_data_dependent_init_and_state_dict(device):
+    """reference normalization_test.py:76-143."""
+    t = T.ActNorm(5).to(device)
+    t.train()
+    x = torch.randn(4096, 5, device=device) * 3 + 1.5
+    with torch.no_grad():
+        y, lad = t(x)
+    assert bool(t.initialized)
+    assert maxdiff(y.mean(0), torch.zeros(5)) <= 1e-4 and maxdiff(y.std(0), torch.ones(5)) <= 1e-4
+    assert maxdiff(lad, torch.full((4096,), float(t.log_scale.sum()))) <= 1e-6
+    t2 = T.ActNorm(5)
+    t2.load_state_dict(t.state_dict())
+    assert bool(t2.initialized)
+    with torch.no_grad():
+        xb, ladb = t.inverse(y)
+    assert maxdiff(xb, x) <= 1e-4 and maxdiff(lad + ladb, torch.zeros(4096)) == 0.0
+
+
+def test_batchnorm_train_mode_statistics(device):
+    """reference normalization_test.py:13-59: training mode normalises with batch mean / unbiased var."""
+    t = T.BatchNorm(4).to(device)
+    t.train()
+    x = torch.randn(512, 4, device=device) * 2 + 0.7
+    with torch.no_grad():
+        y, lad = t(x)
+    mean, var = x.mean(0), x.var(0)
+    w = t.weight.detach()
+    expect = w * ((x - mean) / torch.sqrt(var + t.eps)) + t.bias.detach()
+    assert maxdiff(y, expect) <= 1e-5
+    assert maxdiff(t.running_mean, 0.1 * mean) <= 1e-6
+    assert maxdiff(lad, torch.full((512,), float((torch.log(w) - 0.5 * torch.log(var + t.eps)).sum()))) <= 1e-5
+
+
+# ---- BASELINE.json configurations -----------------------------------------------------------------
+
+def test_config1_readme_maf_flow(device):
+    """configs[0]: MAF(2, hidden 4) + RandomPermutation, batch 4096, vs the CPU oracle."""
+    torch.manual_seed(0)
+    flow = flows.Flow(T.CompositeTransform([T.MaskedAffineAutoregressiveTransform(features=2, hidden_features=4),
+                                            T.RandomPermutation(features=2)]),
+                      distributions.StandardNormal([2])).eval()
+    x = torch.randn(4096, 2)
+    with torch.no_grad():
+        ref = O.flow_log_prob(flow, x.clone())
+        got = flow.to(device).log_prob(x.to(device))
+        s, lp = flow.sample_and_log_prob(1000)
+        assert maxdiff(lp, flow.log_prob(s)) <= 1e-4
+    assert maxdiff(got, ref) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_config2_affine_coupling_bruteforce_jacobian(device):
+    """configs[1]: 8-layer affine coupling, D=32, N=2^18; logabsdet vs slogdet of the brute-force
+    autograd Jacobian (reference transform_test.py:29-37) on a 16-row slice, 1e-5."""
+    torch.manual_seed(0)
+    d, n = 32, 1 << 18
+    stack = T.CompositeTransform([
+        T.AffineCouplingTransform(utils.create_alternating_binary_mask(d, even=(l % 2 == 0)),
+                                  lambda i, o: nets.ResidualNet(i, o, hidden_features=64, num_blocks=2))
+        for l in range(8)]).eval()
+    x = torch.randn(n, d)
+    xs = x[:16].clone().requires_grad_(True)
+    ys, _ = O.transform_apply(stack, xs)  # differentiable CPU restatement
+    jac = utils.batch_jacobian(ys, xs)
+    brute = torch.linalg.slogdet(jac.detach().double())[1].float()
+    with torch.no_grad():
+        y, lad = stack.to(device)(x.to(device))
+        xb, ladb = stack.inverse(y)
+    assert maxdiff(lad[:16], brute) <= 1e-5 * max(1.0, float(brute.abs().max()))
+    assert maxdiff(y[:16], ys) <= 1e-5 * max(1.0, float(ys.abs().max()))
+    assert maxdiff(xb, x) <= 1e-4 and float((lad + ladb).abs().max()) <= 1e-4
+    assert torch.isfinite(y).all() and torch.isfinite(lad).all()
+
+
+def test_config3_rq_nsf_full_depth_properties(device):
+    """configs[2]: 32-layer RQ-NSF coupling, D=64, K=8 at N=2^18 (2^20 is bench.py's job):
+    forward/inverse round trip, logabsdet antisymmetry, oracle spot-check on 256 rows."""
+    torch.manual_seed(0)
+    stack = _rq_stack(64, 32, 64).eval()
+    n = 1 << 18
+    x = torch.randn(n, 64)
+    with torch.no_grad():
+        z_ref, lad_ref = O.transform_apply(stack, x[:256].clone())
+        stack = stack.to(device)
+        xd = x.to(device)
+        z, lad = stack(xd)
+        xb, ladb = stack.inverse(z)
+    assert torch.isfinite(z).all() and torch.isfinite(lad).all()
+    assert maxdiff(z[:256], z_ref) <= 1e-4 and maxdiff(lad[:256], lad_ref) <= 1e-3
+    assert float((xb - xd).abs().max()) <= 5e-3
+    assert float((lad + ladb).abs().max()) <= 5e-2
+    # deterministic: same inputs, same bits
+    with torch.no_grad():
+        z2, lad2 = stack(xd)
+    assert torch.equal(z, z2) and torch.equal(lad, lad2)
+
+
+def test_config5_sylvester_d128_m32_large_batch(device):
+    """configs[4] (non-conditional class, SURVEY.md headline facts): N=2^18, D=128, M=32."""
+    torch.manual_seed(0)
+    t = T.SylvesterTransform(features=128, num_householder=32, device="cpu")
+    with torch.no_grad():
+        t.Q_orth.q_vectors.copy_(torch.randn(32, 128))
+    n = 1 << 18
+    x = torch.randn(n, 128)
+    with torch.no_grad():
+        y_ref, lad_ref = O.transform_apply(t, x[:128].clone())
+        y, lad = t.to(device)(x.to(device))
+    assert torch.isfinite(y).all() and torch.isfinite(lad).all()
+    assert maxdiff(y[:128], y_ref) <= 3e-5 * max(1.0, float(y_ref.abs().max()))
+    assert maxdiff(lad[:128], lad_ref) <= 1e-4 * max(1.0, float(lad_ref.abs().max()))
+    # the tail rows go through the same code path as the head rows
+    with torch.no_grad():
+        y_tail, lad_tail = t(x[-128:].to(device))
+    assert torch.equal(y_tail, y[-128:]) and torch.equal(lad_tail, lad[-128:])

@@ -1,0 +1,140 @@
+"""Host-side behaviour of the Transform mirror that needs no GPU: constructor checks, buffers,
+state_dict keys, error types raised before any kernel launch, mask builders, MADE masks."""
+import pytest
+import torch
+
+from _util import Lib
+
+T, nets, utils = Lib.transforms, Lib.nets, Lib.utils
+
+
+def _net(i, o):
+    return nets.ResidualNet(i, o, hidden_features=8)
+
+
+def test_coupling_constructor_checks_and_buffers():
+    with pytest.raises(ValueError):
+        T.AffineCouplingTransform(torch.zeros(2, 2), _net)
+    with pytest.raises(ValueError):
+        T.AffineCouplingTransform(torch.zeros(0), _net)
+    t = T.PiecewiseRationalQuadraticCouplingTransform([1, -1, 1, 0, 1], _net, num_bins=4, tails="linear")
+    assert t.identity_features.tolist() == [1, 3] and t.transform_features.tolist() == [0, 2, 4]
+    assert t.identity_features.dtype == torch.int64
+    assert t.transform_net.final_layer.out_features == 3 * (3 * 4 - 1)
+    assert set(k.split(".")[0] for k in t.state_dict()) == {"identity_features", "transform_features", "transform_net"}
+    with pytest.raises(ValueError, match="2D or a 4D"):
+        t(torch.zeros(3, 5, 2))
+    with pytest.raises(ValueError, match="Expected features"):
+        t(torch.zeros(3, 4))
+
+
+def test_transform_dim_multipliers():
+    m = utils.create_alternating_binary_mask(6)
+    assert T.PiecewiseRationalQuadraticCouplingTransform(m, _net, num_bins=8)._transform_dim_multiplier() == 25
+    assert T.PiecewiseRationalQuadraticCouplingTransform(m, _net, num_bins=8, tails="linear")._transform_dim_multiplier() == 23
+    assert T.PiecewiseQuadraticCouplingTransform(m, _net, num_bins=8, tails="linear")._transform_dim_multiplier() == 15
+    assert T.PiecewiseQuadraticCouplingTransform(m, _net, num_bins=8)._transform_dim_multiplier() == 17
+    assert T.PiecewiseCubicCouplingTransform(m, _net, num_bins=8)._transform_dim_multiplier() == 18
+    assert T.PiecewiseLinearCouplingTransform(m, _net, num_bins=8)._transform_dim_multiplier() == 8
+    assert T.AffineCouplingTransform(m, _net)._transform_dim_multiplier() == 2
+    assert T.AdditiveCouplingTransform(m, _net)._transform_dim_multiplier() == 1
+
+
+def test_masks():
+    assert utils.create_alternating_binary_mask(5).tolist() == [1, 0, 1, 0, 1]
+    assert utils.create_alternating_binary_mask(5, even=False).tolist() == [0, 1, 0, 1, 0]
+    assert utils.create_mid_split_binary_mask(5).tolist() == [1, 1, 1, 0, 0]
+    m = utils.create_random_binary_mask(7)
+    assert int(m.sum()) == 4 and m.dtype == torch.uint8
+
+
+def test_made_is_autoregressive():
+    """Output block for feature i may depend on inputs < i only (reference autoregressive_test.py:36-41)."""
+    torch.manual_seed(0)
+    made = T.made.MADE(features=5, hidden_features=16, output_multiplier=3, num_blocks=2)
+    x = torch.randn(4, 5, requires_grad=True)
+    out = made(x).view(4, 5, 3)
+    for i in range(5):
+        g = torch.autograd.grad(out[:, i].sum(), x, retain_graph=True)[0]
+        assert float(g[:, i:].abs().max()) == 0.0, i
+        if i > 0:
+            assert float(g[:, :i].abs().max()) > 0.0
+
+
+def test_permutation_checks():
+    with pytest.raises(ValueError):
+        T.Permutation(torch.zeros(2, 2, dtype=torch.long))
+    with pytest.raises(ValueError):
+        T.Permutation(torch.arange(3), dim=0)
+    with pytest.raises(ValueError):
+        T.RandomPermutation(0)
+    p = T.ReversePermutation(4)
+    assert p._permutation.tolist() == [3, 2, 1, 0] and list(p.state_dict()) == ["_permutation"]
+    with pytest.raises(ValueError, match="No dimension"):
+        T.Permutation(torch.arange(3), dim=2)(torch.zeros(2, 3))
+    with pytest.raises(ValueError, match="must be of size"):
+        p(torch.zeros(2, 5))
+
+
+def test_misc_constructor_errors():
+    with pytest.raises(ValueError):
+        T.PointwiseAffineTransform(scale=torch.tensor([1.0, 0.0]))
+    with pytest.raises(TypeError):
+        T.ActNorm(0)
+    with pytest.raises(TypeError):
+        T.BatchNorm(1.5)
+    with pytest.raises(TypeError):
+        T.LULinear(0)
+    with pytest.raises(ValueError):
+        T.LogTanh(cut_point=0)
+    with pytest.raises(ValueError):
+        T.LeakyReLU(negative_slope=0)
+    with pytest.raises(TypeError):
+        T.HouseholderSequence(3, 0)
+    with pytest.raises(T.InverseNotAvailable):
+        T.Transform().inverse(torch.zeros(1, 1))
+    bn = T.BatchNorm(3)
+    bn.train()
+    with pytest.raises(T.InverseNotAvailable):
+        bn.inverse(torch.zeros(2, 3))
+
+
+def test_state_dict_names_match_reference_layout():
+    """Parameter / buffer names are the de-facto checkpoint format."""
+    assert set(T.ActNorm(3).state_dict()) == {"initialized", "log_scale", "shift"}
+    assert set(T.BatchNorm(3).state_dict()) == {"unconstrained_weight", "bias", "running_mean", "running_var"}
+    assert set(T.LULinear(3).state_dict()) == {"bias", "lower_entries", "upper_entries", "unconstrained_upper_diag"}
+    assert set(T.HouseholderSequence(4, 2).state_dict()) == {"q_vectors"}
+    assert set(T.PlanarTransform(3).state_dict()) == {"w", "b", "u"}
+    assert set(T.SylvesterTransform(3, device="cpu").state_dict()) == {
+        "upper_entries1", "log_upper_diag1", "upper_entries2", "log_upper_diag2", "bias", "Q_orth.q_vectors"}
+    maf = T.MaskedAffineAutoregressiveTransform(features=3, hidden_features=8)
+    keys = set(maf.state_dict())
+    assert "autoregressive_net.initial_layer.mask" in keys and "autoregressive_net.final_layer.degrees" in keys
+    assert "autoregressive_net.blocks.0.linear_layers.1.weight" in keys
+
+
+def test_householder_default_init_is_identity_pairs():
+    q = T.HouseholderSequence(5, 5).q_vectors.detach()
+    assert q.tolist() == [[1, 0, 0, 0, 0], [1, 0, 0, 0, 0], [0, 1, 0, 0, 0], [0, 1, 0, 0, 0], [0, 0, 1, 0, 0]]
+
+
+def test_linear_cache_semantics():
+    t = T.LULinear(4, using_cache=True)
+    assert t.cache.weight is None
+    t.eval()
+    t._check_forward_cache()
+    assert t.cache.weight is not None and t.cache.logabsdet is not None
+    t.train()
+    assert t.cache.weight is None and t.cache.inverse is None
+    with pytest.raises(TypeError):
+        t.use_cache("yes")
+
+
+def test_deferred_error_state_resets():
+    from flowconductor_amd import ops
+
+    with pytest.raises(RuntimeError):
+        with ops.deferred_errors():
+            raise RuntimeError("boom")
+    assert ops._state.depth == 0 and not ops._state.dirty

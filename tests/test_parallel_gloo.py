@@ -1,0 +1,80 @@
+"""N > 1 path on CPU: world_size-2 gloo processes run the batch-sharded log_prob reduction of
+flowconductor_amd.parallel (the HIP kernels need a GPU, so each rank's local log_prob here is the
+CPU oracle evaluating the same flow -- what is under test is sharding + the {sum, count} all-reduce)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _flow():
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+    from _util import Lib
+
+    torch.manual_seed(0)
+    d = 6
+    layers = [Lib.transforms.PiecewiseRationalQuadraticCouplingTransform(
+        Lib.utils.create_alternating_binary_mask(d, even=(l % 2 == 0)),
+        lambda i, o: Lib.nets.ResidualNet(i, o, hidden_features=8), num_bins=4, tails="linear", tail_bound=3.0)
+        for l in range(2)]
+    return Lib.flows.Flow(Lib.transforms.CompositeTransform(layers), Lib.distributions.StandardNormal([d])).eval()
+
+
+def _worker(rank, world, port, n, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flowconductor_amd import parallel
+        from oracle import torch_oracle as O
+
+        flow = _flow()
+        x = torch.randn(n, 6, generator=torch.Generator().manual_seed(7))
+        lo, hi = parallel.shard_bounds(n, rank, world)
+        with torch.no_grad():
+            mean = parallel.sharded_log_prob_mean(lambda v: O.flow_log_prob(flow, v), x[lo:hi], chunk=5,
+                                                  group=dist.group.WORLD)
+        if rank == 0:
+            torch.save({"mean": mean, "bounds": [parallel.shard_bounds(n, r, world) for r in range(world)]}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [37, 64])
+def test_sharded_log_prob_mean_world2(tmp_path, n):
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(2, _free_port(), n, out), nprocs=2, join=True)
+    res = torch.load(out)
+    assert res["bounds"][0][0] == 0 and res["bounds"][-1][1] == n
+    assert res["bounds"][0][1] == res["bounds"][1][0]
+    from oracle import torch_oracle as O
+
+    flow = _flow()
+    x = torch.randn(n, 6, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        expect = float(O.flow_log_prob(flow, x).double().mean())
+    assert abs(res["mean"] - expect) <= 1e-5 * max(1.0, abs(expect))
+
+
+def test_shard_bounds_cover_everything():
+    from flowconductor_amd import parallel
+
+    for n in (0, 1, 7, 8, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
