@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libflowcon_hip.so")
+# FLOWCON_HIP_LIB points profiling tools at an ablation build of the same ABI (tools/ only)
+LIB_PATH = os.environ.get("FLOWCON_HIP_LIB") or os.path.join(_HERE, "csrc", "libflowcon_hip.so")
 
 ABI_VERSION = 1
 

@@ -7,6 +7,7 @@
 //            (utils/torchutils.py:147-149), forward rational-quadratic / inverse quadratic root.
 // One thread evaluates one (sample, dim); the K unnormalised widths/heights sit in LDS and
 // are walked with static offsets so no runtime-indexed register array (-> scratch) exists.
+#include <stdlib.h>
 #include "fc_tile.h"
 #include "fc_math.h"
 #include "../../include/flowcon_hip.h"
@@ -30,7 +31,7 @@ struct RQParams {
 // select: take bin `idx`. Returns lower knot and bin size of the chosen bin.
 template <int KS, bool kSearch>
 __device__ __forceinline__ void walk_axis(const float* __restrict__ u, int K, float inv_scale,
-                                          bool scale_by_mul, float scale_div, float minb, float c1,
+                                          float minb, float c1,
                                           float lo, float hi, float v, int& idx, float& knot_lo,
                                           float& bin_size) {
   const float span = hi - lo;
@@ -39,16 +40,16 @@ __device__ __forceinline__ void walk_axis(const float* __restrict__ u, int K, fl
     float m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
-      t[i] = scale_by_mul ? u[i] * inv_scale : u[i] / scale_div;
+      t[i] = u[i] * inv_scale;
       m = fmaxf(m, t[i]);
     }
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
-      t[i] = expf(t[i] - m);
+      t[i] = exp_lean(t[i] - m);
       sum += t[i];
     }
-    const float rs = 1.f / sum;
+    const float rs = div_lean(1.f, sum);
     double cum = 0.0;  // at::cumsum on the CPU accumulates f32 in double
     float prev = lo;
     int found = kSearch ? 0 : idx;
@@ -73,22 +74,22 @@ __device__ __forceinline__ void walk_axis(const float* __restrict__ u, int K, fl
   } else {
     float m = -INFINITY;
     for (int i = 0; i < K; ++i) {
-      const float t = scale_by_mul ? u[i] * inv_scale : u[i] / scale_div;
+      const float t = u[i] * inv_scale;
       m = fmaxf(m, t);
     }
     float sum = 0.f;
     for (int i = 0; i < K; ++i) {
-      const float t = scale_by_mul ? u[i] * inv_scale : u[i] / scale_div;
-      sum += expf(t - m);
+      const float t = u[i] * inv_scale;
+      sum += exp_lean(t - m);
     }
-    const float rs = 1.f / sum;
+    const float rs = div_lean(1.f, sum);
     double cum = 0.0;
     float prev = lo;
     int found = kSearch ? 0 : idx;
     float klo = lo, bsz = 0.f;
     for (int i = 0; i < K; ++i) {
-      const float t = scale_by_mul ? u[i] * inv_scale : u[i] / scale_div;
-      const float p = expf(t - m) * rs;
+      const float t = u[i] * inv_scale;
+      const float p = exp_lean(t - m) * rs;
       const float w = minb + c1 * p;
       cum += (double)w;
       const float next = (i == K - 1) ? hi : (span * (float)cum + lo);
@@ -106,19 +107,90 @@ __device__ __forceinline__ void walk_axis(const float* __restrict__ u, int K, fl
   }
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// exp(x) for x <= 0 in the softmax: 2^(x*log2e) without the product-error compensation of exp_lean.
+// The relative error grows as |x| * 6e-8, i.e. only on bins whose softmax weight is already small.
+__device__ __forceinline__ float exp_softmax(float x) {
+  return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+}
+
+// Both cumulative axes in one pass, widths in .x and heights in .y so that the mul/add chain maps to
+// packed v_pk_{mul,add}_f32 (2 lanes of work per VALU slot).  The bin is searched on one axis
+// (kSearchX: widths, forward; else heights, inverse); knots are monotone, so "last bin whose lower
+// knot <= v" is tracked by one predicate that selects on both axes.
+template <int KS, bool kSearchX>
+__device__ __forceinline__ void walk_both(const float* __restrict__ uw, const float* __restrict__ uh,
+                                          float inv_scale, f2 minb, f2 c1, f2 lo, f2 hi, float v, int& idx,
+                                          f2& knot_lo, f2& bin_size) {
+  f2 t[KS > 0 ? KS : 1];
+  float mx = -INFINITY, my = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    t[i] = f2{uw[i], uh[i]} * inv_scale;
+    mx = fmaxf(mx, t[i].x);
+    my = fmaxf(my, t[i].y);
+  }
+  const f2 m = {mx, my};
+  f2 sum = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    const f2 d = t[i] - m;
+    t[i] = f2{exp_softmax(d.x), exp_softmax(d.y)};
+    sum += t[i];
+  }
+  const f2 rs = {div_lean(1.f, sum.x), div_lean(1.f, sum.y)};
+  const f2 span = hi - lo;
+  double cx = 0.0, cy = 0.0;  // at::cumsum on the CPU accumulates f32 in double
+  f2 prev = lo, sel_lo = lo, sel_hi = lo;
+  int found = 0;
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    const f2 p = t[i] * rs;
+    const f2 w = minb + c1 * p;
+    cx += (double)w.x;
+    cy += (double)w.y;
+    const f2 cum = {(float)cx, (float)cy};
+    const f2 next = (i == KS - 1) ? hi : (span * cum + lo);
+    const bool take = v >= (kSearchX ? prev.x : prev.y);
+    sel_lo.x = take ? prev.x : sel_lo.x;
+    sel_lo.y = take ? prev.y : sel_lo.y;
+    sel_hi.x = take ? next.x : sel_hi.x;
+    sel_hi.y = take ? next.y : sel_hi.y;
+    found = take ? i : found;
+    prev = next;
+  }
+  idx = found;
+  knot_lo = sel_lo;
+  bin_size = sel_hi - sel_lo;
+}
+
 template <int KS>
 struct RQOp {
   static constexpr bool kHasPrepare = false;
   __device__ void prepare(float*, int, int) const {}
   RQParams q;
-  float inv_div;
-  bool mul_exact;
+  float inv_div;  // unnormalised widths/heights are multiplied by 1/wh_div (exact for the usual
+                  // power-of-two sqrt(hidden_features); otherwise within 1 ulp of the reference's division)
 
   __device__ __forceinline__ void eval(const float* __restrict__ prow, int j, int d_t, float x,
                                        float& y, float& lad, uint32_t& err) const {
     const int K = KS > 0 ? KS : q.K;
     const int P = q.tails ? 3 * K - 1 : 3 * K + 1;
-    const float* p = prow + j * P;
+    eval_core<false>(prow + j * P, x, y, lad, err);
+  }
+
+  // p -> the P raw values of one (sample, dim): an LDS pointer, or (kRegs) a register array that
+  // must only be indexed statically, so the two derivatives are picked with a select chain.
+  template <bool kRegs>
+  __device__ __forceinline__ void eval_core(const float* __restrict__ p, float x, float& y, float& lad,
+                                            uint32_t& err) const {
+    const int K = KS > 0 ? KS : q.K;
+#ifdef FC_PROBE_SKIP_EVAL  // tools/ ablation build only: data movement without the spline arithmetic
+    y = x + p[0] * 0.f;
+    lad = 0.f;
+    return;
+#endif
 
     // rational_quadratic.py:26-38 / :81-82
     const bool inside = (x >= q.left) && (x <= q.right);
@@ -131,36 +203,56 @@ struct RQOp {
 
     int idx = 0;
     float xk, wk, yk, hk;
-    if (!q.inverse) {
-      walk_axis<KS, true>(p, K, inv_div, mul_exact, q.wh_div, q.min_w, q.cw, q.left, q.right, x,
+    if constexpr (KS > 0) {
+      const f2 minb = {q.min_w, q.min_h}, c1 = {q.cw, q.ch};
+      const f2 lo = {q.left, q.bottom}, hi = {q.right, q.top};
+      f2 klo, bsz;
+      if (!q.inverse)
+        walk_both<KS, true>(p, p + K, inv_div, minb, c1, lo, hi, x, idx, klo, bsz);
+      else
+        walk_both<KS, false>(p, p + K, inv_div, minb, c1, lo, hi, x, idx, klo, bsz);
+      xk = klo.x; yk = klo.y; wk = bsz.x; hk = bsz.y;
+    } else if (!q.inverse) {
+      walk_axis<KS, true>(p, K, inv_div, q.min_w, q.cw, q.left, q.right, x,
                           idx, xk, wk);
-      walk_axis<KS, false>(p + K, K, inv_div, mul_exact, q.wh_div, q.min_h, q.ch, q.bottom, q.top,
+      walk_axis<KS, false>(p + K, K, inv_div, q.min_h, q.ch, q.bottom, q.top,
                            x, idx, yk, hk);
     } else {
-      walk_axis<KS, true>(p + K, K, inv_div, mul_exact, q.wh_div, q.min_h, q.ch, q.bottom, q.top,
+      walk_axis<KS, true>(p + K, K, inv_div, q.min_h, q.ch, q.bottom, q.top,
                           x, idx, yk, hk);
-      walk_axis<KS, false>(p, K, inv_div, mul_exact, q.wh_div, q.min_w, q.cw, q.left, q.right, x,
+      walk_axis<KS, false>(p, K, inv_div, q.min_w, q.cw, q.left, q.right, x,
                            idx, xk, wk);
     }
 
     // derivatives at the two knots of the bin (rational_quadratic.py:33-36, :100-104)
     const float* ud = p + 2 * K;
     float u0, u1;
-    if (q.tails) {
+    if (kRegs && KS > 0) {
+      // padded derivative row: linear tails [c, ud_0..ud_{K-2}, c]; none [ud_0..ud_K]
+      u0 = q.tails ? q.tail_const : ud[0];
+      u1 = q.tails ? q.tail_const : ud[KS];
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        const float lo_i = q.tails ? (i == 0 ? q.tail_const : ud[i > 0 ? i - 1 : 0]) : ud[i];
+        const float hi_i = q.tails ? (i == KS - 1 ? q.tail_const : ud[i < KS - 1 ? i : 0]) : ud[i + 1];
+        u0 = idx == i ? lo_i : u0;
+        u1 = idx == i ? hi_i : u1;
+      }
+    } else if (q.tails) {
       u0 = idx == 0 ? q.tail_const : ud[idx - 1];
       u1 = idx == K - 1 ? q.tail_const : ud[idx];
     } else {
       u0 = ud[idx];
       u1 = ud[idx + 1];
     }
-    const float d0 = q.min_d + softplus_b(u0, q.beta);
-    const float d1 = q.min_d + softplus_b(u1, q.beta);
-    const float delta = hk / wk;
+    const float d0 = q.min_d + softplus_lean(u0, q.beta);
+    const float d1 = q.min_d + softplus_lean(u1, q.beta);
+    const float delta = div_lean(hk, wk);
     const float dsum = d0 + d1 - 2.f * delta;
 
     float theta;
     if (!q.inverse) {
-      theta = (x - xk) / wk;
+      theta = div_lean(x - xk, wk);
     } else {
       // rational_quadratic.py:133-146
       const float r = x - yk;
@@ -169,16 +261,16 @@ struct RQOp {
       const float qc = -delta * r;
       const float disc = qb * qb - 4.f * qa * qc;
       if (!(disc >= 0.f)) err |= kErrDiscriminant;
-      theta = (2.f * qc) / (-qb - sqrtf(disc));
+      theta = div_lean(2.f * qc, -qb - sqrt_lean(disc));
     }
     const float t1mt = theta * (1.f - theta);
     const float den = delta + dsum * t1mt;
     const float omt = 1.f - theta;
     const float dnum = (delta * delta) * (d1 * (theta * theta) + 2.f * delta * t1mt + d0 * (omt * omt));
-    const float l = logf(dnum) - 2.f * logf(den);
+    const float l = log_lean(dnum) - 2.f * log_lean(den);
     if (!q.inverse) {
       const float num = hk * (delta * (theta * theta) + d0 * t1mt);
-      y = yk + num / den;
+      y = yk + div_lean(num, den);
       lad = l;
     } else {
       y = theta * wk + xk;
@@ -187,14 +279,117 @@ struct RQOp {
   }
 };
 
+// ---- wave-independent variant: parameters straight into registers ----------------------------------
+//
+// One wavefront owns G = 64 / d_t consecutive samples: lane (s, j) loads the P raw values of its own
+// (sample, dim) -- a contiguous P*4-byte chunk, the 64 chunks of a wave forming ONE contiguous span of
+// the conditioner output -- directly into registers.  No LDS image of the parameters, no workgroup
+// barrier: waves drift freely, so one wave's HBM wait is another wave's arithmetic.  Only the G input
+// rows (G*D floats) pass through a per-wave LDS strip so that identity columns are copied and global
+// x / y traffic stays coalesced.  Requires d_t a power of two <= 64 and a compile-time K.
+template <int KS, bool kTails>
+__global__ __launch_bounds__(256) void rq_wave_kernel(RQOp<KS> op, TileArgs a, int64_t groups) {
+  constexpr int P = KS > 0 ? (kTails ? 3 * KS - 1 : 3 * KS + 1) : 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int d_t = a.d_t, D = a.D;
+  const int sh = __builtin_ctz(d_t);
+  const int G = 64 >> sh;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int* cs = reinterpret_cast<int*>(smem);
+  float* xw = smem + round4(d_t) + wave * round4(G * D);
+  for (int j = threadIdx.x; j < d_t; j += blockDim.x) cs[j] = a.cols ? a.cols[j] : j;
+  __syncthreads();
+  const int s = lane >> sh, j = lane & (d_t - 1);
+  const int col = cs[j];
+  const int row_floats = G * D;
+  uint32_t err = 0;
+  const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+  // 16-byte loads through a 4-byte aligned vector type (the lane's chunk is P*4 bytes from its
+  // neighbour's, so only dword aligned; global memory allows it): ~P/4 load instructions, not P
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  auto load_params = [&](float (&dst)[P], int64_t g) {
+    const float* __restrict__ pp = a.params + (g * 64 + lane) * P;  // (n0 * d_t + lane) * P, n0 = g * G
+#pragma unroll
+    for (int i = 0; i + 4 <= P; i += 4) {
+      const f4u v = *reinterpret_cast<const f4u*>(pp + i);
+      dst[i] = v.x; dst[i + 1] = v.y; dst[i + 2] = v.z; dst[i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = P & ~3; i < P; ++i) dst[i] = pp[i];
+  };
+  // (a register double-buffer prefetching the next group's parameters was measured: +31 VGPRs, no
+  //  gain -- 4 resident waves per SIMD already cover the load latency; the kernel sits at ~80 % of the
+  //  per-CU load-path rate)
+  for (int64_t g = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave; g < groups; g += wstride) {
+    const int64_t n0 = g * G;
+    float p[P];
+    load_params(p, g);
+    const float* __restrict__ xg = a.x + n0 * D;
+    if ((row_floats & 255) == 0) {
+      for (int i = lane; i < (row_floats >> 2); i += 64)
+        reinterpret_cast<float4*>(xw)[i] = reinterpret_cast<const float4*>(xg)[i];
+    } else if ((row_floats & 127) == 0) {
+      for (int i = lane; i < (row_floats >> 1); i += 64)
+        reinterpret_cast<float2*>(xw)[i] = reinterpret_cast<const float2*>(xg)[i];
+    } else {
+      for (int i = lane; i < row_floats; i += 64) xw[i] = xg[i];
+    }
+    const float xv = xw[s * D + col];
+    float yv, lad;
+    op.template eval_core<true>(p, xv, yv, lad, err);
+    xw[s * D + col] = yv;
+    if (a.logabsdet) {
+      const float tot = group_sum_rt(lad, d_t);
+      if (j == 0) a.logabsdet[n0 + s] = (a.lad_mode & 2) ? -tot : tot;
+    }
+    float* __restrict__ yg = a.y + n0 * D;
+    if ((row_floats & 255) == 0) {
+      for (int i = lane; i < (row_floats >> 2); i += 64)
+        reinterpret_cast<float4*>(yg)[i] = reinterpret_cast<const float4*>(xw)[i];
+    } else if ((row_floats & 127) == 0) {
+      for (int i = lane; i < (row_floats >> 1); i += 64)
+        reinterpret_cast<float2*>(yg)[i] = reinterpret_cast<const float2*>(xw)[i];
+    } else {
+      for (int i = lane; i < row_floats; i += 64) yg[i] = xw[i];
+    }
+  }
+  if (err && a.err) atomicOr(a.err, err);
+}
+
 template <int KS>
-static hipError_t launch_rq(const RQParams& q, const TileArgs& a, hipStream_t stream) {
+static hipError_t launch_rq(const RQParams& q, TileArgs a, hipStream_t stream) {
   RQOp<KS> op;
   op.q = q;
   op.inv_div = 1.f / q.wh_div;
-  // x / d == x * (1/d) bit-for-bit only when d is a power of two
-  int ex;
-  op.mul_exact = frexpf(q.wh_div, &ex) == 0.5f;
+  const bool pow2 = (a.d_t & (a.d_t - 1)) == 0 && a.d_t <= 64;
+  const char* force = getenv("FC_RQ_PATH");  // "tile" / "wave": pin one structure (A/B measurements)
+  if constexpr (KS > 0 && KS <= 10)
+  if (pow2 && !a.shared_params && a.N > 0 && a.lad_mode != 1 && a.lad_mode != 3 &&
+      !(force && force[0] == 't')) {
+    const int G = 64 / a.d_t;
+    const int64_t groups = a.N / G;
+    const bool al = ((G * a.D) % 4 != 0) || (aligned16(a.x) && aligned16(a.y));
+    if (groups >= 256 && al) {
+      const size_t lds = sizeof(float) * (size_t)(round4(a.d_t) + 4 * round4(G * a.D));
+      int64_t grid = (int64_t)device_cu_count() * 6;
+      if (grid > (groups + 3) / 4) grid = (groups + 3) / 4;
+      TileArgs body = a;
+      if (q.tails)
+        hipLaunchKernelGGL((rq_wave_kernel<KS, true>), dim3((unsigned)grid), dim3(256), lds, stream, op, body, groups);
+      else
+        hipLaunchKernelGGL((rq_wave_kernel<KS, false>), dim3((unsigned)grid), dim3(256), lds, stream, op, body, groups);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return e;
+      const int64_t done = groups * G;
+      if (done == a.N) return hipSuccess;
+      const int P = q.tails ? 3 * KS - 1 : 3 * KS + 1;
+      a.x += done * a.D;
+      a.y += done * a.D;
+      a.params += done * (int64_t)a.d_t * P;
+      if (a.logabsdet) a.logabsdet += done;
+      a.N -= done;
+    }
+  }
   return launch_tile(op, a, stream);
 }
 

@@ -179,6 +179,131 @@ __global__ __launch_bounds__(kMaxBlock) void tile_kernel(Op op, TileArgs a) {
   if (err && a.err) atomicOr(a.err, err);
 }
 
+// ---- persistent, register-prefetching variant ---------------------------------------------------
+//
+// Same tile algorithm, restructured for memory-level parallelism: a resident workgroup walks tiles
+// b, b + G, b + 2G, ... and issues the 16-byte global loads of its NEXT tile into registers right
+// after it has parked the current tile in LDS, so the HBM latency of tile t+1 is covered by the
+// evaluation and the store of tile t.  (With one tile per workgroup every wave spent ~75 % of its
+// life in s_waitcnt for its own loads: rocprofv3 SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/.)
+// No global load may sit inside the evaluation phase -- vmcnt is an in-order counter, waiting for
+// any later load would also drain the prefetch -- so `cols` is staged in LDS once.
+// Handles full tiles only; the host runs the < S leftover samples through tile_kernel.
+template <class Op, int NVP, int NVX>
+__global__ __launch_bounds__(kMaxBlock) void tile_kernel_pf(Op op, TileArgs a, int64_t num_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int S = a.S, D = a.D, d_t = a.d_t, rowlen = a.rowlen;
+  float* ps = smem;
+  float* xs = ps + round4(S * rowlen);
+  float* ls = xs + round4(S * D);
+  int* cs = reinterpret_cast<int*>(ls + round4(S * d_t));
+  const int tid = threadIdx.x;
+  const int pvec = (S * rowlen) >> 2, xvec = (S * D) >> 2;
+
+  for (int j = tid; j < d_t; j += kMaxBlock) cs[j] = a.cols ? a.cols[j] : j;
+
+  float4 pr[NVP], xr[NVX];
+  int64_t tile = blockIdx.x;
+  if (tile < num_tiles) {
+    const float4* pg = reinterpret_cast<const float4*>(a.params + tile * S * rowlen);
+    const float4* xg = reinterpret_cast<const float4*>(a.x + tile * S * D);
+    // unconditional loads with a clamped index keep pr/xr in registers (a predicated load leaves the
+    // array "maybe uninitialised" and hipcc demotes it to scratch)
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) pr[k] = pg[min(tid + k * kMaxBlock, pvec - 1)];
+#pragma unroll
+    for (int k = 0; k < NVX; ++k) xr[k] = xg[min(tid + k * kMaxBlock, xvec - 1)];
+  } else {
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) pr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < NVX; ++k) xr[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  const bool pow2 = (d_t & (d_t - 1)) == 0 && d_t <= 64;
+  const int total = S * d_t;
+  const int padded = ((total + 63) / 64) * 64;
+  uint32_t err = 0;
+
+  for (; tile < num_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * S;
+#pragma unroll
+    for (int k = 0; k < NVP; ++k)
+      if (tid + k * kMaxBlock < pvec) reinterpret_cast<float4*>(ps)[tid + k * kMaxBlock] = pr[k];
+#pragma unroll
+    for (int k = 0; k < NVX; ++k)
+      if (tid + k * kMaxBlock < xvec) reinterpret_cast<float4*>(xs)[tid + k * kMaxBlock] = xr[k];
+    __syncthreads();
+
+    const int64_t next = tile + gridDim.x;
+    if (next < num_tiles) {
+      const float4* pg = reinterpret_cast<const float4*>(a.params + next * S * rowlen);
+      const float4* xg = reinterpret_cast<const float4*>(a.x + next * S * D);
+#pragma unroll
+      for (int k = 0; k < NVP; ++k) pr[k] = pg[min(tid + k * kMaxBlock, pvec - 1)];
+#pragma unroll
+      for (int k = 0; k < NVX; ++k) xr[k] = xg[min(tid + k * kMaxBlock, xvec - 1)];
+    }
+
+    if (Op::kHasPrepare) {
+      for (int e = tid; e < total; e += kMaxBlock) {
+        const int s = e / d_t, j = e - s * d_t;
+        op.prepare(ps + s * rowlen, j, d_t);
+      }
+      __syncthreads();
+    }
+
+    for (int e = tid; e < padded; e += kMaxBlock) {
+      int s, j;
+      if (pow2) {
+        const int sh = __builtin_ctz(d_t);
+        s = e >> sh;
+        j = e & (d_t - 1);
+      } else {
+        s = e / d_t;
+        j = e - s * d_t;
+      }
+      float lad = 0.f;
+      const bool live = e < total;
+      if (live) {
+        const int col = cs[j];
+        const float xv = xs[s * D + col];
+        float yv;
+        op.eval(ps + s * rowlen, j, d_t, xv, yv, lad, err);
+        xs[s * D + col] = yv;
+      }
+      if (a.logabsdet) {
+        if (pow2) {
+          const float tot = group_sum_rt(lad, d_t);
+          if (live && j == 0) ls[s] = tot;
+        } else if (live) {
+          ls[e] = lad;
+        }
+      }
+    }
+    __syncthreads();
+
+    if (a.logabsdet) {
+      // one coalesced store of the tile's S logabsdet values
+      for (int s = tid; s < S; s += kMaxBlock) {
+        float tot;
+        if (pow2) {
+          tot = ls[s];
+        } else {
+          tot = 0.f;
+          const float* r = ls + s * d_t;
+          for (int j = 0; j < d_t; ++j) tot += r[j];
+        }
+        a.logabsdet[n0 + s] = (a.lad_mode & 2) ? -tot : tot;
+      }
+    }
+    float4* yg = reinterpret_cast<float4*>(a.y + n0 * D);
+    for (int i = tid; i < xvec; i += kMaxBlock) yg[i] = reinterpret_cast<const float4*>(xs)[i];
+    __syncthreads();
+  }
+  if (err && a.err) atomicOr(a.err, err);
+}
+
 // ---- host-side launch ---------------------------------------------------------------
 
 struct TilePlan {
@@ -218,6 +343,37 @@ inline bool plan_tile(const TileArgs& a, TilePlan* plan) {
   return true;
 }
 
+inline int device_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  return cus;
+}
+
+template <class Op, int NVP, int NVX>
+inline hipError_t launch_tile_pf(const Op& op, const TileArgs& a, const TilePlan& plan, int64_t full_tiles,
+                                 hipStream_t stream) {
+  const size_t lds = plan.lds_bytes + sizeof(int) * (size_t)round4(a.d_t);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel_pf<Op, NVP, NVX>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 8) per_cu = 8;
+  if (per_cu < 1) per_cu = 1;
+  int64_t grid = (int64_t)device_cu_count() * per_cu;
+  if (grid > full_tiles) grid = full_tiles;
+  hipLaunchKernelGGL((tile_kernel_pf<Op, NVP, NVX>), dim3((unsigned)grid), dim3(kMaxBlock), lds, stream, op, a,
+                     full_tiles);
+  return hipGetLastError();
+}
+
 template <class Op>
 inline hipError_t launch_tile(const Op& op, TileArgs a, hipStream_t stream) {
   if (a.N <= 0) return hipSuccess;
@@ -225,6 +381,30 @@ inline hipError_t launch_tile(const Op& op, TileArgs a, hipStream_t stream) {
   if (!plan_tile(a, &plan)) return hipErrorInvalidConfiguration;
   a.S = plan.S;
   a.vec_ok = plan.vec_ok;
+
+  // Large per-sample-parameter batches: persistent prefetching kernel on the full tiles, then the
+  // < S leftover samples through the one-tile-per-workgroup kernel below.
+  const int64_t full_tiles = a.N / plan.S;
+  const int64_t pvec = ((int64_t)plan.S * a.rowlen) / 4, xvec = ((int64_t)plan.S * a.D) / 4;
+  if (plan.vec_ok && !a.shared_params && plan.block == kMaxBlock && a.lad_mode != 1 && a.lad_mode != 3 &&
+      full_tiles >= 64 && pvec <= 8 * kMaxBlock && xvec <= 2 * kMaxBlock) {
+    TileArgs body = a;
+    body.N = full_tiles * plan.S;
+    hipError_t e = (pvec <= 6 * kMaxBlock && xvec <= kMaxBlock)
+                       ? launch_tile_pf<Op, 6, 1>(op, body, plan, full_tiles, stream)
+                       : launch_tile_pf<Op, 8, 2>(op, body, plan, full_tiles, stream);
+    if (e != hipSuccess) return e;
+    const int64_t done = body.N;
+    if (done == a.N) return hipSuccess;
+    a.x += done * a.D;
+    a.y += done * a.D;
+    a.params += done * a.rowlen;
+    if (a.logabsdet) a.logabsdet += done;
+    a.N -= done;
+    if (!plan_tile(a, &plan)) return hipErrorInvalidConfiguration;
+    a.S = plan.S;
+    a.vec_ok = plan.vec_ok;
+  }
   if (plan.grid > 0x7fffffffLL) return hipErrorInvalidConfiguration;
   dim3 grid((unsigned)plan.grid), block((unsigned)plan.block);
   if (plan.lds_bytes > 64 * 1024) {

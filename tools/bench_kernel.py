@@ -1,0 +1,50 @@
+"""Times one bijector kernel in isolation on the BASELINE.json cfg-3 layer shape and prints achieved
+algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [rq|rq_inv|affine]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from flowconductor_amd import ops  # noqa: E402
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "rq"
+    n = 1 << int(os.environ.get("LOG2N", "20"))
+    d, d_t, k = 64, 32, 8
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    x = torch.randn(n, d, device=dev) * 1.5
+    cols = torch.arange(0, d, 2, dtype=torch.int32, device=dev)
+    if which.startswith("rq"):
+        p = 3 * k - 1
+        params = torch.randn(n, d_t * p, device=dev)
+        fn = lambda: ops.rq_spline(x, params, cols, num_bins=k, tails="linear", tail_bound=3.0,  # noqa: E731
+                                   wh_divisor=8.0, inverse=which == "rq_inv")
+        name = "fc_rq_spline"
+    else:
+        p = 2
+        params = torch.randn(n, d_t * p, device=dev)
+        fn = lambda: ops.affine_coupling(x, params, cols)  # noqa: E731
+        name = "fc_affine"
+    alg = (4 * d_t * (p + 2) + 8) * n
+    with torch.no_grad():
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        timer = ops.KernelTimer(name)
+        with timer:
+            for _ in range(20):
+                fn()
+        torch.cuda.synchronize()
+    ms = sorted(timer.durations_ms())
+    med = ms[len(ms) // 2]
+    print("%s N=2^%d: median %.4f ms  min %.4f  max %.4f  -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s), "
+          "actual bytes/alg = %.3f" % (which, n.bit_length() - 1, med, ms[0], ms[-1], alg / med / 1e6,
+                                       alg / med / 1e6 / 80.0, (4 * (d_t * p + 2 * d + 1)) / (4 * d_t * (p + 2) + 8)))
+
+
+if __name__ == "__main__":
+    main()
