@@ -328,6 +328,14 @@ inline bool plan_tile(const TileArgs& a, TilePlan* plan) {
     return sizeof(float) * (size_t)(round4(a.shared_params ? a.rowlen : s * a.rowlen) +
                                     round4(s * a.D) + round4(s * a.d_t));
   };
+  // cheap per-sample rows (affine, small D): grow the tile towards ~24 KiB so that the per-tile
+  // barriers and the load latency are amortised over more bytes (threads then loop over elements)
+  if (!a.shared_params) {
+    const size_t kTarget = 24 * 1024;
+    while (S >= 4 && bytes(S + 4) <= kTarget && (int64_t)(S + 4) * a.D <= 2 * 4 * kMaxBlock &&
+           (int64_t)(S + 4) * a.rowlen <= 8 * 4 * kMaxBlock && (int64_t)(S + 4) * 64 <= a.N)
+      S += 4;
+  }
   while (S > 4 && bytes(S) > kLdsSoft) S -= 4;
   while (S > 1 && bytes(S) > kLdsSoft) S -= 1;
   if (bytes(S) > kLdsHard) return false;
