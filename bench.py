@@ -43,6 +43,21 @@ def build_flow():
     return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([FEATURES])).eval()
 
 
+def measured_traffic_per_launch(rows_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (tools/profile_bench.sh: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs).  PMC counters
+    cannot be read from inside this process, so the number comes from profiles/; None if absent or if
+    this run's launch shape differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_rq_spline_hbm_traffic.json")
+    try:
+        rec = json.load(open(path))
+        if rows_per_launch != (1 << 20):
+            return None
+        return rec.get("traffic_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
 def algorithmic_bytes_per_sample_layer():
     """B = 4*d_t*(P + 2) + 8: params + x_t + y_t + logabsdet r/w."""
     d_t = FEATURES // 2
@@ -193,8 +208,10 @@ def main():
                        "chunk_rows": rows_per_launch, "parallelism": "batch-sharded dp%d" % world,
                        "mean_log_prob": mean_lp},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "fc_rq_spline (tile_kernel<RQOp<8>>)", "launches_timed": launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_per_launch(rows_per_launch),
+                         "traffic_source": "profiles/r01_rq_spline_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                                           "WRITE_SIZE passes of this command; FETCH_SIZE x2 gfx950 correction)",
+                         "kernel": "fc_rq_spline -> fc::rq_wave_kernel<8, true>", "launches_timed": launches,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "bijector_share_of_step": sum(kernel_ms) / (1e3 * elapsed) if elapsed else None},
         }
