@@ -81,7 +81,8 @@ SIGNATURES = {
     "fc_permute": [_P, _P, _P, _I64, _I32, _I64, _P],
     "fc_pointwise_affine": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],
     "fc_householder": [_P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P],
-    "fc_planar": [_P, _P, _P, _P, _P, _P, _I64, _I32, _P],
+    "fc_planar": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
+    "fc_linear_per_sample": [_P, _P, _P, _P, _I64, _I32, _I32, _F, _F, _P],
     "fc_linear": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _P],
     "fc_sylvester": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "fc_sum_of_sigmoids": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _F, _F, _F,

@@ -10,6 +10,7 @@
 //                                            s = softplus(u) + 1e-3
 //   flowcon/transforms/autoregressive/autoregressive.py:164-196
 //                                            MaskedShift: forward x + 2*tanh(p), inverse x - p
+//   flowcon/transforms/conditional.py:155-272      per-sample shift (additive) / scale = softplus(p) + 1e-5
 #include "fc_tile.h"
 #include "fc_math.h"
 #include "../../include/flowcon_hip.h"
@@ -43,6 +44,10 @@ struct AffineOp {
         s = softplus1(prow[2 * j]) + 1e-3f;
         shift = prow[2 * j + 1];
         break;
+      case FC_AFFINE_SCALE_SOFTPLUS:
+        shift = 0.f;
+        s = softplus1(prow[j]) + 1e-5f;
+        break;
       case FC_AFFINE_SHIFT_TANH2:
         shift = tanhf(prow[j]) * 2.f;
         s = 1.f;
@@ -71,13 +76,14 @@ extern "C" int fc_affine(const float* x, float* y, const float* params, const in
                          float* logabsdet, int64_t n, int32_t d, int32_t d_t, int32_t activation,
                          int32_t inverse, int32_t shared_params, int32_t lad_mode, void* stream) {
   if (n < 0 || d <= 0 || d_t <= 0 || d_t > d) return hipErrorInvalidValue;
-  if (activation < 0 || activation > FC_AFFINE_SHIFT_TANH2) return hipErrorInvalidValue;
+  if (activation < 0 || activation > FC_AFFINE_SCALE_SOFTPLUS) return hipErrorInvalidValue;
   if (n > 0 && (!x || !y || !params)) return hipErrorInvalidValue;
   fc::AffineOp op{activation, inverse};
   fc::TileArgs a{};
   a.x = x; a.y = y; a.params = params; a.cols = cols; a.logabsdet = logabsdet; a.err = nullptr;
   a.N = n; a.D = d; a.d_t = d_t;
-  a.rowlen = (activation == FC_AFFINE_ADDITIVE || activation == FC_AFFINE_SHIFT_TANH2) ? d_t : 2 * d_t;
+  a.rowlen = (activation == FC_AFFINE_ADDITIVE || activation == FC_AFFINE_SHIFT_TANH2 ||
+              activation == FC_AFFINE_SCALE_SOFTPLUS) ? d_t : 2 * d_t;
   a.shared_params = shared_params;
   a.lad_mode = lad_mode;
   return fc::launch_tile(op, a, static_cast<hipStream_t>(stream));

@@ -14,6 +14,7 @@
 //   flowcon/transforms/linear.py:45-76             cached dense weight / inverse path
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "fc_math.h"
 #include "../../include/flowcon_hip.h"
 
 namespace fc {
@@ -125,8 +126,8 @@ template <int E>
 __global__ __launch_bounds__(256) void planar_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                      float* __restrict__ lad, const float* __restrict__ w,
                                                      const float* __restrict__ u_hat, const float* __restrict__ b_ptr,
-                                                     int64_t n, int d) {
-  const float b = b_ptr[0];
+                                                     int64_t n, int d, int per_sample) {
+  float b = b_ptr[0];
   const int lane = threadIdx.x & 63;
   Row<E> wv, uv;
   load_row<E>(wv, w, d, lane);
@@ -135,6 +136,11 @@ __global__ __launch_bounds__(256) void planar_kernel(const float* __restrict__ x
   for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < n; row += stride) {
     Row<E> r;
     load_row<E>(r, x + row * d, d, lane);
+    if (per_sample) {
+      load_row<E>(wv, w + row * d, d, lane);
+      load_row<E>(uv, u_hat + row * d, d, lane);
+      b = b_ptr[row];
+    }
     const float a = dot_rows<E>(r, wv) + b;   // mm(inputs, w.T) + b
     const float t = tanhf(a);
     const float dt = 1.f - t * t;
@@ -256,6 +262,102 @@ __global__ __launch_bounds__(256) void sylvester_kernel(const float* __restrict_
   }
 }
 
+// Per-sample [d, d] matrices, row-major as emitted by a hyper-network.  Lane j holds x_j; output i is
+// a coalesced read of matrix row i, one multiply per lane and a 64-lane butterfly.  Modes: see header.
+template <int E>
+__global__ __launch_bounds__(256) void linear_per_sample_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                float* __restrict__ lad, const float* __restrict__ m,
+                                                                int64_t n, int d, int mode, float sp, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < n; row += stride) {
+    const float* mr = m + row * (int64_t)d * d;
+    Row<E> v, out;
+    load_row<E>(v, x + row * d, d, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) out.v[e] = 0.f;
+    float ld = 0.f;
+    if (mode == 0) {  // y_i = sum_j M_ij x_j
+      for (int i = 0; i < d; ++i) {
+        Row<E> mi;
+        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
+        const float s = dot_rows<E>(mi, v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] = s;
+      }
+    } else if (mode == 1) {  // y_j = sum_i M_ij x_i: row i scaled by the broadcast x_i
+      for (int i = 0; i < d; ++i) {
+        Row<E> mi;
+        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
+        const float xi = bcast<E>(v, i);
+#pragma unroll
+        for (int e = 0; e < E; ++e) out.v[e] += mi.v[e] * xi;
+      }
+    } else if (mode == 2) {  // t = U x, y = L t
+      Row<E> t;
+#pragma unroll
+      for (int e = 0; e < E; ++e) t.v[e] = 0.f;
+      for (int i = 0; i < d; ++i) {
+        Row<E> mi, ui;
+        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int j = lane + 64 * e;
+          const float dg = softplus1(mi.v[e]) + eps;
+          ui.v[e] = j > i ? sp * mi.v[e] : (j == i ? dg : 0.f);
+          if (j == i) ld += logf(dg);
+        }
+        const float s = dot_rows<E>(ui, v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (lane + 64 * e == i) t.v[e] = s;
+      }
+      for (int i = 0; i < d; ++i) {
+        Row<E> mi, li;
+        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int j = lane + 64 * e;
+          li.v[e] = j < i ? sp * mi.v[e] : (j == i ? 1.f : 0.f);
+        }
+        const float s = dot_rows<E>(li, t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] = s;
+      }
+      ld = wave_sum(ld);
+    } else {  // forward substitution with unit-lower L, then back substitution with U (no pivoting)
+      out = v;
+      for (int i = 0; i < d; ++i) {
+        Row<E> mi;
+        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (lane + 64 * e < i) part += sp * mi.v[e] * out.v[e];
+        part = wave_sum(part);
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] -= part;
+      }
+      for (int i = d - 1; i >= 0; --i) {
+        Row<E> mi;
+        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
+        float part = 0.f, dg = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int j = lane + 64 * e;
+          if (j > i && j < d) part += sp * mi.v[e] * out.v[e];
+          if (j == i) dg = softplus1(mi.v[e]) + eps;
+        }
+        part = wave_sum(part);
+        dg = wave_sum(dg);
+        ld -= logf(dg);
+#pragma unroll
+        for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] = (out.v[e] - part) / dg;
+      }
+    }
+    store_row<E>(out, y + row * d, d, lane);
+    if (lad && lane == 0) lad[row] = ld;
+  }
+}
+
 inline unsigned row_grid(int64_t n) {
   int64_t g = (n + kWavesPerBlock - 1) / kWavesPerBlock;
   const int64_t cap = 256 * 8;
@@ -287,13 +389,13 @@ extern "C" int fc_householder(const float* x, float* y, const float* q, int64_t 
 }
 
 extern "C" int fc_planar(const float* x, float* y, float* logabsdet, const float* w, const float* u_hat,
-                         const float* b, int64_t n, int32_t d, void* stream) {
+                         const float* b, int64_t n, int32_t d, int32_t per_sample, void* stream) {
   if (n < 0 || d <= 0 || d > 512) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
   if (!x || !y || !w || !u_hat || !b) return hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
   FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::planar_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x, y,
-                                        logabsdet, w, u_hat, b, n, d));
+                                        logabsdet, w, u_hat, b, n, d, per_sample));
   return hipGetLastError();
 }
 
@@ -305,6 +407,17 @@ extern "C" int fc_linear(const float* x, float* y, const float* a_t, const float
   hipStream_t s = static_cast<hipStream_t>(stream);
   FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::linear_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x, y, a_t,
                                         b_t, bias, n, d, mode));
+  return hipGetLastError();
+}
+
+extern "C" int fc_linear_per_sample(const float* x, float* y, float* logabsdet, const float* m, int64_t n,
+                                    int32_t d, int32_t mode, float offdiag_scale, float eps, void* stream) {
+  if (n < 0 || d <= 0 || d > 512 || mode < 0 || mode > 3) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!x || !y || !m) return hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::linear_per_sample_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x,
+                                        y, logabsdet, m, n, d, mode, offdiag_scale, eps));
   return hipGetLastError();
 }
 

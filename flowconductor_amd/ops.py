@@ -236,6 +236,7 @@ AFFINE_SCALE_GIVEN = 2
 AFFINE_ADDITIVE = 3
 AFFINE_MAF_SOFTPLUS = 4
 AFFINE_SHIFT_TANH2 = 5
+AFFINE_SCALE_SOFTPLUS = 6
 
 
 def affine_coupling(inputs, params, cols=None, *, activation=AFFINE_SIGMOID_PLUS2, inverse=False,
@@ -252,7 +253,7 @@ def affine_coupling(inputs, params, cols=None, *, activation=AFFINE_SIGMOID_PLUS
     n, d = x.shape
     cols = _as_cols(cols, x.device)
     d_t = d if cols is None else cols.numel()
-    rowlen = d_t if activation in (AFFINE_ADDITIVE, AFFINE_SHIFT_TANH2) else 2 * d_t
+    rowlen = d_t if activation in (AFFINE_ADDITIVE, AFFINE_SHIFT_TANH2, AFFINE_SCALE_SOFTPLUS) else 2 * d_t
     want = rowlen if shared_params else n * rowlen
     if p.numel() != want:
         raise ValueError("params has %d elements, expected %d" % (p.numel(), want))
@@ -390,8 +391,9 @@ def householder(inputs, q_vectors, reverse=False):
     return y
 
 
-def planar(inputs, w, u_hat, b):
-    """Planar flow forward + logabsdet (reference no_analytic_inv/planar.py:30-49)."""
+def planar(inputs, w, u_hat, b, per_sample=False):
+    """Planar flow forward + logabsdet (reference no_analytic_inv/planar.py:30-49; with ``per_sample``
+    the [N, D] / [N] parameters of ConditionalPlanarTransform, conditional.py:824-838)."""
     lib = _hip.load()
     x = _rows(inputs)
     _hip.require_no_grad(inputs)
@@ -399,13 +401,35 @@ def planar(inputs, w, u_hat, b):
     wv = _param(w, x.device, "w").reshape(-1)
     uv = _param(u_hat, x.device, "u").reshape(-1)
     bv = _param(b, x.device, "b").reshape(-1)
-    if wv.numel() != d or uv.numel() != d or bv.numel() != 1:
+    rows = n if per_sample else 1
+    if wv.numel() != rows * d or uv.numel() != rows * d or bv.numel() != rows:
         raise ValueError("planar parameters do not match %d features" % d)
     y = torch.empty_like(x)
     lad = torch.empty(n, dtype=torch.float32, device=x.device)
     _call("fc_planar", lib.fc_planar, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(lad), _hip.ptr(wv),
-          _hip.ptr(uv), _hip.ptr(bv), n, d, _hip.stream_ptr(x.device))
+          _hip.ptr(uv), _hip.ptr(bv), n, d, 1 if per_sample else 0, _hip.stream_ptr(x.device))
     return y, lad
+
+
+PER_SAMPLE_DENSE, PER_SAMPLE_DENSE_T, PER_SAMPLE_LU_FORWARD, PER_SAMPLE_LU_INVERSE = 0, 1, 2, 3
+
+
+def linear_per_sample(inputs, matrices, mode=PER_SAMPLE_DENSE, offdiag_scale=1.0, eps=0.0, want_logabsdet=False):
+    """Per-sample ``[N, D, D]`` matrices applied to the rows of ``inputs`` (reference
+    conditional.py:275-401): dense ``M x`` / ``M^T x`` or the LU forms built from raw hyper-network
+    output on the fly.  Returns ``outputs`` or ``(outputs, logabsdet)``."""
+    lib = _hip.load()
+    x = _rows(inputs)
+    m = _hip.dev_f32(matrices, "matrices")
+    _hip.require_no_grad(inputs, matrices)
+    n, d = x.shape
+    if m.numel() != n * d * d:
+        raise ValueError("matrices must be [%d, %d, %d]" % (n, d, d))
+    y = torch.empty_like(x)
+    lad = torch.empty(n, dtype=torch.float32, device=x.device) if want_logabsdet else None
+    _call("fc_linear_per_sample", lib.fc_linear_per_sample, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(lad),
+          _hip.ptr(m), n, d, mode, float(offdiag_scale), float(eps), _hip.stream_ptr(x.device))
+    return (y, lad) if want_logabsdet else y
 
 
 LINEAR_DENSE, LINEAR_LU_FORWARD, LINEAR_LU_INVERSE = 0, 1, 2

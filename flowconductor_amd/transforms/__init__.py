@@ -15,6 +15,20 @@ from flowconductor_amd.transforms.base import (  # noqa: F401
     InverseTransform,
     Transform,
 )
+from flowconductor_amd.transforms.conditional import (  # noqa: F401
+    ConditionalLUTransform,
+    ConditionalOrthogonalTransform,
+    ConditionalPiecewiseRationalQuadraticTransform,
+    ConditionalPlanarTransform,
+    ConditionalRotationTransform,
+    ConditionalScaleTransform,
+    ConditionalShiftTransform,
+    ConditionalSumOfSigmoidsTransform,
+    ConditionalSVDTransform,
+    ConditionalSylvesterTransform,
+    ConditionalTransform,
+    PiecewiseLinearConditionalTransform,
+)
 from flowconductor_amd.transforms.coupling import (  # noqa: F401
     AdditiveCouplingTransform,
     AffineCouplingTransform,

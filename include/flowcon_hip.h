@@ -102,6 +102,8 @@ int fc_piecewise_spline(const float* x, float* y, const float* params, const int
 #define FC_AFFINE_SHIFT_TANH2 5     /* row [p d_t], shift = 2*tanh(p), s = 1 (autoregressive.py:164-175;
                                        the reference's inverse subtracts raw p: use ADDITIVE) */
 
+#define FC_AFFINE_SCALE_SOFTPLUS 6   /* row [p d_t], shift = 0, s = softplus(p)+1e-5 (conditional.py:212-272) */
+
 /* y = x*s + shift (forward) or (x - shift)/s (inverse) on the `cols` columns, logabsdet =
  * +/- sum_j log s.  Replaces AffineCouplingTransform / AdditiveCouplingTransform
  * (coupling.py:212-269) incl. the split/merge of coupling.py:82-98, and
@@ -179,9 +181,10 @@ int fc_householder(const float* x, float* y, const float* q, int64_t n, int32_t 
 
 /* y = x + u_hat * tanh(x.w + b); logabsdet = log(1e-7 + |1 + sum_j u_hat_j (1 - tanh^2) w_j|).
  * u_hat is the constrained u (host computes it from w, u: a [1, d] expression); b is a device scalar.
+ * per_sample != 0: w, u_hat are [n, d] and b is [n] (ConditionalPlanarTransform, conditional.py:824-838).
  * Replaces PlanarTransform.forward / forward_logabsdet (no_analytic_inv/planar.py:30-49). */
 int fc_planar(const float* x, float* y, float* logabsdet, const float* w, const float* u_hat,
-              const float* b, int64_t n, int32_t d, void* stream);
+              const float* b, int64_t n, int32_t d, int32_t per_sample, void* stream);
 
 /* Dense linear maps with batch-shared [d, d] matrices given TRANSPOSED (a_t[j*d + i] = A[i][j]).
  * mode 0: y = A x + bias                        (linear.py:45-52 cached weight; bias may be NULL)
@@ -189,6 +192,15 @@ int fc_planar(const float* x, float* y, float* logabsdet, const float* w, const 
  * mode 2: y = A^-1 B^-1 (x - bias), A = U upper, B = L unit-lower (lu.py:70-91, solve_triangular) */
 int fc_linear(const float* x, float* y, const float* a_t, const float* b_t, const float* bias,
               int64_t n, int32_t d, int32_t mode, void* stream);
+
+/* Per-sample dense [d, d] matrices M [n, d, d] (row-major, as a hyper-network emits them), d <= 512.
+ * mode 0: y = M x                 mode 1: y = M^T x          (ConditionalRotationTransform, conditional.py:374-401)
+ * mode 2: y = L (U x), mode 3: y = U^-1 L^-1 x with, as in ConditionalLUTransform (conditional.py:300-346),
+ *   L = sp * tril(M, -1) + I,  U = sp * triu(M, 1) + diag(softplus(diag M) + eps),  sp = softplus(scale)
+ *   given as `offdiag_scale`; logabsdet (may be NULL) = +/- sum_i log U_ii.
+ * HBM-bound: every matrix element is read exactly once, rows coalesced. */
+int fc_linear_per_sample(const float* x, float* y, float* logabsdet, const float* m, int64_t n,
+                         int32_t d, int32_t mode, float offdiag_scale, float eps, void* stream);
 
 /* Sylvester flow, fused: y = z + Q R2 tanh(R1 Q^T z + bias), Q = num_householder reflections q,
  * logabsdet = sum_j log(1 + (1 - tanh^2(.)_j) * r_diag_prod_j), r_diag_prod = diag(R1)*diag(R2).

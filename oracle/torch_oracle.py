@@ -990,6 +990,153 @@ def _make_sibling_cdf(kind):
         return y, sum_except_batch(lad)
     return fn
 
+
+# ---- conditional.py (hyper-network transforms) -------------------------------------------------------------
+
+def _conditional(fwd_inv):
+    """conditional.py:73-85: params = conditional_net(context); dispatch to the given-params functions."""
+    def fn(t, x, c, inverse):
+        if c is None:
+            raise TypeError("Conditional transforms require a context.")
+        return fwd_inv(t, x, t.conditional_net(c), inverse)
+    return fn
+
+
+def _cond_shift(t, x, p, inverse):
+    """conditional.py:172-190."""
+    shift = p.view(-1, _int(t.features)).view(x.shape)
+    return (x - shift if inverse else x + shift), x.new_zeros(x.shape[0])
+
+
+def _cond_scale(t, x, p, inverse):
+    """conditional.py:229-260."""
+    scale = F.softplus(p.view(-1, _int(t.features))) + t.eps
+    lad = torch.log(scale).sum(-1).view(x.shape[0])
+    if inverse:
+        return x / scale.view(x.shape), -lad
+    return x * scale.view(x.shape), lad
+
+
+def _int(v):
+    return int(v.item()) if isinstance(v, torch.Tensor) else int(v)
+
+
+def _cond_lu(t, x, p, inverse):
+    """conditional.py:300-346."""
+    f = _int(t.features)
+    m = p.view(-1, f, f)
+    sp = F.softplus(t.scale_non_diag.detach())
+    eye = torch.eye(f, dtype=x.dtype)
+    lower = sp * torch.tril(m, diagonal=-1) + eye
+    upper = sp * torch.triu(m, diagonal=1) + torch.diag_embed(F.softplus(m.diagonal(0, -1, -2)) + t.eps)
+    lad = upper.diagonal(0, -1, -2).log().sum(-1)
+    if not inverse:
+        return (lower @ (upper @ x.unsqueeze(-1))).view(x.shape), lad
+    pivots = torch.arange(1, f + 1, dtype=torch.int32).unsqueeze(0)
+    out = torch.linalg.lu_solve(torch.tril(lower, -1) + upper, torch.broadcast_to(pivots, x.shape), x.unsqueeze(-1))
+    return out.view(x.shape), -lad
+
+
+def _cond_rotation(t, x, p, inverse):
+    """conditional.py:374-401."""
+    c, s = torch.cos(p), torch.sin(p)
+    mat = torch.cat([c, -s, s, c], -1).view(-1, 2, 2)
+    if inverse:
+        mat = mat.transpose(-2, -1)
+    return (mat @ x.unsqueeze(-1)).squeeze(-1), x.new_zeros(x.shape[0])
+
+
+def _cond_orthogonal(t, x, p, inverse):
+    """conditional.py:424-452."""
+    f = _int(t.features)
+    q = p.view(-1, f, f)
+    if inverse:
+        q = q.flip(-2)
+    return householder_apply(x, q), x.new_zeros(x.shape[0])
+
+
+def _cond_svd(t, x, p, inverse):
+    """conditional.py:480-543."""
+    f = _int(t.features)
+    sizes = [f * f, f * f, f] + ([f] if t.use_bias else [])
+    parts = torch.split(p, sizes, -1)
+    q_u, q_v, s_raw = parts[0].view(-1, f, f), parts[1].view(-1, f, f), parts[2]
+    bias = parts[3] if t.use_bias else None
+    if t.lipschitz_constant is not None:
+        s = torch.sigmoid(s_raw) * (t.lipschitz_constant - t.eps) + t.eps
+    else:
+        s = torch.exp(s_raw) + t.eps
+    if not inverse:
+        out = householder_apply(householder_apply(x, q_v) * s, q_u)
+        return (out + bias if t.use_bias else out), s.log().sum(-1)
+    y = x - bias if t.use_bias else x
+    out = householder_apply(householder_apply(y, q_u.flip(-2)) / s, q_v.flip(-2))
+    return out, -s.log().sum(-1)
+
+
+def _cond_linear_spline(t, x, p, inverse):
+    """conditional.py:628-653."""
+    rows = p.view(x.shape[0], _int(t.features), t.num_bins)
+    y, lad = linear_spline(x, rows, inverse=inverse, left=-4.0, right=4.0, bottom=-4.0, top=4.0)
+    return y, sum_except_batch(lad)
+
+
+def _cond_rq(t, x, p, inverse):
+    """conditional.py:693-743."""
+    b, d = x.shape
+    rows = p.view(b, d, p.shape[1] // d)
+    y, lad = rq_from_rows(x, rows, t.num_bins, t.tails, t.tail_bound, inverse,
+                          wh_divisor=_net_divisor(t.conditional_net) if hasattr(t.conditional_net, "hidden_features") else None,
+                          box=(-1.2, 1.2, -1.2, 1.2), enable_identity_init=True,
+                          mins=(t.min_bin_width, t.min_bin_height, t.min_derivative))
+    return y, sum_except_batch(lad)
+
+
+def _cond_sos(t, x, p, inverse):
+    """conditional.py:770-787."""
+    s, f = t.n_sigmoids, _int(t.features)
+    raw = p.view(x.shape[0], f, 3 * s + 1)
+    sp, ls, rs, es = torch.split(raw, [s, s, s, 1], dim=-1)
+    es = es.reshape(-1, f)
+
+    def fwd(v):
+        return sos_forward(v, sp, ls, rs, es)
+
+    if inverse:
+        return monotonic_inverse(fwd, x, 120, 50)
+    return fwd(x)
+
+
+def _cond_planar(t, x, p, inverse):
+    """conditional.py:824-865 (forward only)."""
+    if inverse:
+        raise NotImplementedError()
+    f = _int(t.features)
+    b_ = p[..., -1:]
+    vals = p[..., :-1].view(-1, f, 2)
+    u_, w_ = vals[..., 0][:, None, :], vals[..., 1][:, None, :]
+    wtu = torch.bmm(u_, w_.transpose(-2, -1))
+    u_ = u_ + (-1 + torch.log(1 + torch.exp(wtu)) - wtu) * w_ / torch.norm(w_, p=2, dim=-1, keepdim=True) ** 2
+    pre = torch.bmm(x.view(-1, 1, f), w_.transpose(-2, -1)).squeeze(-1).squeeze(-1) + b_.squeeze(-1)
+    out = x + (u_ * torch.tanh(pre).view(-1, 1, 1)).squeeze(1)
+    psi = (1 - torch.tanh(pre) ** 2).view(-1, 1, 1) * w_
+    abs_det = (1 + torch.bmm(u_, psi.transpose(-2, -1))).abs()
+    return out, torch.log(1e-7 + abs_det).reshape(-1)
+
+
+def _cond_sylvester(t, x, p, inverse):
+    """conditional.py:925-989, with Q = the full per-sample Householder product (D-general; equals the
+    reference's two-row construction for features == 2)."""
+    if inverse:
+        raise NotImplementedError()
+    f = _int(t.features)
+    r_full, r2_diag, q_raw, b = torch.split(p, [f * f, f, f * f, f], -1)
+    r_full = r_full.reshape(-1, f, f)
+    mask = torch.triu(torch.ones(f, f, dtype=x.dtype), diagonal=1).unsqueeze(0)
+    r1 = r_full * mask + torch.diag_embed(torch.tanh(torch.diagonal(r_full, dim1=-2, dim2=-1)))
+    r2 = r_full.transpose(-2, -1) * mask + torch.diag_embed(torch.tanh(r2_diag))
+    return sylvester_forward(x, q_raw.reshape(-1, f, f), r1, r2, b.reshape(-1, f))
+
 _DISPATCH = {
     "CompositeTransform": _composite,
     "CompositeCDFTransform": _composite,
@@ -1036,6 +1183,17 @@ _DISPATCH = {
     "PiecewiseLinearCDF": _make_sibling_cdf("linear"),
     "PiecewiseQuadraticCDF": _make_sibling_cdf("quadratic"),
     "PiecewiseCubicCDF": _make_sibling_cdf("cubic"),
+    "ConditionalShiftTransform": _conditional(_cond_shift),
+    "ConditionalScaleTransform": _conditional(_cond_scale),
+    "ConditionalLUTransform": _conditional(_cond_lu),
+    "ConditionalRotationTransform": _conditional(_cond_rotation),
+    "ConditionalOrthogonalTransform": _conditional(_cond_orthogonal),
+    "ConditionalSVDTransform": _conditional(_cond_svd),
+    "PiecewiseLinearConditionalTransform": _conditional(_cond_linear_spline),
+    "ConditionalPiecewiseRationalQuadraticTransform": _conditional(_cond_rq),
+    "ConditionalSumOfSigmoidsTransform": _conditional(_cond_sos),
+    "ConditionalPlanarTransform": _conditional(_cond_planar),
+    "ConditionalSylvesterTransform": _conditional(_cond_sylvester),
     "SumOfSigmoids": _sum_of_sigmoids,
     "MaskedSumOfSigmoidsTransform": lambda t, x, c, inv: _autoregressive(t, x, c, inv, _ew_sos_ar),
 }

@@ -339,6 +339,62 @@ def _(L):
     return L.transforms.PiecewiseCubicCDF(shape=[5], num_bins=9)
 
 
+# ---- hyper-network ("conditional") transforms: parameters from the context ----
+
+@case("cond_shift_d5", 5, context=3, tol=(1e-5, 0, 1e-5, 0))
+def _(L):
+    return L.transforms.ConditionalShiftTransform(features=5, hidden_features=16, context_features=3)
+
+
+@case("cond_scale_d5", 5, context=3)
+def _(L):
+    return L.transforms.ConditionalScaleTransform(features=5, hidden_features=16, context_features=3)
+
+
+@case("cond_lu_d6", 6, context=3, boost=1.0)
+def _(L):
+    return L.transforms.ConditionalLUTransform(features=6, hidden_features=16, context_features=3)
+
+
+@case("cond_rotation_d2", 2, context=3)
+def _(L):
+    return L.transforms.ConditionalRotationTransform(features=2, hidden_features=8, context_features=3)
+
+
+@case("cond_orthogonal_d5", 5, context=3, boost=1.0)
+def _(L):
+    return L.transforms.ConditionalOrthogonalTransform(features=5, hidden_features=16, context_features=3)
+
+
+@case("cond_svd_d4", 4, context=3, boost=1.0)
+def _(L):
+    return L.transforms.ConditionalSVDTransform(features=4, hidden_features=16, context_features=3)
+
+
+@case("cond_linear_spline_d4", 4, context=3, x_scale=1.5, clamp=(-4.0, 4.0))
+def _(L):
+    return L.transforms.conditional.PiecewiseLinearConditionalTransform(num_bins=8, features=4, hidden_features=16,
+                                                                        context_features=3)
+
+
+@case("cond_rq_tails_d4", 4, context=3, x_scale=1.5)
+def _(L):
+    return L.transforms.ConditionalPiecewiseRationalQuadraticTransform(
+        features=4, hidden_features=16, context_features=3, num_bins=8, tails="linear", tail_bound=3.0)
+
+
+@case("cond_sos_d3", 3, context=3, x_scale=2.0)
+def _(L):
+    return L.transforms.ConditionalSumOfSigmoidsTransform(features=3, hidden_features=16, context_features=3,
+                                                          n_sigmoids=10)
+
+
+@case("cond_sylvester_d2", 2, context=3, inverse=False)
+def _(L):
+    # the reference class only works for features == 2 (conditional.py:970-975)
+    return L.transforms.ConditionalSylvesterTransform(features=2, hidden_features=16, context_features=3)
+
+
 def boost_parameters(module, factor, seed):
     """Make default-initialised conditioners produce non-trivial spline/affine parameters.
 

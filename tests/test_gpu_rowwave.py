@@ -125,3 +125,47 @@ def test_lu_linear_matches_dense_weight(device):
     assert maxdiff(winv @ w, torch.eye(11)) <= 1e-4
     assert maxdiff(lad, torch.full((20,), float(torch.linalg.slogdet(w.double().cpu())[1]))) <= 1e-5
     assert maxdiff(lad + ladb, torch.zeros(20)) == 0.0
+
+
+def test_conditional_planar_and_general_sylvester_vs_oracle(device):
+    """Classes the reference cannot run on CPU / for D != 2 (SURVEY.md headline facts): HIP vs the oracle's
+    restatement of conditional.py:824-865 and :925-989 (D-general Q)."""
+    torch.manual_seed(3)
+    ctx = torch.randn(50, 4)
+    for t, d in ((T.ConditionalPlanarTransform(features=7, hidden_features=16, context_features=4), 7),
+                 (T.ConditionalSylvesterTransform(features=6, hidden_features=16, context_features=4), 6)):
+        t.eval()
+        x = torch.randn(50, d)
+        with torch.no_grad():
+            y_ref, lad_ref = O.transform_apply(t, x.clone(), ctx.clone())
+            y, lad = t.to(device)(x.to(device), ctx.to(device))
+        assert maxdiff(y, y_ref) <= 2e-5 * max(1.0, float(y_ref.abs().max())), type(t).__name__
+        assert maxdiff(lad, lad_ref) <= 1e-4, type(t).__name__
+        with pytest.raises(TypeError):
+            t(x.to(device))
+        with pytest.raises(NotImplementedError):
+            t.inverse(x.to(device), ctx.to(device))
+
+
+@pytest.mark.parametrize("d", [3, 64, 100])
+def test_per_sample_lu_round_trip(d, device):
+    torch.manual_seed(d)
+    n = 37
+    m = torch.randn(n, d, d, device=device) / d ** 0.5
+    x = torch.randn(n, d, device=device)
+    with torch.no_grad():
+        y, lad = ops.linear_per_sample(x, m, mode=ops.PER_SAMPLE_LU_FORWARD, offdiag_scale=0.3, eps=1e-3,
+                                       want_logabsdet=True)
+        xb, ladb = ops.linear_per_sample(y, m, mode=ops.PER_SAMPLE_LU_INVERSE, offdiag_scale=0.3, eps=1e-3,
+                                         want_logabsdet=True)
+        mt = ops.linear_per_sample(x, m, mode=ops.PER_SAMPLE_DENSE)
+        mtt = ops.linear_per_sample(x, m, mode=ops.PER_SAMPLE_DENSE_T)
+    lower = 0.3 * torch.tril(m, -1) + torch.eye(d, device=device)
+    upper = 0.3 * torch.triu(m, 1) + torch.diag_embed(torch.nn.functional.softplus(m.diagonal(0, -1, -2)) + 1e-3)
+    ref = (lower @ (upper @ x.unsqueeze(-1))).squeeze(-1)
+    scale = max(1.0, float(ref.abs().max()))
+    assert maxdiff(y, ref) <= 2e-5 * scale
+    assert maxdiff(lad, upper.diagonal(0, -1, -2).log().sum(-1)) <= 1e-4
+    assert maxdiff(xb, x) <= 5e-4 * scale and maxdiff(lad + ladb, torch.zeros(n)) <= 1e-4
+    assert maxdiff(mt, (m @ x.unsqueeze(-1)).squeeze(-1)) <= 2e-5 * scale
+    assert maxdiff(mtt, (m.transpose(-2, -1) @ x.unsqueeze(-1)).squeeze(-1)) <= 2e-5 * scale
