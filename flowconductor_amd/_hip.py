@@ -90,6 +90,8 @@ SIGNATURES = {
     "fc_elementwise": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _F, _P],
     "fc_piecewise_spline": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32,
                             ctypes.POINTER(SplineConfig), _P],
+    "fc_rq_spline_fused_linear": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32,
+                                  ctypes.POINTER(RQConfig), _P],
     "fc_affine": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P],
 }
 

@@ -63,10 +63,15 @@ class ResidualNet(nn.Module):
         )
         self.final_layer = nn.Linear(hidden_features, out_features)
 
-    def forward(self, inputs, context=None):
+    def hidden(self, inputs, context=None):
+        """Everything up to (not including) ``final_layer``: the [N, hidden_features] activation that the
+        fused final-layer + spline kernel consumes (``forward`` = ``final_layer(hidden(...))``)."""
         if context is not None:
             inputs = torch.cat((inputs, context), dim=1)
         h = self.initial_layer(inputs)
         for block in self.blocks:
             h = block(h, context=context)
-        return self.final_layer(h)
+        return h
+
+    def forward(self, inputs, context=None):
+        return self.final_layer(self.hidden(inputs, context))

@@ -228,6 +228,60 @@ def rq_spline(inputs, params, cols=None, *, num_bins, tails=None, tail_bound=1.0
     return y, lad
 
 
+FUSED_ROWS, FUSED_HIDDEN, FUSED_DT, FUSED_BINS = 32, 64, 32, 8
+
+
+def fused_linear_supported(n, d, d_t, hidden, num_bins, tails):
+    """Shapes the fused final-layer + RQ-spline kernel is specialised for (the north-star layer)."""
+    return (hidden == FUSED_HIDDEN and d_t == FUSED_DT and num_bins == FUSED_BINS and tails == "linear"
+            and d % 4 == 0 and d <= 128 and n >= FUSED_ROWS)
+
+
+def pack_final_layer(weight, bias, num_bins=FUSED_BINS):
+    """[d_t*23, 64] weight / [d_t*23] bias of the conditioner's final Linear -> (w_frag [24, 64, 32],
+    bias_pad [768]) in the layout ``fc_rq_spline_fused_linear`` consumes (see include/flowcon_hip.h)."""
+    p = 3 * num_bins - 1
+    d_t = weight.shape[0] // p
+    w = weight.detach().reshape(d_t, p, weight.shape[1])
+    wpad = torch.cat((w, w.new_zeros(d_t, 1, weight.shape[1])), dim=1).reshape(d_t * (p + 1), weight.shape[1])
+    b = bias.detach().reshape(d_t, p)
+    bpad = torch.cat((b, b.new_zeros(d_t, 1)), dim=1).reshape(-1).contiguous()
+    tiles = wpad.shape[0] // 32
+    # [tile, col, s, kk] -> [tile, kk, col, s] -> [tile, lane = kk*32 + col, s]
+    frag = wpad.reshape(tiles, 32, weight.shape[1] // 2, 2).permute(0, 3, 1, 2).reshape(tiles, 64, weight.shape[1] // 2)
+    return frag.contiguous(), bpad
+
+
+def rq_spline_fused_linear(inputs, hidden, w_frag, bias_pad, cols, *, num_bins, tail_bound,
+                           min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
+                           min_derivative=DEFAULT_MIN_DERIVATIVE, wh_divisor=1.0, inverse=False):
+    """RQ-spline coupling bijector with the conditioner's final Linear fused in (rows must be a multiple
+    of 32).  ``hidden``: [N, 64] input of that Linear.  Returns ``(outputs [N, D], logabsdet [N])``."""
+    lib = _hip.load()
+    x = _prep_2d(inputs)
+    h = _hip.dev_f32(hidden, "hidden")
+    _hip.require_no_grad(inputs, hidden)
+    n, d = x.shape
+    cols = _as_cols(cols, x.device)
+    if n % FUSED_ROWS != 0 or h.shape != (n, FUSED_HIDDEN) or cols.numel() != FUSED_DT:
+        raise ValueError("fused RQ layer: unsupported shapes %s / %s" % (tuple(x.shape), tuple(h.shape)))
+    cfg = _hip.RQConfig()
+    cfg.num_bins, cfg.tails, cfg.inverse = num_bins, 1, 1 if inverse else 0
+    cfg.left, cfg.right, cfg.bottom, cfg.top = -tail_bound, tail_bound, -tail_bound, tail_bound
+    cfg.min_bin_width, cfg.min_bin_height, cfg.min_derivative = min_bin_width, min_bin_height, min_derivative
+    cfg.wh_divisor = wh_divisor
+    cfg.softplus_beta = 1.0
+    cfg.tail_constant = float(np.log(np.exp(1 - min_derivative) - 1))
+    y = torch.empty_like(x)
+    lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    err = _err_word(x.device, True)
+    _call("fc_rq_spline_fused_linear", lib.fc_rq_spline_fused_linear, x.device, _hip.ptr(x), _hip.ptr(y),
+          _hip.ptr(h), _hip.ptr(w_frag), _hip.ptr(bias_pad), _hip.ptr(cols), _hip.ptr(lad), _hip.ptr(err), n, d,
+          FUSED_DT, FUSED_HIDDEN, cfg, _hip.stream_ptr(x.device))
+    _finish(True)
+    return y, lad
+
+
 # ---- affine / additive ------------------------------------------------------------------------
 
 AFFINE_SIGMOID_PLUS2 = 0

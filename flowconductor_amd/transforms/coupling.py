@@ -7,6 +7,7 @@ reduction are ONE HIP kernel launch per layer: the kernel reads the full ``[N, D
 the conditioner's ``[N, d_t * multiplier]`` output once, writes the full output once
 (identity columns copied through LDS) and the ``[N]`` logabsdet once.
 """
+import os
 import warnings
 
 import numpy as np
@@ -236,6 +237,59 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             tails=self.tails, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
             min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
             wh_divisor=_softmax_divisor(self.transform_net, warn=True), inverse=inverse)
+
+    # ---- fused final conditioner layer -------------------------------------------
+    # When the conditioner is this package's ResidualNet with the north-star shape (hidden 64, 32
+    # transformed dims, K = 8, linear tails) its last nn.Linear is evaluated INSIDE the spline kernel on
+    # the exact-f32 matrix cores, so the [N, 736] parameter tensor never touches HBM.  The hidden layers
+    # stay PyTorch-ROCm.  Any other conditioner / shape takes the generic path; FC_FUSED=0 disables it.
+
+    def _fused_ok(self, inputs):
+        from flowconductor_amd.nn.nets.resnet import ResidualNet
+
+        net = self.transform_net
+        return (os.environ.get("FC_FUSED", "1") != "0" and type(net) is ResidualNet and inputs.dim() == 2
+                and inputs.is_cuda and inputs.dtype == torch.float32
+                and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], self.num_transform_features,
+                                               net.hidden_features, self.num_bins, self.tails))
+
+    def _packed_final_layer(self):
+        lin = self.transform_net.final_layer
+        key = (lin.weight._version, lin.bias._version, lin.weight.device, lin.weight.data_ptr())
+        if getattr(self, "_packed", None) is None or self._packed[0] != key:
+            self._packed = (key,) + ops.pack_final_layer(lin.weight, lin.bias, self.num_bins)
+        return self._packed[1], self._packed[2]
+
+    def _run(self, inputs, context, inverse):
+        if not self._fused_ok(inputs):
+            return super()._run(inputs, context, inverse)
+        self._check(inputs)
+        identity_split = inputs[:, self.identity_features]
+        logabsdet_identity = None
+        if inverse and self.unconditional_transform is not None:
+            identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
+        net = self.transform_net
+        hidden = net.hidden(identity_split, context)
+        w_frag, bias_pad = self._packed_final_layer()
+        kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
+                  min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
+                  wh_divisor=_softmax_divisor(net, warn=False), inverse=inverse)
+        n = inputs.shape[0]
+        body = n - n % ops.FUSED_ROWS
+        cols = self._cols(inputs.device)
+        if body == n:
+            outputs, logabsdet = ops.rq_spline_fused_linear(inputs, hidden, w_frag, bias_pad, cols, **kw)
+        else:
+            # the < 32 leftover rows go through the final Linear + the stand-alone kernel
+            out_a, lad_a = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_frag, bias_pad, cols, **kw)
+            out_b, lad_b = self._coupling_kernel(inputs[body:].contiguous(), net.final_layer(hidden[body:]), inverse)
+            outputs, logabsdet = torch.cat((out_a, out_b)), torch.cat((lad_a, lad_b))
+        if self.unconditional_transform is not None:
+            if not inverse:
+                identity_split, logabsdet_identity = self.unconditional_transform(identity_split, context)
+            outputs[:, self.identity_features] = identity_split
+            logabsdet = logabsdet + logabsdet_identity
+        return outputs, logabsdet
 
 
 def _divisor_if_hidden_features(net):

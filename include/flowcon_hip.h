@@ -63,6 +63,20 @@ int fc_rq_spline(const float* x, float* y, const float* params, const int32_t* c
                  float* logabsdet, uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t,
                  int32_t shared_params, int32_t lad_mode, const fc_rq_config* cfg, void* stream);
 
+/* Final conditioner layer fused with the RQ-spline coupling bijector: the [n, d_t*(3K-1)] parameter
+ * tensor  h @ W^T + b  (flowcon/nn/nets/resnet.py:91,99 final_layer) is produced tile by tile on the
+ * exact-f32 matrix cores into LDS and consumed there by the spline (coupling.py:279-293, 549-582); it
+ * never reaches HBM.  Specialised: hidden == 64, d_t == 32, K == 8, linear tails, d % 4 == 0, d <= 128,
+ * n % 32 == 0 (callers route other shapes / the leftover rows through fc_rq_spline).
+ *   h        [n, 64]  last hidden activation of the conditioner (input of its final Linear)
+ *   w_frag   [24][64][32]  the weight, zero-padded from 23 to 24 columns per dim, in MFMA B-fragment order:
+ *            w_frag[t][l][s] = Wpad[t*32 + (l & 31)][2*s + (l >> 5)]   (tile t, lane l, k-step s)
+ *   bias_pad [768]     bias with the same padding */
+int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const float* w_frag,
+                              const float* bias_pad, const int32_t* cols, float* logabsdet,
+                              uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t, int32_t hidden,
+                              const fc_rq_config* cfg, void* stream);
+
 /* ---- linear / quadratic / cubic splines ------------------------------------------------------ */
 #define FC_SPLINE_LINEAR 0    /* row per dim: [K pdf]                          (splines/linear.py:38-105) */
 #define FC_SPLINE_QUADRATIC 1 /* row per dim: [K widths | K-1 or K+1 heights]  (splines/quadratic.py:55-159) */

@@ -1,0 +1,58 @@
+"""Final-conditioner-layer + RQ-spline fused kernel (fc_rq_spline_fused_linear) vs the unfused HIP path
+and the CPU oracle."""
+import os
+
+import pytest
+import torch
+
+from _util import build_case, maxdiff
+from flowconductor_amd import ops
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [32, 64, 95, 4096, 100003])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fused_matches_unfused_and_oracle(n, inverse, device, monkeypatch):
+    t, _ = build_case("rq_coupling_linear_tails_d64_k8_h64")
+    gen = torch.Generator().manual_seed(n)
+    x = torch.randn(n, 64, generator=gen) * 1.5
+    rows = min(n, 512)
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(t, x[:rows].clone(), inverse=inverse)
+    t = t.to(device)
+    xd = x.to(device)
+    fn = t.inverse if inverse else t.forward
+    with torch.no_grad():
+        assert t._fused_ok(xd)
+        with ops.KernelTimer("fc_rq_spline_fused_linear") as timer:
+            y_f, lad_f = fn(xd)
+        assert len(timer.pairs) == 1, "the fused kernel did not run"
+        monkeypatch.setenv("FC_FUSED", "0")
+        assert not t._fused_ok(xd)
+        y_u, lad_u = fn(xd)
+    scale = max(1.0, float(ref_y.abs().max()))
+    # fused vs unfused: same spline arithmetic, GEMM by exact-f32 MFMA vs hipBLASLt
+    assert maxdiff(y_f, y_u) <= 5e-5 * scale
+    # (the spline inverse is ill-conditioned on a few elements: tools/noise_floor.py, max 1.9e-3 at 2^14 rows)
+    assert maxdiff(lad_f, lad_u) <= (1e-3 if not inverse else 1e-2)
+    tol_y, tol_l = (2e-5, 2e-4) if not inverse else (3e-4, 3e-3)
+    assert maxdiff(y_f[:rows], ref_y) <= tol_y * scale
+    assert maxdiff(lad_f[:rows], ref_lad) <= tol_l * max(1.0, float(ref_lad.abs().max()) / 10)
+    assert torch.isfinite(y_f).all() and torch.isfinite(lad_f).all()
+
+
+def test_pack_final_layer_layout():
+    w = torch.arange(736 * 64, dtype=torch.float32).reshape(736, 64)
+    b = torch.arange(736, dtype=torch.float32)
+    frag, bpad = ops.pack_final_layer(w, b)
+    assert frag.shape == (24, 64, 32) and bpad.shape == (768,)
+    # w_frag[t][l][s] = Wpad[t*32 + (l & 31)][2*s + (l >> 5)], Wpad row j*24+i = W row j*23+i (i < 23)
+    for (t_, s_, l_) in [(0, 0, 0), (3, 7, 45), (23, 31, 63), (11, 16, 31)]:
+        prow, k = t_ * 32 + (l_ & 31), 2 * s_ + (l_ >> 5)
+        j, i = divmod(prow, 24)
+        expect = 0.0 if i == 23 else float(w[j * 23 + i, k])
+        assert float(frag[t_, l_, s_]) == expect
+    assert float(bpad[23]) == 0.0 and float(bpad[24]) == float(b[23])
+test_pack_final_layer_layout.pytestmark = []  # CPU-only check, runs in both suites

@@ -24,6 +24,15 @@ def main():
         fn = lambda: ops.rq_spline(x, params, cols, num_bins=k, tails="linear", tail_bound=3.0,  # noqa: E731
                                    wh_divisor=8.0, inverse=which == "rq_inv")
         name = "fc_rq_spline"
+    elif which == "fused":
+        p = 3 * k - 1
+        h = torch.randn(n, 64, device=dev)
+        w = torch.randn(d_t * p, 64, device=dev) * 0.2
+        b = torch.randn(d_t * p, device=dev) * 0.1
+        frag, bpad = ops.pack_final_layer(w, b)
+        fn = lambda: ops.rq_spline_fused_linear(x, h, frag, bpad, cols, num_bins=k, tail_bound=3.0,  # noqa: E731
+                                                wh_divisor=8.0)
+        name = "fc_rq_spline_fused_linear"
     else:
         p = 2
         params = torch.randn(n, d_t * p, device=dev)
