@@ -75,3 +75,32 @@ class ResidualNet(nn.Module):
 
     def forward(self, inputs, context=None):
         return self.final_layer(self.hidden(inputs, context))
+
+    # ---- device fast path for the hidden layers (inference) ------------------------------------------
+    def hip_hidden_supported(self, features_total):
+        """True when ``fc_resnet_hidden`` covers this net: hidden 64, <= 2 blocks, ReLU, no context, no
+        batch norm, dropout inactive, even input width <= 64, input rows of <= 128 features (multiple of 4)."""
+        def is_relu(f):
+            return isinstance(f, torch.nn.ReLU) or f is F.relu or f is torch.relu
+
+        if self.context_features is not None or self.hidden_features != 64 or len(self.blocks) > 2:
+            return False
+        in_f = self.initial_layer.in_features
+        if in_f % 2 or in_f > 64 or features_total % 4 or features_total > 128:
+            return False
+        for block in self.blocks:
+            if block.use_batch_norm or not is_relu(block.activation):
+                return False
+            if block.dropout.p > 0 and self.training:
+                return False
+        return True
+
+    def hidden_hip(self, rows, id_cols):
+        """h [N, 64] from FULL input rows + the identity column indices (N a multiple of 64)."""
+        from flowconductor_amd import ops
+
+        key = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
+            self._hip_packed = (key, ops.pack_resnet_hidden(self))
+        return ops.resnet_hidden(rows, id_cols, self._hip_packed[1], self.initial_layer.in_features,
+                                 len(self.blocks))

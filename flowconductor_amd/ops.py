@@ -237,6 +237,51 @@ def fused_linear_supported(n, d, d_t, hidden, num_bins, tails):
             and d % 4 == 0 and d <= 128 and n >= FUSED_ROWS)
 
 
+def pack_linear_frag(weight):
+    """nn.Linear weight [out, in] (out % 32 == 0, in even) -> MFMA B fragments [out/32, 64, in/2]:
+    frag[t][l][s] = W[t*32 + (l & 31)][2*s + (l >> 5)]."""
+    out_f, in_f = weight.shape
+    w = weight.detach().reshape(out_f // 32, 32, in_f // 2, 2)       # [tile, col, s, kk]
+    return w.permute(0, 3, 1, 2).reshape(out_f // 32, 64, in_f // 2).contiguous()  # lane = kk*32 + col
+
+
+HIDDEN_ROWS = 64
+
+
+def pack_resnet_hidden(net):
+    """Pack the hidden layers of a ResidualNet (hidden 64, <= 2 blocks) for ``fc_resnet_hidden``."""
+    w0 = pack_linear_frag(net.initial_layer.weight)
+    b0 = net.initial_layer.bias.detach().contiguous()
+    frags, biases = [], []
+    for block in net.blocks:
+        for lin in block.linear_layers:
+            frags.append(pack_linear_frag(lin.weight))
+            biases.append(lin.bias.detach())
+    if frags:
+        wb = torch.stack(frags).contiguous()
+        bb = torch.stack(biases).contiguous()
+    else:
+        wb = bb = None
+    return w0, b0, wb, bb
+
+
+def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks):
+    """Hidden layers of the conditioner on the rows of ``inputs`` (multiple of 64 rows) -> h [N, 64]."""
+    lib = _hip.load()
+    x = _prep_2d(inputs)
+    _hip.require_no_grad(inputs)
+    n, d = x.shape
+    if n % HIDDEN_ROWS != 0:
+        raise ValueError("fc_resnet_hidden needs a multiple of %d rows" % HIDDEN_ROWS)
+    w0, b0, wb, bb = packed
+    ids = _as_cols(id_cols, x.device)
+    h = torch.empty(n, 64, dtype=torch.float32, device=x.device)
+    _call("fc_resnet_hidden", lib.fc_resnet_hidden, x.device, _hip.ptr(x), _hip.ptr(h), _hip.ptr(ids),
+          _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(wb), _hip.ptr(bb), n, d, in_features, 64, num_blocks,
+          _hip.stream_ptr(x.device))
+    return h
+
+
 def pack_final_layer(weight, bias, num_bins=FUSED_BINS):
     """[d_t*23, 64] weight / [d_t*23] bias of the conditioner's final Linear -> (w_frag [24, 64, 32],
     bias_pad [768]) in the layout ``fc_rq_spline_fused_linear`` consumes (see include/flowcon_hip.h)."""

@@ -75,6 +75,14 @@ class CouplingTransform(Transform):
             self._cols_cache = c
         return c
 
+    def _id_cols(self, device):
+        """int32 copy of ``identity_features`` on ``device``."""
+        c = getattr(self, "_id_cols_cache", None)
+        if c is None or c.device != device or c.numel() != self.num_identity_features:
+            c = self.identity_features.to(device=device, dtype=torch.int32).contiguous()
+            self._id_cols_cache = c
+        return c
+
     def _check(self, inputs):
         if inputs.dim() not in [2, 4]:
             raise ValueError("Inputs must be a 2D or a 4D tensor.")
@@ -269,12 +277,20 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         if inverse and self.unconditional_transform is not None:
             identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
         net = self.transform_net
-        hidden = net.hidden(identity_split, context)
+        n = inputs.shape[0]
+        body64 = n - n % ops.HIDDEN_ROWS
+        if (self.unconditional_transform is None and context is None and body64 > 0
+                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0" and net.hip_hidden_supported(inputs.shape[1])):
+            # hidden layers of the conditioner in one MFMA kernel straight from the full input rows
+            hidden = net.hidden_hip(inputs[:body64], self._id_cols(inputs.device))
+            if body64 < n:
+                hidden = torch.cat((hidden, net.hidden(identity_split[body64:], context)))
+        else:
+            hidden = net.hidden(identity_split, context)
         w_frag, bias_pad = self._packed_final_layer()
         kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                   min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
                   wh_divisor=_softmax_divisor(net, warn=False), inverse=inverse)
-        n = inputs.shape[0]
         body = n - n % ops.FUSED_ROWS
         cols = self._cols(inputs.device)
         if body == n:

@@ -56,3 +56,41 @@ def test_pack_final_layer_layout():
         assert float(frag[t_, l_, s_]) == expect
     assert float(bpad[23]) == 0.0 and float(bpad[24]) == float(b[23])
 test_pack_final_layer_layout.pytestmark = []  # CPU-only check, runs in both suites
+
+
+@pytest.mark.parametrize("in_f,blocks,d,n", [(32, 2, 64, 64), (32, 2, 64, 6400), (16, 1, 32, 128), (6, 0, 12, 64),
+                                            (64, 2, 128, 192)])
+def test_resnet_hidden_kernel_matches_torch(in_f, blocks, d, n, device):
+    """fc_resnet_hidden vs the same nn.Module evaluated by PyTorch on the CPU."""
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(in_f + blocks)
+    net = nets.ResidualNet(in_f, 8, hidden_features=64, num_blocks=blocks).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)  # make the residual blocks matter (their last layer is initialised ~1e-3)
+    ids = torch.randperm(d)[:in_f].sort().values
+    x = torch.randn(n, d)
+    with torch.no_grad():
+        ref = net.hidden(x[:, ids])
+        assert net.hip_hidden_supported(d)
+        got = net.to(device).hidden_hip(x.to(device), ids.to(device))
+    assert got.shape == (n, 64)
+    assert maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_fused_hidden_path_in_coupling(device, monkeypatch):
+    t, _ = build_case("rq_coupling_linear_tails_d64_k8_h64")
+    x = torch.randn(1000, 64) * 1.5
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(t, x.clone())
+    t = t.to(device)
+    with torch.no_grad():
+        with ops.KernelTimer("fc_resnet_hidden") as timer:
+            y, lad = t(x.to(device))
+        assert len(timer.pairs) == 1, "the hidden-layer kernel did not run"
+        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        y2, lad2 = t(x.to(device))
+    assert maxdiff(y, ref_y) <= 2e-5 * max(1.0, float(ref_y.abs().max()))
+    assert maxdiff(lad, ref_lad) <= 3e-4
+    assert maxdiff(y, y2) <= 2e-5 and maxdiff(lad, lad2) <= 3e-4
