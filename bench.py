@@ -8,8 +8,10 @@ on synthetic Gaussian batches, one process per GPU, batch-sharded (BASELINE.json
 One "step" = one ``Flow.log_prob`` pass of every rank's 2^20-sample shard through all 32
 layers (conditioners on PyTorch-ROCm, bijectors in the HIP kernels) + the RCCL all-reduce of
 {sum log_prob, count}.  Inputs are resident in HBM before the timed region.  Prints ONE JSON
-line on rank 0 (contract in the task statement), carrying ``roofline`` for the dominant kernel
-(fc_rq_spline) and ``cpu_baseline`` (the CPU oracle timed on the host cores, rank 0, N=1).
+line on rank 0 (contract in the task statement), carrying ``roofline`` (the HBM-bound stand-alone
+spline kernel fc_rq_spline), ``roofline_fused`` / ``roofline_hidden`` (the MFMA-bound kernels that
+carry the timed flow since the conditioner fusion) and ``cpu_baseline`` (the CPU oracle timed on the
+host cores, rank 0, N=1).
 """
 import argparse
 import json
@@ -27,7 +29,8 @@ from flowconductor_amd import distributions, flows, ops, transforms, utils  # no
 from flowconductor_amd.nn import nets  # noqa: E402
 
 FEATURES, LAYERS, BINS, HIDDEN, BLOCKS, TAIL_BOUND = 64, 32, 8, 64, 2, 3.0
-HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak, same guide (v_mfma_f32_32x32x2_f32)
 
 
 def build_flow():
@@ -166,8 +169,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(device)
     timer = ops.KernelTimer("fc_rq_spline")
+    timer_fused = ops.KernelTimer("fc_rq_spline_fused_linear")
+    timer_hidden = ops.KernelTimer("fc_resnet_hidden")
     t0 = time.perf_counter()
-    with timer:
+    with timer, timer_fused, timer_hidden:
         for _ in range(args.steps):
             mean_lp = step()
     torch.cuda.synchronize(device)
@@ -183,11 +188,24 @@ def main():
     log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
     if rank == 0:
         total = n_local * world * args.steps
-        kernel_ms = timer.durations_ms()
-        launches = len(kernel_ms)
-        avg_ms = sum(kernel_ms) / max(launches, 1)
         rows_per_launch = n_local if chunk is None else min(chunk, n_local)
         alg_bytes = algorithmic_bytes_per_sample_layer() * rows_per_launch
+        fused_ms = timer_fused.durations_ms()
+        hidden_ms = timer_hidden.durations_ms()
+        fused_path = len(fused_ms) > 0
+        if fused_path:
+            # the stand-alone spline kernel does not run in the fused flow: time it in one extra, untimed
+            # pass with the fusion switched off (same flow, same inputs) for the HBM-roofline entry
+            os.environ["FC_FUSED"] = "0"
+            with ops.KernelTimer("fc_rq_spline") as extra:
+                step()
+            torch.cuda.synchronize(device)
+            os.environ.pop("FC_FUSED")
+            kernel_ms = extra.durations_ms()
+        else:
+            kernel_ms = timer.durations_ms()
+        launches = len(kernel_ms)
+        avg_ms = sum(kernel_ms) / max(launches, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         out = {
             "metric": "log_prob samples/sec, 32xRQ-NSF coupling D=64 K=8",
@@ -213,8 +231,29 @@ def main():
                                            "WRITE_SIZE passes of this command; FETCH_SIZE x2 gfx950 correction)",
                          "kernel": "fc_rq_spline -> fc::rq_wave_kernel<8, true>", "launches_timed": launches,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "bijector_share_of_step": sum(kernel_ms) / (1e3 * elapsed) if elapsed else None},
+                         "measured_in": "extra untimed pass with FC_FUSED=0" if fused_path else "timed region"},
         }
+        if fused_path:
+            # dominant kernel of the timed region: final conditioner Linear (64 -> 736) fused with the spline.
+            # Algorithmic flops = the GEMM's 2*64*736 per sample (the spline arithmetic rides on the VALU).
+            f_avg = sum(fused_ms) / len(fused_ms)
+            flops = 2.0 * HIDDEN * (FEATURES // 2) * (3 * BINS - 1) * rows_per_launch
+            tf = flops / (f_avg * 1e-3) / 1e12
+            out["roofline_fused"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                                     "kernel": "fc_rq_spline_fused_linear -> fc::rq_fused_linear_kernel",
+                                     "launches_timed": len(fused_ms), "avg_launch_ms": f_avg,
+                                     "algorithmic_flops_per_launch": flops,
+                                     "share_of_step": sum(fused_ms) / (1e3 * elapsed)}
+            if hidden_ms:
+                h_avg = sum(hidden_ms) / len(hidden_ms)
+                hflops = 2.0 * (HIDDEN * (FEATURES // 2) + 2 * BLOCKS * HIDDEN * HIDDEN) * rows_per_launch
+                out["roofline_hidden"] = {"bound": "mfma", "achieved": hflops / (h_avg * 1e-3) / 1e12,
+                                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                          "frac": hflops / (h_avg * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                          "kernel": "fc_resnet_hidden -> fc::resnet_hidden_kernel<2>",
+                                          "launches_timed": len(hidden_ms), "avg_launch_ms": h_avg,
+                                          "share_of_step": sum(hidden_ms) / (1e3 * elapsed)}
         if world == 1:
             flow_cpu = build_flow()
             out["parity"] = parity(flow, flow_cpu, device)

@@ -65,6 +65,18 @@ __device__ __forceinline__ float softplus_lean(float x, float beta) {
   return beta == 1.f ? v : div_lean(v, beta);
 }
 
+// the same without control flow (both sides evaluated, select at the end): lets the scheduler interleave
+// several independent element evaluations in one basic block
+__device__ __forceinline__ float softplus_lean_sel(float x, float beta) {
+  const float xb = x * beta;
+  const float t = exp_lean(fminf(xb, 20.f));
+  const float u = 1.f + t;
+  const float d = u - 1.f;
+  const float l1p = d == 0.f ? t : log_lean(u) * div_lean(t, d == 0.f ? 1.f : d);
+  const float v = beta == 1.f ? l1p : div_lean(l1p, beta);
+  return xb > 20.f ? x : v;
+}
+
 // F.softplus(x, beta, threshold=20): x*beta > 20 ? x : log1p(exp(x*beta)) / beta
 __device__ __forceinline__ float softplus_b(float x, float beta) {
   const float xb = x * beta;

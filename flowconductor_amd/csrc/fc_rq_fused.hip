@@ -65,6 +65,46 @@ struct FusedArgs {
   int debug;             // profiling ablations (tools/ only): 1 skip MFMA, 2 skip spline arithmetic
 };
 
+// Consumer work of one half-step: the 2 elements of this thread, as two independent straight-line chains.
+// A separate (noinline) function on purpose: it gets its own register allocation, so the producers' 192
+// resident weight registers and this code's ~100 temporaries never compete in hipcc's allocator.
+template <bool kInv>
+__device__ __attribute__((noinline)) uint32_t fused_consume(RQOp<kK> op, const float* __restrict__ phalf,
+                                                            float* __restrict__ xtile, const int* __restrict__ cols_half,
+                                                            float* __restrict__ lbuf, int D, int ctid, int first_half,
+                                                            int skip) {
+  uint32_t err = 0;
+  float xin[2], yv[2], lad[2];
+  float* xr[2];
+  const float* pp[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = ctid + it * 256;
+    const int row = e >> 4, jj = e & 15;
+    xr[it] = xtile + row * D + cols_half[jj];
+    pp[it] = phalf + row * kPRow + skewed(jj * kPP);
+    xin[it] = *xr[it];
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    if (skip) { yv[it] = xin[it] + pp[it][0] * 0.f; lad[it] = 0.f; }
+    else op.template eval_tails_straight<kInv>(pp[it], xin[it], yv[it], lad[it], err);
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = ctid + it * 256;
+    const int row = e >> 4, jj = e & 15;
+    *xr[it] = yv[it];
+    float l = lad[it];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) l += __shfl_xor(l, o, 16);
+    if (jj == 0) {
+      if (first_half) lbuf[row] = l; else lbuf[row] += l;
+    }
+  }
+  return err;
+}
+
 __global__ __launch_bounds__(512) void rq_fused_linear_kernel(RQOp<kK> op, FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* pbuf = smem;                              // [2][kR][kPRow]
@@ -178,25 +218,13 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel(RQOp<kK> op, Fused
       for (int k = 0; k < 4; ++k)
         if (ctid + k * 256 < xvec) xd[ctid + k * 256] = xv[k];
     };
+    const bool inv = op.q.inverse != 0;
     auto consume = [&](int xb, int hf) {
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int e = ctid + it * 256;
-        const int row = e >> 4, jj = e & 15;
-        const int col = cs[hf * kHalfDims + jj];
-        float* xr = xbuf + (xb * kR + row) * D;
-        const float* p = pbuf + (hf * kR + row) * kPRow + skewed(jj * kPP);
-        const float xin = xr[col];
-        float yv, lad;
-        if (a.debug & 2) { yv = xin + p[0] * 0.f; lad = 0.f; }
-        else op.template eval_core<false>(p, xin, yv, lad, err);
-        xr[col] = yv;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) lad += __shfl_xor(lad, o, 16);
-        if (jj == 0) {
-          if (hf == 0) lbuf[row] = lad; else lbuf[row] += lad;
-        }
-      }
+      const float* phalf = pbuf + hf * kR * kPRow;
+      float* xtile = xbuf + xb * kR * D;
+      const int* ch = cs + hf * kHalfDims;
+      err |= inv ? fused_consume<true>(op, phalf, xtile, ch, lbuf, D, ctid, hf == 0, a.debug & 2)
+                 : fused_consume<false>(op, phalf, xtile, ch, lbuf, D, ctid, hf == 0, a.debug & 2);
     };
 
     fetch_x(tile0);

@@ -175,6 +175,58 @@ struct RQOp {
     eval_core<false>(prow + j * P, x, y, lad, err);
   }
 
+  // Branch-free evaluation for linear tails with the parameters in LDS (used by the fused kernel's
+  // consumers): no early return for out-of-interval inputs (evaluated on a clamped copy, selected away at
+  // the end), select-form softplus, direction fixed at compile time.  One straight-line block per element,
+  // so two elements per thread interleave and hide each other's transcendental / LDS latencies.
+  template <bool kInverse>
+  __device__ __forceinline__ void eval_tails_straight(const float* __restrict__ p, float x, float& y, float& lad,
+                                                      uint32_t& err) const {
+    static_assert(KS > 0, "static bin count required");
+    const bool inside = (x >= q.left) && (x <= q.right);
+    const float xc = inside ? x : q.left;
+    const f2 minb = {q.min_w, q.min_h}, c1 = {q.cw, q.ch};
+    const f2 lo = {q.left, q.bottom}, hi = {q.right, q.top};
+    int idx;
+    f2 klo, bsz;
+    walk_both<KS, !kInverse>(p, p + KS, inv_div, minb, c1, lo, hi, xc, idx, klo, bsz);
+    const float xk = klo.x, yk = klo.y, wk = bsz.x, hk = bsz.y;
+    const float* ud = p + 2 * KS;
+    const float r0 = ud[idx > 0 ? idx - 1 : 0], r1 = ud[idx < KS - 1 ? idx : KS - 2];
+    const float u0 = idx == 0 ? q.tail_const : r0;
+    const float u1 = idx == KS - 1 ? q.tail_const : r1;
+    const float d0 = q.min_d + softplus_lean_sel(u0, q.beta);
+    const float d1 = q.min_d + softplus_lean_sel(u1, q.beta);
+    const float delta = div_lean(hk, wk);
+    const float dsum = d0 + d1 - 2.f * delta;
+    float theta;
+    if constexpr (!kInverse) {
+      theta = div_lean(xc - xk, wk);
+    } else {
+      const float r = xc - yk;
+      const float qa = r * dsum + hk * (delta - d0);
+      const float qb = hk * d0 - r * dsum;
+      const float qc = -delta * r;
+      const float disc = qb * qb - 4.f * qa * qc;
+      if (inside && !(disc >= 0.f)) err |= kErrDiscriminant;
+      theta = div_lean(2.f * qc, -qb - sqrt_lean(disc));
+    }
+    const float t1mt = theta * (1.f - theta);
+    const float den = delta + dsum * t1mt;
+    const float omt = 1.f - theta;
+    const float dnum = (delta * delta) * (d1 * (theta * theta) + 2.f * delta * t1mt + d0 * (omt * omt));
+    const float l = log_lean(dnum) - 2.f * log_lean(den);
+    float ys;
+    if constexpr (!kInverse) {
+      const float num = hk * (delta * (theta * theta) + d0 * t1mt);
+      ys = yk + div_lean(num, den);
+    } else {
+      ys = theta * wk + xk;
+    }
+    y = inside ? ys : x;
+    lad = inside ? (kInverse ? -l : l) : 0.f;
+  }
+
   // p -> the P raw values of one (sample, dim): an LDS pointer, or (kRegs) a register array that
   // must only be indexed statically, so the two derivatives are picked with a select chain.
   template <bool kRegs>

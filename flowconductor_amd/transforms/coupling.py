@@ -272,20 +272,21 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         if not self._fused_ok(inputs):
             return super()._run(inputs, context, inverse)
         self._check(inputs)
-        identity_split = inputs[:, self.identity_features]
-        logabsdet_identity = None
-        if inverse and self.unconditional_transform is not None:
-            identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
         net = self.transform_net
         n = inputs.shape[0]
         body64 = n - n % ops.HIDDEN_ROWS
+        identity_split = logabsdet_identity = None
         if (self.unconditional_transform is None and context is None and body64 > 0
                 and os.environ.get("FC_FUSED_HIDDEN", "1") != "0" and net.hip_hidden_supported(inputs.shape[1])):
-            # hidden layers of the conditioner in one MFMA kernel straight from the full input rows
+            # hidden layers of the conditioner in one MFMA kernel straight from the full input rows: the
+            # identity half is never gathered into a separate tensor
             hidden = net.hidden_hip(inputs[:body64], self._id_cols(inputs.device))
             if body64 < n:
-                hidden = torch.cat((hidden, net.hidden(identity_split[body64:], context)))
+                hidden = torch.cat((hidden, net.hidden(inputs[body64:, self.identity_features], context)))
         else:
+            identity_split = inputs[:, self.identity_features]
+            if inverse and self.unconditional_transform is not None:
+                identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
             hidden = net.hidden(identity_split, context)
         w_frag, bias_pad = self._packed_final_layer()
         kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,

@@ -11,6 +11,16 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle runs inside the GPU tests too.  torch defaults to one thread per HOST core; on a
+    # cgroup-limited box that oversubscribes the CPU share and OpenMP spin-waits can stall a test for
+    # minutes.  Pin to the cores this process may actually use (at most 8).
+    import torch
+
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(8, usable)))
 
 
 @pytest.fixture(scope="session")
