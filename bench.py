@@ -126,6 +126,8 @@ def main():
     ap.add_argument("--chunk-log2", type=int, default=0, help="log2 rows per pass through the stack (0 = whole shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log2", type=int, default=17)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + FC_BENCH_SHARE_DEVICE0=1 rehearses the N>1 code path on a one-GPU box")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,6 +139,8 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if os.environ.get("FC_BENCH_SHARE_DEVICE0") == "1":
+        local_rank = 0  # rehearsal only: every rank on the single GPU of the box (with --dist-backend gloo)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     dist = None
@@ -144,7 +148,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     from flowconductor_amd import parallel
 
@@ -197,8 +204,8 @@ def main():
             # the stand-alone spline kernel does not run in the fused flow: time it in one extra, untimed
             # pass with the fusion switched off (same flow, same inputs) for the HBM-roofline entry
             os.environ["FC_FUSED"] = "0"
-            with ops.KernelTimer("fc_rq_spline") as extra:
-                step()
+            with ops.KernelTimer("fc_rq_spline") as extra, torch.no_grad():
+                parallel.local_log_prob(flow.log_prob, x, chunk=chunk)  # rank-local: no collective here
             torch.cuda.synchronize(device)
             os.environ.pop("FC_FUSED")
             kernel_ms = extra.durations_ms()

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from _util import Lib
+from flowconductor_amd import ops
 
 T, nets, utils = Lib.transforms, Lib.nets, Lib.utils
 
@@ -138,3 +139,27 @@ def test_deferred_error_state_resets():
         with ops.deferred_errors():
             raise RuntimeError("boom")
     assert ops._state.depth == 0 and not ops._state.dirty
+
+
+def test_pack_final_layer_layout():
+    w = torch.arange(736 * 64, dtype=torch.float32).reshape(736, 64)
+    b = torch.arange(736, dtype=torch.float32)
+    frag, bpad = ops.pack_final_layer(w, b)
+    assert frag.shape == (24, 64, 32) and bpad.shape == (768,)
+    # w_frag[t][l][s] = Wpad[t*32 + (l & 31)][2*s + (l >> 5)], Wpad row j*24+i = W row j*23+i (i < 23)
+    for (t_, s_, l_) in [(0, 0, 0), (3, 7, 45), (23, 31, 63), (11, 16, 31)]:
+        prow, k = t_ * 32 + (l_ & 31), 2 * s_ + (l_ >> 5)
+        j, i = divmod(prow, 24)
+        expect = 0.0 if i == 23 else float(w[j * 23 + i, k])
+        assert float(frag[t_, l_, s_]) == expect
+    assert float(bpad[23]) == 0.0 and float(bpad[24]) == float(b[23])
+
+
+def test_pack_linear_frag_layout():
+    from flowconductor_amd import ops
+
+    w = torch.arange(64 * 32, dtype=torch.float32).reshape(64, 32)
+    frag = ops.pack_linear_frag(w)
+    assert frag.shape == (2, 64, 16)
+    for (t_, l_, s_) in [(0, 0, 0), (1, 37, 9), (1, 63, 15)]:
+        assert float(frag[t_, l_, s_]) == float(w[t_ * 32 + (l_ & 31), 2 * s_ + (l_ >> 5)])
