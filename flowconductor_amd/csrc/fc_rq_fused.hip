@@ -29,41 +29,10 @@
 #include "fc_tile.h"
 #include "fc_math.h"
 #include "fc_rq_op.h"
+#include "fc_rq_fused.h"
 #include "../../include/flowcon_hip.h"
 
 namespace fc {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kR = 32;            // rows per tile
-constexpr int kH = 64;            // hidden width (GEMM K)
-constexpr int kDt = 32;           // transformed dims
-constexpr int kK = 8;             // spline bins
-constexpr int kPP = 24;           // padded
-constexpr int kHalfDims = 16;
-constexpr int kHalfCols = kHalfDims * kPP;        // 384 = 12 tiles of 32
-constexpr int kPRow = kHalfCols + 2 * 4 + 1;      // + skew (2 floats per group of 4 dims) + odd pad = 393
-constexpr int kPBuf = (2 * kR * kPRow + 3) & ~3;   // floats, rounded so the next region is 16-byte aligned
-constexpr int kHRow = kH + 1;                     // 65: conflict-free A-fragment reads
-constexpr int kHBuf = (2 * kR * kHRow + 3) & ~3;
-constexpr int kTilesPerWave = 3;                  // 12 tiles per half / 4 producer waves
-constexpr int kSteps = kH / 2;                    // 32 MFMA k-steps
-
-__device__ __forceinline__ int skewed(int c) { return c + 2 * (c / (4 * kPP)); }
-
-struct FusedArgs {
-  const float* x;        // [N, D]
-  float* y;              // [N, D]
-  const float* h;        // [N, 64] last hidden activation of the conditioner
-  const float* wfrag;    // [2 halves][12 tiles][64 lanes][32 k-steps] B fragments of the padded weight
-  const float* bias;     // [768] padded bias
-  const int32_t* cols;   // [32]
-  float* logabsdet;      // [N]
-  uint32_t* err;
-  int64_t tiles;         // full 32-row tiles
-  int D;
-  int debug;             // profiling ablations (tools/ only): 1 skip MFMA, 2 skip spline arithmetic
-};
 
 // Consumer work of one half-step: the 2 elements of this thread, as two independent straight-line chains.
 // A separate (noinline) function on purpose: it gets its own register allocation, so the producers' 192
@@ -134,14 +103,11 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel(RQOp<kK> op, Fused
     for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
       for (int t = 0; t < kTilesPerWave; ++t) {
-        const float4* wf = reinterpret_cast<const float4*>(
-            a.wfrag + ((int64_t)(hf * 12 + wave * kTilesPerWave + t) * 64 + lane) * kSteps);
+        // B fragment of v_mfma_f32_32x32x2_f32: lane l holds Wpad[col = tile*32 + (l & 31)][k = 2s + (l >> 5)]
+        const float* wrow = a.wpad + (int64_t)(hf * kHalfCols + (wave * kTilesPerWave + t) * 32 + (lane & 31)) * kH +
+                            (lane >> 5);
 #pragma unroll
-        for (int q = 0; q < kSteps / 4; ++q) {
-          const float4 v = wf[q];
-          wreg[hf][t][4 * q] = v.x; wreg[hf][t][4 * q + 1] = v.y;
-          wreg[hf][t][4 * q + 2] = v.z; wreg[hf][t][4 * q + 3] = v.w;
-        }
+        for (int s = 0; s < kSteps; ++s) wreg[hf][t][s] = wrow[2 * s];
         breg[hf][t] = a.bias[hf * kHalfCols + (wave * kTilesPerWave + t) * 32 + (lane & 31)];
       }
     }
@@ -258,7 +224,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel(RQOp<kK> op, Fused
 
 }  // namespace fc
 
-extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const float* w_frag,
+extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const float* w_pad,
                                          const float* bias_pad, const int32_t* cols, float* logabsdet,
                                          uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t, int32_t hidden,
                                          const fc_rq_config* cfg, void* stream) {
@@ -267,7 +233,7 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
     return hipErrorInvalidValue;  // only the north-star layer shape is fused; callers fall back otherwise
   if (n % fc::kR != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
-  if (!x || !y || !h || !w_frag || !bias_pad || !cols || !logabsdet) return hipErrorInvalidValue;
+  if (!x || !y || !h || !w_pad || !bias_pad || !cols || !logabsdet) return hipErrorInvalidValue;
   if ((((uintptr_t)h | (uintptr_t)x | (uintptr_t)y) & 15u) != 0) return hipErrorInvalidValue;
 
   fc::RQOp<fc::kK> op;
@@ -283,10 +249,21 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
   op.inv_div = 1.f / q.wh_div;
 
   const char* dbg = getenv("FC_FUSED_DEBUG");
-  fc::FusedArgs a{x, y, h, w_frag, bias_pad, cols, logabsdet, err_flag, n / fc::kR, d, dbg ? atoi(dbg) : 0};
+  fc::FusedArgs a{x, y, h, w_pad, bias_pad, cols, logabsdet, err_flag, n / fc::kR, d, dbg ? atoi(dbg) : 0};
   const size_t lds = sizeof(float) * (size_t)(fc::kPBuf + fc::kHBuf + 2 * fc::kR * d + fc::kR) +
                      sizeof(int) * fc::kDt;
   if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
+  // "1": f32 MFMA, producer/consumer waves; "2": f32 MFMA, symmetric waves; default: split-bf16 MFMA
+  const char* which = getenv("FC_FUSED_KERNEL");
+  int64_t grid0 = fc::device_cu_count();
+  if (grid0 > a.tiles) grid0 = a.tiles;
+  if (!which || (which[0] != '1' && which[0] != '2')) {
+    if (fc::fused3_lds_bytes(d) <= 160 * 1024)
+      return fc::launch_fused3(op, a, (unsigned)grid0, static_cast<hipStream_t>(stream));
+    which = "2";
+  }
+  if (which[0] == '2')
+    return fc::launch_fused2(op, a, lds, (unsigned)grid0, static_cast<hipStream_t>(stream));
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc::rq_fused_linear_kernel),

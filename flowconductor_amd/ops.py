@@ -283,21 +283,18 @@ def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks):
 
 
 def pack_final_layer(weight, bias, num_bins=FUSED_BINS):
-    """[d_t*23, 64] weight / [d_t*23] bias of the conditioner's final Linear -> (w_frag [24, 64, 32],
-    bias_pad [768]) in the layout ``fc_rq_spline_fused_linear`` consumes (see include/flowcon_hip.h)."""
+    """[d_t*23, 64] weight / [d_t*23] bias of the conditioner's final Linear -> (w_pad [d_t*24, 64],
+    bias_pad [d_t*24]): one zero row / entry appended per dim so that the 768 columns form whole MFMA tiles."""
     p = 3 * num_bins - 1
     d_t = weight.shape[0] // p
     w = weight.detach().reshape(d_t, p, weight.shape[1])
     wpad = torch.cat((w, w.new_zeros(d_t, 1, weight.shape[1])), dim=1).reshape(d_t * (p + 1), weight.shape[1])
     b = bias.detach().reshape(d_t, p)
-    bpad = torch.cat((b, b.new_zeros(d_t, 1)), dim=1).reshape(-1).contiguous()
-    tiles = wpad.shape[0] // 32
-    # [tile, col, s, kk] -> [tile, kk, col, s] -> [tile, lane = kk*32 + col, s]
-    frag = wpad.reshape(tiles, 32, weight.shape[1] // 2, 2).permute(0, 3, 1, 2).reshape(tiles, 64, weight.shape[1] // 2)
-    return frag.contiguous(), bpad
+    bpad = torch.cat((b, b.new_zeros(d_t, 1)), dim=1).reshape(-1)
+    return wpad.contiguous(), bpad.contiguous()
 
 
-def rq_spline_fused_linear(inputs, hidden, w_frag, bias_pad, cols, *, num_bins, tail_bound,
+def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, tail_bound,
                            min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
                            min_derivative=DEFAULT_MIN_DERIVATIVE, wh_divisor=1.0, inverse=False):
     """RQ-spline coupling bijector with the conditioner's final Linear fused in (rows must be a multiple
@@ -321,7 +318,7 @@ def rq_spline_fused_linear(inputs, hidden, w_frag, bias_pad, cols, *, num_bins, 
     lad = torch.empty(n, dtype=torch.float32, device=x.device)
     err = _err_word(x.device, True)
     _call("fc_rq_spline_fused_linear", lib.fc_rq_spline_fused_linear, x.device, _hip.ptr(x), _hip.ptr(y),
-          _hip.ptr(h), _hip.ptr(w_frag), _hip.ptr(bias_pad), _hip.ptr(cols), _hip.ptr(lad), _hip.ptr(err), n, d,
+          _hip.ptr(h), _hip.ptr(w_pad), _hip.ptr(bias_pad), _hip.ptr(cols), _hip.ptr(lad), _hip.ptr(err), n, d,
           FUSED_DT, FUSED_HIDDEN, cfg, _hip.stream_ptr(x.device))
     _finish(True)
     return y, lad

@@ -288,17 +288,17 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             if inverse and self.unconditional_transform is not None:
                 identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
             hidden = net.hidden(identity_split, context)
-        w_frag, bias_pad = self._packed_final_layer()
+        w_pad, bias_pad = self._packed_final_layer()
         kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                   min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
                   wh_divisor=_softmax_divisor(net, warn=False), inverse=inverse)
         body = n - n % ops.FUSED_ROWS
         cols = self._cols(inputs.device)
         if body == n:
-            outputs, logabsdet = ops.rq_spline_fused_linear(inputs, hidden, w_frag, bias_pad, cols, **kw)
+            outputs, logabsdet = ops.rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, **kw)
         else:
             # the < 32 leftover rows go through the final Linear + the stand-alone kernel
-            out_a, lad_a = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_frag, bias_pad, cols, **kw)
+            out_a, lad_a = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_pad, bias_pad, cols, **kw)
             out_b, lad_b = self._coupling_kernel(inputs[body:].contiguous(), net.final_layer(hidden[body:]), inverse)
             outputs, logabsdet = torch.cat((out_a, out_b)), torch.cat((lad_a, lad_b))
         if self.unconditional_transform is not None:

@@ -69,10 +69,9 @@ int fc_rq_spline(const float* x, float* y, const float* params, const int32_t* c
  * never reaches HBM.  Specialised: hidden == 64, d_t == 32, K == 8, linear tails, d % 4 == 0, d <= 128,
  * n % 32 == 0 (callers route other shapes / the leftover rows through fc_rq_spline).
  *   h        [n, 64]  last hidden activation of the conditioner (input of its final Linear)
- *   w_frag   [24][64][32]  the weight, zero-padded from 23 to 24 columns per dim, in MFMA B-fragment order:
- *            w_frag[t][l][s] = Wpad[t*32 + (l & 31)][2*s + (l >> 5)]   (tile t, lane l, k-step s)
+ *   w_pad    [768, 64]  the weight, zero-padded from 23 to 24 rows per dim (row j*24+i = W row j*23+i, i < 23)
  *   bias_pad [768]     bias with the same padding */
-int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const float* w_frag,
+int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const float* w_pad,
                               const float* bias_pad, const int32_t* cols, float* logabsdet,
                               uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t, int32_t hidden,
                               const fc_rq_config* cfg, void* stream);

@@ -144,15 +144,13 @@ def test_deferred_error_state_resets():
 def test_pack_final_layer_layout():
     w = torch.arange(736 * 64, dtype=torch.float32).reshape(736, 64)
     b = torch.arange(736, dtype=torch.float32)
-    frag, bpad = ops.pack_final_layer(w, b)
-    assert frag.shape == (24, 64, 32) and bpad.shape == (768,)
-    # w_frag[t][l][s] = Wpad[t*32 + (l & 31)][2*s + (l >> 5)], Wpad row j*24+i = W row j*23+i (i < 23)
-    for (t_, s_, l_) in [(0, 0, 0), (3, 7, 45), (23, 31, 63), (11, 16, 31)]:
-        prow, k = t_ * 32 + (l_ & 31), 2 * s_ + (l_ >> 5)
+    wpad, bpad = ops.pack_final_layer(w, b)
+    assert wpad.shape == (768, 64) and bpad.shape == (768,)
+    for prow in (0, 22, 23, 24, 500, 767):
         j, i = divmod(prow, 24)
-        expect = 0.0 if i == 23 else float(w[j * 23 + i, k])
-        assert float(frag[t_, l_, s_]) == expect
-    assert float(bpad[23]) == 0.0 and float(bpad[24]) == float(b[23])
+        expect = torch.zeros(64) if i == 23 else w[j * 23 + i]
+        assert torch.equal(wpad[prow], expect)
+        assert float(bpad[prow]) == (0.0 if i == 23 else float(b[j * 23 + i]))
 
 
 def test_pack_linear_frag_layout():

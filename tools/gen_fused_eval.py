@@ -1,0 +1,112 @@
+"""Generates flowconductor_amd/csrc/fc_rq_fused3_eval.inc: the straight-line RQ-spline evaluation of one
+element in the fused final-Linear + spline kernel (K = 8 bins, linear tails), with the element's 23 raw
+parameters read from the lane's own MFMA accumulators (macro FC_P(i)) and 72 MFMA hook points spread
+evenly over its instruction stream.  hipcc's sched_group_barrier pipeline clusters about half of the MFMAs,
+so the interleave is explicit in the source: FC_HOOK(n) issues MFMA number n of the NEXT block and pins its
+position with a sched_barrier.
+
+    python tools/gen_fused_eval.py        # rewrites the .inc (committed; the build does not run this)
+
+The arithmetic and its order are those of RQOp::eval_tails_straight (fc_rq_op.h), which restates
+flowcon/transforms/splines/rational_quadratic.py:26-38 (tails) and :78-188 (spline).
+"""
+import os
+
+K = 8
+HOOKS = 72
+chunks = []  # (code, weight ~ VALU issue slots)
+
+
+def add(code, w):
+    chunks.append((code, w))
+
+
+add("const bool inside = (x >= q.left) && (x <= q.right);\nconst float xc = inside ? x : q.left;", 3)
+add("const f2 minb = {q.min_w, q.min_h}, c1 = {q.cw, q.ch};\nconst f2 lo = {q.left, q.bottom}, hi = {q.right, q.top};\n"
+    "const f2 span = hi - lo;\nfloat mx = -INFINITY, my = -INFINITY;", 1)
+for i in range(K):
+    add("f2 t%d = f2{FC_P(%d), FC_P(%d)} * inv_div;\nmx = fmaxf(mx, t%d.x);\nmy = fmaxf(my, t%d.y);" % (i, i, K + i, i, i), 3)
+add("const f2 m = {mx, my};\nf2 sum = {0.f, 0.f};", 0)
+for i in range(K):
+    add("t%d = t%d - m;" % (i, i), 1)
+    add("t%d = f2{exp_softmax(t%d.x), exp_softmax(t%d.y)};" % (i, i, i), 5)
+    add("sum += t%d;" % i, 1)
+add("const float rsx = div_lean(1.f, sum.x);", 5)
+add("const float rsy = div_lean(1.f, sum.y);\nconst f2 rs = {rsx, rsy};", 5)
+add("double cx = 0.0, cy = 0.0;\nf2 prev = lo, sel_lo = lo, sel_hi = lo;\nfloat u0 = q.tail_const, u1 = q.tail_const;", 1)
+for i in range(K):
+    add("const f2 w%d = minb + c1 * (t%d * rs);" % (i, i), 3)
+    add("cx += (double)w%d.x;\ncy += (double)w%d.y;" % (i, i), 4)
+    if i == K - 1:
+        add("const f2 next%d = hi;" % i, 0)
+    else:
+        add("const f2 next%d = span * f2{(float)cx, (float)cy} + lo;" % i, 4)
+    add("const bool take%d = xc >= (kInv ? prev.y : prev.x);" % i, 1)
+    add("sel_lo.x = take%d ? prev.x : sel_lo.x;\nsel_lo.y = take%d ? prev.y : sel_lo.y;" % (i, i), 2)
+    add("sel_hi.x = take%d ? next%d.x : sel_hi.x;\nsel_hi.y = take%d ? next%d.y : sel_hi.y;\nprev = next%d;" % (i, i, i, i, i), 2)
+    # derivative knots of the selected bin: the boundary ones are the linear-tail constant
+    lo_d = "q.tail_const" if i == 0 else "FC_P(%d)" % (2 * K + i - 1)
+    hi_d = "q.tail_const" if i == K - 1 else "FC_P(%d)" % (2 * K + i)
+    add("u0 = take%d ? %s : u0;\nu1 = take%d ? %s : u1;" % (i, lo_d, i, hi_d), 2)
+add("const float xk = sel_lo.x, yk = sel_lo.y;\nconst float wk = sel_hi.x - sel_lo.x, hk = sel_hi.y - sel_lo.y;", 2)
+add("const float delta = div_lean(hk, wk);", 5)
+add("float theta;\nif constexpr (!kInv) theta = div_lean(xc - xk, wk);", 3)
+# two softplus evaluations (softplus_lean_sel of fc_math.h), written out so hooks can sit inside them
+for n in (0, 1):
+    add("const float xb%d = u%d * q.beta;\nconst float xm%d = fminf(xb%d, 20.f);\nconst float e%d_hi = xm%d * 1.4426950216293335f;"
+        % (n, n, n, n, n, n), 3)
+    add("float e%d_lo = __builtin_fmaf(xm%d, 1.4426950216293335f, -e%d_hi);\n"
+        "e%d_lo = __builtin_fmaf(xm%d, 1.925963033500011e-8f, e%d_lo);" % (n, n, n, n, n, n), 2)
+    add("const float ex%d_0 = __builtin_amdgcn_exp2f(e%d_hi);\nconst float ex%d = __builtin_fmaf(ex%d_0, e%d_lo * 0.6931471805599453f, ex%d_0);"
+        % (n, n, n, n, n, n), 4)
+    add("const float up%d = 1.f + ex%d;\nconst float dd%d = up%d - 1.f;" % (n, n, n, n), 2)
+    add("const float lg%d = log_lean(up%d);" % (n, n), 5)
+    add("const float dv%d = div_lean(ex%d, dd%d == 0.f ? 1.f : dd%d);" % (n, n, n, n), 6)
+    add("const float l1p%d = dd%d == 0.f ? ex%d : lg%d * dv%d;" % (n, n, n, n, n), 2)
+    add("const float sp%d = q.beta == 1.f ? l1p%d : div_lean(l1p%d, q.beta);\nconst float d%d = q.min_d + (xb%d > 20.f ? u%d : sp%d);"
+        % (n, n, n, n, n, n, n), 6)
+add("const float dsum = d0 + d1 - 2.f * delta;", 3)
+add("""if constexpr (kInv) {
+  const float rr = xc - yk;
+  const float qa = rr * dsum + hk * (delta - d0);
+  const float qb = hk * d0 - rr * dsum;
+  const float qc = -delta * rr;
+  const float disc = qb * qb - 4.f * qa * qc;
+  if (inside && !(disc >= 0.f)) err |= kErrDiscriminant;
+  theta = div_lean(2.f * qc, -qb - sqrt_lean(disc));
+}""", 2)
+add("const float t1mt = theta * (1.f - theta);\nconst float den = delta + dsum * t1mt;", 4)
+add("const float omt = 1.f - theta;\nconst float dn1 = d1 * (theta * theta) + 2.f * delta * t1mt;", 5)
+add("const float dnum = (delta * delta) * (dn1 + d0 * (omt * omt));", 4)
+add("const float lg_a = log_lean(dnum);", 5)
+add("const float lg_b = log_lean(den);", 5)
+add("const float lval = lg_a - 2.f * lg_b;", 2)
+add("""float ys;
+if constexpr (!kInv) {
+  const float num = hk * (delta * (theta * theta) + d0 * t1mt);
+  ys = yk + div_lean(num, den);
+} else {
+  ys = theta * wk + xk;
+}""", 8)
+add("y = inside ? ys : x;\nlad = inside ? (kInv ? -lval : lval) : 0.f;", 3)
+
+total = sum(w for _, w in chunks)
+out = ["// GENERATED by tools/gen_fused_eval.py -- do not edit by hand.",
+       "// Straight-line RQ-spline evaluation (K = %d, linear tails) of one element with %d MFMA hook points." % (K, HOOKS),
+       "// Expects in scope: FC_P(i) (raw parameter i of the element, 0 <= i < 23), x, inv_div, q (RQParams), err,",
+       "// kInv (constexpr bool), outputs y / lad, and FC_HOOK(n)."]
+acc = 0.0
+hook = 0
+for code, w in chunks:
+    out.append(code)
+    acc += w
+    while hook < HOOKS and acc >= (hook + 1) * total / HOOKS:
+        out.append("FC_HOOK(%d)" % hook)
+        hook += 1
+while hook < HOOKS:
+    out.append("FC_HOOK(%d)" % hook)
+    hook += 1
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flowconductor_amd", "csrc",
+                    "fc_rq_fused3_eval.inc")
+open(path, "w").write("\n".join(out) + "\n")
+print("wrote", path, "chunks", len(chunks), "weight", total)
