@@ -33,12 +33,31 @@
 #include "fc_rq_fused.h"
 #include "../../include/flowcon_hip.h"
 
-// tools/probe/build_fused_variants.sh only: ablation builds (1 no evaluation, 4 no MFMAs).
+// tools/probe/build_fused_variants.sh only: ablation builds (1 no evaluation, 4 no MFMAs, 8 loads from L2,
+// 16 clock stamps, 32 half of the MFMAs).
 #ifndef FC_ABL
 #define FC_ABL 0
 #endif
 
 namespace fc {
+
+// (x, y) pair of the dual-axis walk.  FC_SCALAR_WALK: plain struct instead of the packed-math vector type.
+struct s2 {
+  float x, y;
+};
+__device__ __forceinline__ s2 operator+(s2 a, s2 b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ s2 operator-(s2 a, s2 b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ s2 operator*(s2 a, s2 b) { return {a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ s2 operator*(s2 a, float b) { return {a.x * b, a.y * b}; }
+__device__ __forceinline__ s2& operator+=(s2& a, s2 b) { a.x += b.x; a.y += b.y; return a; }
+#ifndef FC_CUM_T
+#define FC_CUM_T double   // at::cumsum on the CPU accumulates f32 in double
+#endif
+#ifdef FC_SCALAR_WALK
+#define FC_F2 s2
+#else
+#define FC_F2 f2
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -122,6 +141,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   const int xvec = kR * D / 4;
   float4 hv, xv0, xv1;
   auto fetch = [&](int64_t t) {
+    if (FC_ABL & 8) t = tile0;   // ablation: every tile's loads hit in L2
     hv = reinterpret_cast<const float4*>(a.h + t * kR * kH)[tid];
     const float4* xg = reinterpret_cast<const float4*>(a.x + t * kR * D);
     xv0 = xg[tid < xvec ? tid : 0];
@@ -187,25 +207,22 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   auto step = [&](const f32x4 (&pa)[kCt3], int xb, int cblk, f32x4 (&acc)[kCt3], int hb, int pblk) {
     float* xr = xbuf + (xb * kR + 16 * cblk + s16) * XS + cs[4 * wave + g];
     const float x = *xr;
-    // operands are read one use ahead of the MFMA that takes them
+    // LDS operands are read well ahead of the MFMA that takes them: h^T fragments one group of 6 MFMAs,
+    // Wl fragments 4 MFMAs, accumulator start values 3 MFMAs
     bf16x8 bcur, bnext = hfrag(hb, pblk, term_h(0), 0);
-    bf16x8 wlcur, wlnext = wl_w[0];
-    f32x4 bcurv, bnextv = bb_w[0];
+    bf16x8 wlq[4] = {wl_w[0], wl_w[2 * 64], wl_w[4 * 64], wl_w[6 * 64]};
+    f32x4 bq[3] = {bb_w[0], bb_w[4], bb_w[8]};
     auto hook = [&](auto N) {
       constexpr int n = decltype(N)::value;
       if constexpr (n % 6 == 0) {
         bcur = bnext;
         if constexpr (n + 6 < 72) bnext = hfrag(hb, pblk, term_h((n + 6) / 12), ((n + 6) / 6) % 2);
       }
-      if constexpr (n < 12) {
-        wlcur = wlnext;
-        if constexpr (n + 1 < 12) wlnext = wl_w[(((n + 1) % 6) * 2 + (n + 1) / 6) * 64];
-      }
-      if constexpr (n < kCt3) {
-        bcurv = bnextv;
-        if constexpr (n + 1 < kCt3) bnextv = bb_w[(n + 1) * 4];
-      }
-      if constexpr (!(FC_ABL & 4)) mfma_n(N, acc, bcur, wlcur, bcurv);
+      const bf16x8 wlcur = wlq[n < 12 ? n % 4 : 0];
+      const f32x4 bcurv = bq[n < kCt3 ? n % 3 : 0];
+      if constexpr (n + 4 < 12) wlq[n % 4] = wl_w[(((n + 4) % 6) * 2 + (n + 4) / 6) * 64];
+      if constexpr (n + 3 < kCt3) bq[n % 3] = bb_w[(n + 3) * 4];
+      if constexpr (!(FC_ABL & 4) && !((FC_ABL & 32) && n >= 36)) mfma_n(N, acc, bcur, wlcur, bcurv);
       __builtin_amdgcn_sched_barrier(0);
     };
     const RQParams& q = op.q;
@@ -238,6 +255,9 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     if (g == 0) lpart[(xb * 8 + wave) * kR + 16 * cblk + s16] = l;
   };
 
+#if FC_ABL & 16   // ablation: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, stamped around the loop
+  const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   f32x4 acc0[kCt3], acc1[kCt3];
 #pragma unroll
   for (int t = 0; t < kCt3; ++t) acc0[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -272,6 +292,12 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     }
     tb ^= 1;
   }
+#if FC_ABL & 16   // the stamps overwrite two outputs of the workgroup's first tile: probe builds only
+  if (tid == 0) {
+    a.y[tile0 * kR * D] = (float)(__builtin_amdgcn_s_memtime() - stamp_c0);
+    a.y[tile0 * kR * D + 1] = (float)(__builtin_amdgcn_s_memrealtime() - stamp_r0);
+  }
+#endif
   if (err && a.err) atomicOr(a.err, err);
 }
 

@@ -22,25 +22,25 @@ def add(code, w):
 
 
 add("const bool inside = (x >= q.left) && (x <= q.right);\nconst float xc = inside ? x : q.left;", 3)
-add("const f2 minb = {q.min_w, q.min_h}, c1 = {q.cw, q.ch};\nconst f2 lo = {q.left, q.bottom}, hi = {q.right, q.top};\n"
-    "const f2 span = hi - lo;\nfloat mx = -INFINITY, my = -INFINITY;", 1)
+add("const FC_F2 minb = {q.min_w, q.min_h}, c1 = {q.cw, q.ch};\nconst FC_F2 lo = {q.left, q.bottom}, hi = {q.right, q.top};\n"
+    "const FC_F2 span = hi - lo;\nfloat mx = -INFINITY, my = -INFINITY;", 1)
 for i in range(K):
-    add("f2 t%d = f2{FC_P(%d), FC_P(%d)} * inv_div;\nmx = fmaxf(mx, t%d.x);\nmy = fmaxf(my, t%d.y);" % (i, i, K + i, i, i), 3)
-add("const f2 m = {mx, my};\nf2 sum = {0.f, 0.f};", 0)
+    add("FC_F2 t%d = FC_F2{FC_P(%d), FC_P(%d)} * inv_div;\nmx = fmaxf(mx, t%d.x);\nmy = fmaxf(my, t%d.y);" % (i, i, K + i, i, i), 3)
+add("const FC_F2 m = {mx, my};\nFC_F2 sum = {0.f, 0.f};", 0)
 for i in range(K):
     add("t%d = t%d - m;" % (i, i), 1)
-    add("t%d = f2{exp_softmax(t%d.x), exp_softmax(t%d.y)};" % (i, i, i), 5)
+    add("t%d = FC_F2{exp_softmax(t%d.x), exp_softmax(t%d.y)};" % (i, i, i), 5)
     add("sum += t%d;" % i, 1)
 add("const float rsx = div_lean(1.f, sum.x);", 5)
-add("const float rsy = div_lean(1.f, sum.y);\nconst f2 rs = {rsx, rsy};", 5)
-add("double cx = 0.0, cy = 0.0;\nf2 prev = lo, sel_lo = lo, sel_hi = lo;\nfloat u0 = q.tail_const, u1 = q.tail_const;", 1)
+add("const float rsy = div_lean(1.f, sum.y);\nconst FC_F2 rs = {rsx, rsy};", 5)
+add("FC_CUM_T cx = 0, cy = 0;\nFC_F2 prev = lo, sel_lo = lo, sel_hi = lo;\nfloat u0 = q.tail_const, u1 = q.tail_const;", 1)
 for i in range(K):
-    add("const f2 w%d = minb + c1 * (t%d * rs);" % (i, i), 3)
-    add("cx += (double)w%d.x;\ncy += (double)w%d.y;" % (i, i), 4)
+    add("const FC_F2 w%d = minb + c1 * (t%d * rs);" % (i, i), 3)
+    add("cx += (FC_CUM_T)w%d.x;\ncy += (FC_CUM_T)w%d.y;" % (i, i), 4)
     if i == K - 1:
-        add("const f2 next%d = hi;" % i, 0)
+        add("const FC_F2 next%d = hi;" % i, 0)
     else:
-        add("const f2 next%d = span * f2{(float)cx, (float)cy} + lo;" % i, 4)
+        add("const FC_F2 next%d = span * FC_F2{(float)cx, (float)cy} + lo;" % i, 4)
     add("const bool take%d = xc >= (kInv ? prev.y : prev.x);" % i, 1)
     add("sel_lo.x = take%d ? prev.x : sel_lo.x;\nsel_lo.y = take%d ? prev.y : sel_lo.y;" % (i, i), 2)
     add("sel_hi.x = take%d ? next%d.x : sel_hi.x;\nsel_hi.y = take%d ? next%d.y : sel_hi.y;\nprev = next%d;" % (i, i, i, i, i), 2)

@@ -1,0 +1,34 @@
+"""In-kernel clock of the fused kernel: needs a probe build with FC_ABL & 16
+(tools/probe/build_fused_variants.sh 16; FLOWCON_HIP_LIB=tools/probe/build/libfc_abl16.so)."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from flowconductor_amd import ops  # noqa: E402
+
+n, d, d_t, k = 1 << 20, 64, 32, 8
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+x = torch.randn(n, d, device=dev) * 1.5
+cols = torch.arange(0, d, 2, dtype=torch.int32, device=dev)
+h = torch.randn(n, 64, device=dev)
+w = torch.randn(d_t * 23, 64, device=dev) * 0.2
+b = torch.randn(d_t * 23, device=dev) * 0.1
+wp, bp = ops.pack_final_layer(w, b)
+t0 = time.time()
+with torch.no_grad():
+    while time.time() - t0 < 2.5:   # >= 2 s of back-to-back launches before reading the stamps
+        for _ in range(50):
+            y, lad = ops.rq_spline_fused_linear(x, h, wp, bp, cols, num_bins=k, tail_bound=3.0, wh_divisor=8.0)
+        torch.cuda.synchronize()
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+yy = y.view(-1, 32 * d)[:cus, :2].double().cpu()
+cyc, rt = yy[:, 0], yy[:, 1]
+ghz = (cyc / rt * 0.1)
+tiles = n // 32 / cus
+print("workgroups %d  tiles/wg %.0f  cycles median %.0f  realtime median %.1f us  clock median %.3f GHz (min %.3f max %.3f)  cycles/tile %.0f"
+      % (cus, tiles, cyc.median(), rt.median() / 100.0, ghz.median(), ghz.min(), ghz.max(), cyc.median() / tiles))
