@@ -1,4 +1,4 @@
-// Fused final-Linear + RQ-spline kernel, third structure: split-bf16 matrix cores, parameters born in the
+// Fused final-Linear + RQ-spline kernel, third structure: split-f16 matrix cores, parameters born in the
 // evaluating lane's registers.  gfx950.
 //
 //   params[n, :] = W h[n, :] + b        (flowcon/nn/nets/resnet.py:91,99, the conditioner's final Linear)
@@ -6,24 +6,29 @@
 //
 // Why not the f32-input MFMA (fc_rq_fused.hip, fc_rq_fused2.hip): v_mfma_f32_*_f32 runs at the f32 VALU
 // rate and, measured here, does not overlap with VALU work at all -- MFMA-only 0.85 ms, spline-only
-// 0.72 ms, both 1.29 ms per 2^20-row launch, whichever way the two streams were interleaved.  The bf16
-// matrix pipe is 16x faster and does run beside the VALU.  So the f32 product is computed exactly enough
-// on it: every f32 value is split into three bf16 pieces (x = xh + xm + xl, exact), and
-//   W h = Wl hh + Wh hl + Wm hm + Wm hh + Wh hm + Wh hh      (+ three terms <= 2^-24 |W||h|, dropped)
-// is accumulated in f32 by v_mfma_f32_16x16x32_bf16: 6 MFMA terms x 2 k-steps per 16x16 output tile, 3/8
-// of the f32-MFMA cycles, truncation error 1.4e-8 sum|W||h| (an f32 GEMM's own rounding is ~4e-7).
+// 0.72 ms, both 1.29 ms per 2^20-row launch, whichever way the two streams were interleaved.  The 16-bit
+// matrix pipe is 16x faster.  So the f32 product is computed to f32 accuracy on it: after an exact
+// power-of-two scaling (per wave for its weight rows, per sample for the h row, so that the row maximum
+// sits in [2^10, 2^11)) every value is split into two f16 pieces, x = xh + xl + O(2^-22 max|x|), and
+//   W h = Wl hh + Wh hl + Wh hh                    (+ Wl hl <= 2^-22 |W||h|, dropped)
+// is accumulated in f32 by v_mfma_f32_16x16x32_f16: 3 terms x 2 k-steps per 16x16 output tile, 3/16 of
+// the f32-MFMA cycles.  Error against float64: max 1.7e-7, rms 2.2e-8 of sum|W||h| -- an f32 GEMM's own
+// rounding is 4.1e-7 / 3.4e-8 on the same data (tools/probe/split_accuracy.py).  [A three-piece bf16
+// split (6 terms, no scaling needed) measured 0.77 ms; a bf16 MFMA costs its full 16 cycles beside a
+// VALU-bound stream (tools/probe/mfma_valu_overlap.hip), so halving the MFMA count pays.]
 //
 // Layout.  The product is taken transposed, P^T = W h^T: A = weight rows (features), B = h^T (samples on
 // the columns).  The C layout then gives lane (s = lane & 15, g = lane >> 4) the features 4g..4g+3 of
 // sample s; with the weight rows of a tile ordered as (dim g, param 4t + r), six tiles hand that lane all
 // 24 (23 + pad) parameters of element (sample s, dim 4w + g) in its own accumulators: no LDS round trip
-// for the parameters (the f32 kernels moved 98 KB of them through LDS per 32-row tile).
+// for the parameters (the f32 kernels moved 98 KB of them through LDS per 32-row tile).  The scaling is
+// undone for free: logit = fma(acc, 2^-(S_w + T_s) / sqrt(hidden), bias / sqrt(hidden)).
 //
 // One 512-thread workgroup per CU walks 32-row tiles.  Wave w owns transformed dims 4w..4w+3 for the whole
-// kernel: their weight pieces Wh, Wm stay in 96 VGPRs, Wl in LDS (96 KB for the 8 waves).  Per 16-sample
-// block a wave issues 72 MFMAs for the NEXT block and evaluates one element per lane of the CURRENT
-// block, hand-interleaved: the evaluation is generated straight-line code with 72 hook points
-// (tools/gen_fused_eval.py), hook n issues MFMA n and pins it with a sched_barrier.
+// kernel: both weight pieces stay in 96 VGPRs.  Per 16-sample block a wave issues 36 MFMAs for the NEXT
+// block and evaluates one element per lane of the CURRENT block, hand-interleaved: the evaluation is
+// generated straight-line code with 36 hook points (tools/gen_fused_eval.py), hook n issues MFMA n and pins
+// it with a sched_barrier.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
@@ -34,69 +39,59 @@
 #include "../../include/flowcon_hip.h"
 
 // tools/probe/build_fused_variants.sh only: ablation builds (1 no evaluation, 4 no MFMAs, 8 loads from L2,
-// 16 clock stamps, 32 half of the MFMAs).
+// 16 clock stamps).
 #ifndef FC_ABL
 #define FC_ABL 0
 #endif
 
 namespace fc {
 
-// (x, y) pair of the dual-axis walk.  FC_SCALAR_WALK: plain struct instead of the packed-math vector type.
-struct s2 {
-  float x, y;
-};
-__device__ __forceinline__ s2 operator+(s2 a, s2 b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ s2 operator-(s2 a, s2 b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ s2 operator*(s2 a, s2 b) { return {a.x * b.x, a.y * b.y}; }
-__device__ __forceinline__ s2 operator*(s2 a, float b) { return {a.x * b, a.y * b}; }
-__device__ __forceinline__ s2& operator+=(s2& a, s2 b) { a.x += b.x; a.y += b.y; return a; }
 #ifndef FC_CUM_T
 #define FC_CUM_T double   // at::cumsum on the CPU accumulates f32 in double
 #endif
-#ifdef FC_SCALAR_WALK
-#define FC_F2 s2
-#else
 #define FC_F2 f2
-#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCt3 = 6;                       // 16-feature tiles per wave: 4 dims x 24 padded params
-constexpr int kHB = kH + 8;                   // bf16 per h row in LDS (144 B: conflict-free b128 reads)
-constexpr int kHPiece = kR * kHB;             // bf16 per piece per buffer
-constexpr int kWlBytes = 8 * kCt3 * 2 * 64 * 16;   // Wl fragments [wave][tile][k-step][lane] x 16 B
-constexpr int kHbufBytes = 2 * 3 * kHPiece * 2;
+constexpr int kHB = kH + 8;                   // f16 per h row in LDS (144 B: conflict-free b128 reads)
+constexpr int kHPiece = kR * kHB;             // f16 per piece per buffer
+constexpr int kHbufBytes = 2 * 2 * kHPiece * 2;    // [buf][piece][row][kHB] f16
 constexpr int kBiasBytes = 8 * kCt3 * 4 * 16;      // [wave][tile][g] float4
 constexpr int kLpartBytes = 2 * 8 * kR * 4;        // [buf][wave][row]
+constexpr int kHscaleBytes = 2 * kR * 4;           // [buf][row] 2^-T of the h row
 
 size_t fused3_lds_bytes(int d) {
-  return (size_t)kWlBytes + kHbufBytes + kBiasBytes + kLpartBytes + 2 * kR * (d + 4) * 4 + kDt * 4;
+  return (size_t)kHbufBytes + kBiasBytes + kLpartBytes + kHscaleBytes + 2 * kR * (d + 4) * 4 + kDt * 4;
 }
 
-// x = h + m + l with bf16 pieces (round-to-nearest-even; both differences are exact in f32)
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
-  h = (__bf16)x;
-  const float r1 = x - (float)h;
-  m = (__bf16)r1;
-  l = (__bf16)(r1 - (float)m);
+// Power-of-two scale that lifts m = max|x| into [2^10, 2^11), and its inverse.  Tiny or zero maxima are left
+// alone (their pieces underflow to an absolute error far below f32 resolution of any O(1) result).
+__device__ __forceinline__ void pow2_scale(float m, float& scale, float& unscale) {
+  const uint32_t e = (__float_as_uint(m) >> 23) & 255u;      // biased exponent, floor(log2 m) = e - 127
+  const bool ok = e >= 11u && e < 255u;
+  scale = ok ? __uint_as_float((264u - e) << 23) : 1.f;       // 2^(10 - (e - 127))
+  unscale = ok ? __uint_as_float((e - 10u) << 23) : 1.f;
 }
 
-// term order: small products first.  (weight piece, h piece), 0 = high, 1 = middle, 2 = low
-__host__ __device__ constexpr int term_w(int term) { return term == 0 ? 2 : (term == 2 || term == 3 ? 1 : 0); }
-__host__ __device__ constexpr int term_h(int term) { return term == 1 ? 2 : (term == 2 || term == 4 ? 1 : 0); }
+// x = h + l (+ residual <= 2^-22 |x|) with f16 pieces, round-to-nearest-even; the difference is exact in f32
+__device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
+  h = (_Float16)x;
+  l = (_Float16)(x - (float)h);
+}
 
 template <bool kInv>
 __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  bf16x8* wl = reinterpret_cast<bf16x8*>(smem3);                                   // [8][6][2][64]
-  __bf16* hbuf = reinterpret_cast<__bf16*>(smem3 + kWlBytes);                       // [2][3][kR][kHB]
-  f32x4* bbuf = reinterpret_cast<f32x4*>(smem3 + kWlBytes + kHbufBytes);            // [8][6][4]
-  float* lpart = reinterpret_cast<float*>(smem3 + kWlBytes + kHbufBytes + kBiasBytes);   // [2][8][kR]
-  float* xbuf = lpart + 2 * 8 * kR;                                                 // [2][kR][D + 4]
+  _Float16* hbuf = reinterpret_cast<_Float16*>(smem3);                               // [2][2][kR][kHB]
+  f32x4* bbuf = reinterpret_cast<f32x4*>(smem3 + kHbufBytes);                         // [8][6][4]
+  float* lpart = reinterpret_cast<float*>(smem3 + kHbufBytes + kBiasBytes);           // [2][8][kR]
+  float* hscale = lpart + 2 * 8 * kR;                                                 // [2][kR]
+  float* xbuf = hscale + 2 * kR;                                                      // [2][kR][D + 4]
   const int D = a.D, XS = D + 4;
-  int* cs = reinterpret_cast<int*>(xbuf + 2 * kR * XS);                             // [kDt]
+  int* cs = reinterpret_cast<int*>(xbuf + 2 * kR * XS);                               // [kDt]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s16 = lane & 15, g = lane >> 4;
@@ -104,37 +99,58 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   const int64_t tile0 = blockIdx.x;
   if (tile0 >= a.tiles) return;
   if (tid < kDt) cs[tid] = a.cols[tid];
+  const float inv_div = op.inv_div;
 
   // ---- resident weights ---------------------------------------------------------------------------------
   // A operand of tile t, k-step ks: lane holds W[row(t, lane & 15)][k = 32 ks + 8 (lane >> 4) + j], j < 8,
   // where row(t, rho) = padded feature (dim 4w + (rho >> 2)) * 24 + 4t + (rho & 3).
-  bf16x8 wh[kCt3][2], wm[kCt3][2];
+  f16x8 wh[kCt3][2], wl[kCt3][2];
+  float w_unscale;
+  {
+    float wv[kCt3][2][8];
+    float wmax = 0.f;
 #pragma unroll
-  for (int t = 0; t < kCt3; ++t) {
-    const int row = (4 * wave + (s16 >> 2)) * kPP + 4 * t + (s16 & 3);
+    for (int t = 0; t < kCt3; ++t) {
+      const int row = (4 * wave + (s16 >> 2)) * kPP + 4 * t + (s16 & 3);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const float4* src = reinterpret_cast<const float4*>(a.wpad + (int64_t)row * kH + 32 * ks + 8 * g);
-      const float4 v0 = src[0], v1 = src[1];
-      const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      bf16x8 lo8;
+      for (int ks = 0; ks < 2; ++ks) {
+        const float4* src = reinterpret_cast<const float4*>(a.wpad + (int64_t)row * kH + 32 * ks + 8 * g);
+        const float4 v0 = src[0], v1 = src[1];
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        __bf16 ph, pm, pl;
-        split3(v[j], ph, pm, pl);
-        wh[t][ks][j] = ph;
-        wm[t][ks][j] = pm;
-        lo8[j] = pl;
+        for (int j = 0; j < 8; ++j) {
+          wv[t][ks][j] = v[j];
+          wmax = fmaxf(wmax, fabsf(v[j]));
+        }
       }
-      wl[((wave * kCt3 + t) * 2 + ks) * 64 + lane] = lo8;
     }
-    // accumulator start values: lane (s, g) register r of tile t is feature (dim 4w + g, param 4t + r)
-    if (s16 == 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+    float w_scale;
+    pow2_scale(wmax, w_scale, w_unscale);
+#pragma unroll
+    for (int t = 0; t < kCt3; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          _Float16 ph, pl;
+          split2(wv[t][ks][j] * w_scale, ph, pl);
+          wh[t][ks][j] = ph;
+          wl[t][ks][j] = pl;
+        }
+  }
+  // bias of lane (s, g), register r of tile t: feature (dim 4w + g, param 4t + r).  The width / height
+  // logits are divided by sqrt(hidden_features) (rational_quadratic.py:26-29 callers, coupling.py:565-566);
+  // the division is folded into the fma that also undoes the scaling, so their bias is stored pre-divided.
+  if (s16 == 0) {
+#pragma unroll
+    for (int t = 0; t < kCt3; ++t) {
       const float* bsrc = a.bias + (4 * wave + g) * kPP + 4 * t;
-      bbuf[(wave * kCt3 + t) * 4 + g] = f32x4{bsrc[0], bsrc[1], bsrc[2], bsrc[3]};
+      const float m = t < 4 ? inv_div : 1.f;   // params 0..15 are widths and heights
+      bbuf[(wave * kCt3 + t) * 4 + g] = f32x4{bsrc[0] * m, bsrc[1] * m, bsrc[2] * m, bsrc[3] * m};
     }
   }
-  const bf16x8* wl_w = wl + wave * kCt3 * 2 * 64 + lane;   // + (t * 2 + ks) * 64
   const f32x4* bb_w = bbuf + wave * kCt3 * 4 + g;           // + t * 4
 
   uint32_t err = 0;
@@ -152,100 +168,96 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     return reinterpret_cast<float4*>(xbuf + (buf * kR + r) * XS + c);
   };
   auto park = [&](int buf) {
+    // thread tid holds h[row tid >> 4][4 (tid & 15) ..]: the 16 threads of a row are 16 adjacent lanes
     const int r = tid >> 4, c = (tid & 15) * 4;
     const float v[4] = {hv.x, hv.y, hv.z, hv.w};
-    bf16x4 p0, p1, p2;
+    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+    float sc, un;
+    pow2_scale(m, sc, un);
+    f16x4 p0, p1;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      __bf16 ph, pm, pl;
-      split3(v[j], ph, pm, pl);
-      p0[j] = ph; p1[j] = pm; p2[j] = pl;
+      _Float16 ph, pl;
+      split2(v[j] * sc, ph, pl);
+      p0[j] = ph; p1[j] = pl;
     }
-    __bf16* dst = hbuf + (buf * 3 * kR + r) * kHB + c;
-    *reinterpret_cast<bf16x4*>(dst) = p0;
-    *reinterpret_cast<bf16x4*>(dst + kHPiece) = p1;
-    *reinterpret_cast<bf16x4*>(dst + 2 * kHPiece) = p2;
+    _Float16* dst = hbuf + (buf * 2 * kR + r) * kHB + c;
+    *reinterpret_cast<f16x4*>(dst) = p0;
+    *reinterpret_cast<f16x4*>(dst + kHPiece) = p1;
+    if ((tid & 15) == 0) hscale[buf * kR + r] = un;
     if (tid < xvec) *xslot(buf, tid) = xv0;
     if (tid + 512 < xvec) *xslot(buf, tid + 512) = xv1;
   };
   // B operand (h^T piece `hp`, k-step ks) of block `blk` in buffer `hb`:
   // lane holds h[sample 16 blk + (lane & 15)][k = 32 ks + 8 (lane >> 4) + j]
   auto hfrag = [&](int hb, int blk, int hp, int ks) {
-    return *reinterpret_cast<const bf16x8*>(hbuf + ((hb * 3 + hp) * kR + 16 * blk + s16) * kHB + 32 * ks + 8 * g);
+    return *reinterpret_cast<const f16x8*>(hbuf + ((hb * 2 + hp) * kR + 16 * blk + s16) * kHB + 32 * ks + 8 * g);
   };
 
-  // MFMA number n of a block: term n / 12, k-step (n / 6) % 2, tile n % 6
-  auto mfma_n = [&](auto N, f32x4 (&acc)[kCt3], const bf16x8& bcur, const bf16x8& wlcur, const f32x4& bias) {
+  // MFMA number n of a block: term n / 12 (0: Wl hh, 1: Wh hl, 2: Wh hh -- small products first),
+  // k-step (n / 6) % 2, tile n % 6
+  auto mfma_n = [&](auto N, f32x4 (&acc)[kCt3], const f16x8& bcur) {
     constexpr int n = decltype(N)::value, term = n / 12, ks = (n / 6) % 2, t = n % 6;
-    constexpr int wp = term_w(term);
-    const bf16x8& aop = wp == 0 ? wh[t][ks] : (wp == 1 ? wm[t][ks] : wlcur);
-    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, bcur, n < kCt3 ? bias : acc[t], 0, 0, 0);
+    const f16x8& aop = term == 0 ? wl[t][ks] : wh[t][ks];
+    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aop, bcur, n < kCt3 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[t], 0, 0, 0);
   };
+  constexpr auto term_h = [](int term) { return term == 1 ? 1 : 0; };   // h piece of a term
+
+#define FC_ALL36(M)                                                                                          \
+  M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18)     \
+  M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31) M(32) M(33) M(34) M(35)
 
   // Prologue only: the parameters of block `blk` of the tile in buffer `hb`, nothing to evaluate yet.
   auto produce_only = [&](f32x4 (&acc)[kCt3], int hb, int blk) {
-    bf16x8 bcur = hfrag(hb, blk, term_h(0), 0);
-    auto step = [&](auto N) {
+    f16x8 bcur = hfrag(hb, blk, term_h(0), 0);
+    auto one = [&](auto N) {
       constexpr int n = decltype(N)::value;
       if constexpr (n % 6 == 0 && n > 0) bcur = hfrag(hb, blk, term_h(n / 12), (n / 6) % 2);
-      // n < 12: term 0, k-step n / 6, tile n % 6 -> Wl fragment index (n % 6) * 2 + n / 6
-      const bf16x8 wlcur = n < 12 ? wl_w[((n % 6) * 2 + n / 6) * 64] : bcur;
-      mfma_n(N, acc, bcur, wlcur, n < kCt3 ? bb_w[(n % 6) * 4] : f32x4{0.f, 0.f, 0.f, 0.f});
+      mfma_n(N, acc, bcur);
     };
-#define FC_S(n) step(std::integral_constant<int, n>{});
-    FC_S(0) FC_S(1) FC_S(2) FC_S(3) FC_S(4) FC_S(5) FC_S(6) FC_S(7) FC_S(8) FC_S(9) FC_S(10) FC_S(11)
-    FC_S(12) FC_S(13) FC_S(14) FC_S(15) FC_S(16) FC_S(17) FC_S(18) FC_S(19) FC_S(20) FC_S(21) FC_S(22) FC_S(23)
-    FC_S(24) FC_S(25) FC_S(26) FC_S(27) FC_S(28) FC_S(29) FC_S(30) FC_S(31) FC_S(32) FC_S(33) FC_S(34) FC_S(35)
-    FC_S(36) FC_S(37) FC_S(38) FC_S(39) FC_S(40) FC_S(41) FC_S(42) FC_S(43) FC_S(44) FC_S(45) FC_S(46) FC_S(47)
-    FC_S(48) FC_S(49) FC_S(50) FC_S(51) FC_S(52) FC_S(53) FC_S(54) FC_S(55) FC_S(56) FC_S(57) FC_S(58) FC_S(59)
-    FC_S(60) FC_S(61) FC_S(62) FC_S(63) FC_S(64) FC_S(65) FC_S(66) FC_S(67) FC_S(68) FC_S(69) FC_S(70) FC_S(71)
+#define FC_S(n) one(std::integral_constant<int, n>{});
+    FC_ALL36(FC_S)
 #undef FC_S
   };
 
-  // One step: evaluate this lane's element of block `cblk` of the tile in buffer `xb` from the parameters in
-  // `pa`, and produce into `acc` the parameters of block `pblk` of the tile in buffer `hb`.
+  // One step: evaluate this lane's element of block `cblk` of the tile in buffer `xb` from the accumulators
+  // `pa`, and produce into `acc` the accumulators of block `pblk` of the tile in buffer `hb`.
   auto step = [&](const f32x4 (&pa)[kCt3], int xb, int cblk, f32x4 (&acc)[kCt3], int hb, int pblk) {
     float* xr = xbuf + (xb * kR + 16 * cblk + s16) * XS + cs[4 * wave + g];
     const float x = *xr;
-    // LDS operands are read well ahead of the MFMA that takes them: h^T fragments one group of 6 MFMAs,
-    // Wl fragments 4 MFMAs, accumulator start values 3 MFMAs
-    bf16x8 bcur, bnext = hfrag(hb, pblk, term_h(0), 0);
-    bf16x8 wlq[4] = {wl_w[0], wl_w[2 * 64], wl_w[4 * 64], wl_w[6 * 64]};
-    f32x4 bq[3] = {bb_w[0], bb_w[4], bb_w[8]};
+    const float c_d = hscale[xb * kR + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
+    const float c_wh = c_d * inv_div;
+    f32x4 bw[kCt3];
+#pragma unroll
+    for (int t = 0; t < kCt3; ++t) bw[t] = bb_w[t * 4];
+    // h^T fragments are read one group of 6 MFMAs ahead of their use
+    f16x8 bcur, bnext = hfrag(hb, pblk, term_h(0), 0);
     auto hook = [&](auto N) {
       constexpr int n = decltype(N)::value;
       if constexpr (n % 6 == 0) {
         bcur = bnext;
-        if constexpr (n + 6 < 72) bnext = hfrag(hb, pblk, term_h((n + 6) / 12), ((n + 6) / 6) % 2);
+        if constexpr (n + 6 < 36) bnext = hfrag(hb, pblk, term_h((n + 6) / 12), ((n + 6) / 6) % 2);
       }
-      const bf16x8 wlcur = wlq[n < 12 ? n % 4 : 0];
-      const f32x4 bcurv = bq[n < kCt3 ? n % 3 : 0];
-      if constexpr (n + 4 < 12) wlq[n % 4] = wl_w[(((n + 4) % 6) * 2 + (n + 4) / 6) * 64];
-      if constexpr (n + 3 < kCt3) bq[n % 3] = bb_w[(n + 3) * 4];
-      if constexpr (!(FC_ABL & 4) && !((FC_ABL & 32) && n >= 36)) mfma_n(N, acc, bcur, wlcur, bcurv);
+      if constexpr (!(FC_ABL & 4)) mfma_n(N, acc, bcur);
       __builtin_amdgcn_sched_barrier(0);
     };
     const RQParams& q = op.q;
-    const float inv_div = op.inv_div;
     float y, lad;
     __builtin_amdgcn_sched_barrier(0);
 #define FC_HOOK(n) hook(std::integral_constant<int, n>{});
-#define FC_P(i) pa[(i) >> 2][(i) & 3]
+#define FC_WH(i) __builtin_fmaf(pa[(i) >> 2][(i) & 3], c_wh, bw[(i) >> 2][(i) & 3])
+#define FC_UD(j) __builtin_fmaf(pa[((j) + 16) >> 2][((j) + 16) & 3], c_d, bw[((j) + 16) >> 2][((j) + 16) & 3])
 #if FC_ABL & 1
-    FC_HOOK(0) FC_HOOK(1) FC_HOOK(2) FC_HOOK(3) FC_HOOK(4) FC_HOOK(5) FC_HOOK(6) FC_HOOK(7) FC_HOOK(8) FC_HOOK(9)
-    FC_HOOK(10) FC_HOOK(11) FC_HOOK(12) FC_HOOK(13) FC_HOOK(14) FC_HOOK(15) FC_HOOK(16) FC_HOOK(17) FC_HOOK(18) FC_HOOK(19)
-    FC_HOOK(20) FC_HOOK(21) FC_HOOK(22) FC_HOOK(23) FC_HOOK(24) FC_HOOK(25) FC_HOOK(26) FC_HOOK(27) FC_HOOK(28) FC_HOOK(29)
-    FC_HOOK(30) FC_HOOK(31) FC_HOOK(32) FC_HOOK(33) FC_HOOK(34) FC_HOOK(35) FC_HOOK(36) FC_HOOK(37) FC_HOOK(38) FC_HOOK(39)
-    FC_HOOK(40) FC_HOOK(41) FC_HOOK(42) FC_HOOK(43) FC_HOOK(44) FC_HOOK(45) FC_HOOK(46) FC_HOOK(47) FC_HOOK(48) FC_HOOK(49)
-    FC_HOOK(50) FC_HOOK(51) FC_HOOK(52) FC_HOOK(53) FC_HOOK(54) FC_HOOK(55) FC_HOOK(56) FC_HOOK(57) FC_HOOK(58) FC_HOOK(59)
-    FC_HOOK(60) FC_HOOK(61) FC_HOOK(62) FC_HOOK(63) FC_HOOK(64) FC_HOOK(65) FC_HOOK(66) FC_HOOK(67) FC_HOOK(68) FC_HOOK(69)
-    FC_HOOK(70) FC_HOOK(71)
-    y = x + (FC_P(0) + FC_P(5) + FC_P(10) + FC_P(15) + FC_P(16) + FC_P(21)) * 0.f + q.left * 0.f + inv_div * 0.f;
+    FC_ALL36(FC_HOOK)
+    y = x + (FC_WH(0) + FC_WH(5) + FC_WH(10) + FC_WH(15) + FC_UD(0) + FC_UD(5)) * 0.f + q.left * 0.f;
     lad = 0.f;
 #else
 #include "fc_rq_fused3_eval.inc"
 #endif
-#undef FC_P
+#undef FC_UD
+#undef FC_WH
 #undef FC_HOOK
     *xr = y;
     // logabsdet partial of this wave's 4 dims: lanes s, s+16, s+32, s+48 hold the same sample
@@ -300,6 +312,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #endif
   if (err && a.err) atomicOr(a.err, err);
 }
+#undef FC_ALL36
 
 hipError_t launch_fused3(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
   const size_t lds = fused3_lds_bytes(a.D);

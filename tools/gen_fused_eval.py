@@ -1,7 +1,8 @@
 """Generates flowconductor_amd/csrc/fc_rq_fused3_eval.inc: the straight-line RQ-spline evaluation of one
 element in the fused final-Linear + spline kernel (K = 8 bins, linear tails), with the element's 23 raw
-parameters read from the lane's own MFMA accumulators (macro FC_P(i)) and 72 MFMA hook points spread
-evenly over its instruction stream.  hipcc's sched_group_barrier pipeline clusters about half of the MFMAs,
+parameters read from the lane's own MFMA accumulators (macros FC_WH(i): width / height logit i < 16, already
+divided by sqrt(hidden_features); FC_UD(j): derivative logit j < 7) and 36 MFMA hook points spread evenly
+over its instruction stream.  hipcc's sched_group_barrier pipeline clusters about half of the MFMAs,
 so the interleave is explicit in the source: FC_HOOK(n) issues MFMA number n of the NEXT block and pins its
 position with a sched_barrier.
 
@@ -13,7 +14,7 @@ flowcon/transforms/splines/rational_quadratic.py:26-38 (tails) and :78-188 (spli
 import os
 
 K = 8
-HOOKS = 72
+HOOKS = 36
 chunks = []  # (code, weight ~ VALU issue slots)
 
 
@@ -25,7 +26,10 @@ add("const bool inside = (x >= q.left) && (x <= q.right);\nconst float xc = insi
 add("const FC_F2 minb = {q.min_w, q.min_h}, c1 = {q.cw, q.ch};\nconst FC_F2 lo = {q.left, q.bottom}, hi = {q.right, q.top};\n"
     "const FC_F2 span = hi - lo;\nfloat mx = -INFINITY, my = -INFINITY;", 1)
 for i in range(K):
-    add("FC_F2 t%d = FC_F2{FC_P(%d), FC_P(%d)} * inv_div;\nmx = fmaxf(mx, t%d.x);\nmy = fmaxf(my, t%d.y);" % (i, i, K + i, i, i), 3)
+    add("FC_F2 t%d = FC_F2{FC_WH(%d), FC_WH(%d)};\nmx = fmaxf(mx, t%d.x);\nmy = fmaxf(my, t%d.y);" % (i, i, K + i, i, i), 3)
+# the derivative logits leave the accumulators early, so the next block's MFMAs can reuse those registers
+for j in range(K - 1):
+    add("const float ud%d = FC_UD(%d);" % (j, j), 1)
 add("const FC_F2 m = {mx, my};\nFC_F2 sum = {0.f, 0.f};", 0)
 for i in range(K):
     add("t%d = t%d - m;" % (i, i), 1)
@@ -45,8 +49,8 @@ for i in range(K):
     add("sel_lo.x = take%d ? prev.x : sel_lo.x;\nsel_lo.y = take%d ? prev.y : sel_lo.y;" % (i, i), 2)
     add("sel_hi.x = take%d ? next%d.x : sel_hi.x;\nsel_hi.y = take%d ? next%d.y : sel_hi.y;\nprev = next%d;" % (i, i, i, i, i), 2)
     # derivative knots of the selected bin: the boundary ones are the linear-tail constant
-    lo_d = "q.tail_const" if i == 0 else "FC_P(%d)" % (2 * K + i - 1)
-    hi_d = "q.tail_const" if i == K - 1 else "FC_P(%d)" % (2 * K + i)
+    lo_d = "q.tail_const" if i == 0 else "ud%d" % (i - 1)
+    hi_d = "q.tail_const" if i == K - 1 else "ud%d" % i
     add("u0 = take%d ? %s : u0;\nu1 = take%d ? %s : u1;" % (i, lo_d, i, hi_d), 2)
 add("const float xk = sel_lo.x, yk = sel_lo.y;\nconst float wk = sel_hi.x - sel_lo.x, hk = sel_hi.y - sel_lo.y;", 2)
 add("const float delta = div_lean(hk, wk);", 5)
@@ -93,7 +97,7 @@ add("y = inside ? ys : x;\nlad = inside ? (kInv ? -lval : lval) : 0.f;", 3)
 total = sum(w for _, w in chunks)
 out = ["// GENERATED by tools/gen_fused_eval.py -- do not edit by hand.",
        "// Straight-line RQ-spline evaluation (K = %d, linear tails) of one element with %d MFMA hook points." % (K, HOOKS),
-       "// Expects in scope: FC_P(i) (raw parameter i of the element, 0 <= i < 23), x, inv_div, q (RQParams), err,",
+       "// Expects in scope: FC_WH(i) / FC_UD(j) (logits of the element), FC_F2, FC_CUM_T, x, q (RQParams), err,",
        "// kInv (constexpr bool), outputs y / lad, and FC_HOOK(n)."]
 acc = 0.0
 hook = 0
