@@ -46,6 +46,9 @@
 
 namespace fc {
 
+#ifndef FC_HOOK_MASK
+#define FC_HOOK_MASK 0   // sched_barrier mask at each MFMA hook: 0 pins everything
+#endif
 #ifndef FC_CUM_T
 #define FC_CUM_T double   // at::cumsum on the CPU accumulates f32 in double
 #endif
@@ -100,6 +103,9 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   if (tile0 >= a.tiles) return;
   if (tid < kDt) cs[tid] = a.cols[tid];
   const float inv_div = op.inv_div;
+#if FC_ABL & 16
+  const uint64_t stamp_r_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- resident weights ---------------------------------------------------------------------------------
   // A operand of tile t, k-step ks: lane holds W[row(t, lane & 15)][k = 32 ks + 8 (lane >> 4) + j], j < 8,
@@ -241,10 +247,16 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
         if constexpr (n + 6 < 36) bnext = hfrag(hb, pblk, term_h((n + 6) / 12), ((n + 6) / 6) % 2);
       }
       if constexpr (!(FC_ABL & 4)) mfma_n(N, acc, bcur);
-      __builtin_amdgcn_sched_barrier(0);
+      // Fairness between the two waves of a SIMD.  VALU issue goes to the higher s_setprio, then to the OLDER
+      // wave: left alone, waves 0-3 run each step unimpeded, wait ~3700 cycles per tile at the barriers, and
+      // waves 4-7 finish alone at single-wave issue rate.  A priority that falls as a wave advances (a
+      // sawtooth over 12 hooks) always favours the wave that is behind, so both reach the barrier together.
+      if constexpr (n % 3 == 2) __builtin_amdgcn_s_setprio(3 - ((n + 1) % 12) / 3);
+      __builtin_amdgcn_sched_barrier(FC_HOOK_MASK);
     };
     const RQParams& q = op.q;
     float y, lad;
+    __builtin_amdgcn_s_setprio(3);
     __builtin_amdgcn_sched_barrier(0);
 #define FC_HOOK(n) hook(std::integral_constant<int, n>{});
 #define FC_WH(i) __builtin_fmaf(pa[(i) >> 2][(i) & 3], c_wh, bw[(i) >> 2][(i) & 3])
@@ -270,6 +282,17 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #if FC_ABL & 16   // ablation: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, stamped around the loop
   const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#if FC_ABL & 16   // cycles each wave spends waiting at the two barriers of the loop
+  uint64_t barrier_wait = 0;
+#define FC_TIMED_BARRIER()                                        \
+  do {                                                            \
+    const uint64_t b0 = __builtin_amdgcn_s_memtime();             \
+    __syncthreads();                                              \
+    barrier_wait += __builtin_amdgcn_s_memtime() - b0;            \
+  } while (0)
+#else
+#define FC_TIMED_BARRIER() __syncthreads()
+#endif
   f32x4 acc0[kCt3], acc1[kCt3];
 #pragma unroll
   for (int t = 0; t < kCt3; ++t) acc0[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -283,11 +306,11 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     if (has_next) fetch(tile + stride);
     step(acc0, tb, 0, acc1, tb, 1);        // A: evaluate block 0 of `tile`, produce its block 1
     if (has_next) park(tb ^ 1);
-    __syncthreads();
+    FC_TIMED_BARRIER();
     // B: evaluate block 1, produce block 0 of the next tile (unconditional: on the last tile the MFMAs work
     // on stale h rows into accumulators nobody reads -- a branch would split the interleaved block).
     step(acc1, tb, 1, acc0, tb ^ 1, 0);
-    __syncthreads();
+    FC_TIMED_BARRIER();
     // Every thread writes out exactly the float4 slots it parks, and lpart is double-buffered, so no third
     // barrier is needed before the next iteration.
     {
@@ -308,11 +331,15 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   if (tid == 0) {
     a.y[tile0 * kR * D] = (float)(__builtin_amdgcn_s_memtime() - stamp_c0);
     a.y[tile0 * kR * D + 1] = (float)(__builtin_amdgcn_s_memrealtime() - stamp_r0);
+    a.y[tile0 * kR * D + 2] = (float)(stamp_r0 - stamp_r_entry);                 // prologue, 10 ns ticks
+    a.y[tile0 * kR * D + 3] = (float)(stamp_r_entry & 0xffffff);                  // entry time (for launch skew)
   }
+  if (lane == 0) a.y[tile0 * kR * D + 4 + wave] = (float)barrier_wait;
 #endif
   if (err && a.err) atomicOr(a.err, err);
 }
 #undef FC_ALL36
+#undef FC_TIMED_BARRIER
 
 hipError_t launch_fused3(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
   const size_t lds = fused3_lds_bytes(a.D);

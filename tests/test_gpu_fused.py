@@ -81,3 +81,55 @@ def test_fused_hidden_path_in_coupling(device, monkeypatch):
     assert maxdiff(y, ref_y) <= 2e-5 * max(1.0, float(ref_y.abs().max()))
     assert maxdiff(lad, ref_lad) <= 3e-4
     assert maxdiff(y, y2) <= 2e-5 and maxdiff(lad, lad2) <= 3e-4
+
+
+@pytest.mark.parametrize("case", ["typical", "zero_weights", "huge_h_rows", "tiny_h_rows", "mixed_row_scales",
+                                  "tiny_weights", "large_weights"])
+def test_fused_linear_scaling_edge_cases(case, device):
+    """The fused kernel computes W h on the f16 matrix cores after power-of-two scaling (per wave for the
+    weights, per row for h).  Parity of the whole op against a float64 Linear + the oracle's spline on
+    inputs that stress the scaling: zero-initialised final layer, rows of h far outside the f16 range."""
+    torch.manual_seed(7)
+    n, d, d_t, k, hidden = 256, 64, 32, 8, 64
+    x = torch.randn(n, d) * 1.5
+    h = torch.relu(torch.randn(n, hidden)) * 2 + torch.randn(n, hidden) * 0.3
+    w = torch.randn(d_t * (3 * k - 1), hidden) * 0.2
+    b = torch.randn(d_t * (3 * k - 1)) * 0.1
+    if case == "zero_weights":
+        w.zero_()
+    elif case == "huge_h_rows":
+        h *= 3.0e5       # beyond the f16 maximum; the weights shrink so that the logits stay O(1)
+        w /= 3.0e5
+    elif case == "tiny_h_rows":
+        h *= 1.0e-6
+        w *= 1.0e6
+    elif case == "mixed_row_scales":
+        s = torch.logspace(-6, 2, n).unsqueeze(1)
+        h *= s
+        w *= 0.05       # logits of the large rows stay moderate: the spline amplifies logit errors by their size
+    elif case == "tiny_weights":
+        w *= 1.0e-7
+    elif case == "large_weights":
+        w *= 40.0
+        h *= 0.025
+    cols = torch.arange(0, d, 2, dtype=torch.int32)
+    params64 = (h.double() @ w.double().T + b.double())
+    rows = params64.float().view(n, d_t, 3 * k - 1).clone()
+    out, lad_e = O.rq_from_rows(x[:, cols.long()], rows, k, "linear", 3.0, False, wh_divisor=float(hidden) ** 0.5)
+    ref_y = x.clone()
+    ref_y[:, cols.long()] = out
+    ref_lad = lad_e.sum(dim=1)
+    # what an f32 GEMM in front of the same spline gives: its distance from the float64-GEMM result is the
+    # noise floor of this input
+    rows32 = (h @ w.T + b).view(n, d_t, 3 * k - 1).clone()
+    out32, lad32 = O.rq_from_rows(x[:, cols.long()], rows32, k, "linear", 3.0, False, wh_divisor=float(hidden) ** 0.5)
+    floor_y = maxdiff(out32, out)
+    floor_lad = maxdiff(lad32.sum(dim=1), ref_lad)
+    wp, bp = ops.pack_final_layer(w.to(device), b.to(device))
+    with torch.no_grad():
+        y, lad = ops.rq_spline_fused_linear(x.to(device), h.to(device), wp, bp, cols.to(device), num_bins=k,
+                                            tail_bound=3.0, wh_divisor=float(hidden) ** 0.5)
+    # same bounds as the flow-level fused test above (f32 spline arithmetic on both sides)
+    assert maxdiff(y, ref_y) <= 2e-5 * max(1.0, float(ref_y.abs().max())) + 4 * floor_y
+    assert maxdiff(lad, ref_lad) <= 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10) + 4 * floor_lad
+    assert torch.isfinite(y).all() and torch.isfinite(lad).all()

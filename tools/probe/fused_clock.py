@@ -26,7 +26,12 @@ with torch.no_grad():
             y, lad = ops.rq_spline_fused_linear(x, h, wp, bp, cols, num_bins=k, tail_bound=3.0, wh_divisor=8.0)
         torch.cuda.synchronize()
 cus = torch.cuda.get_device_properties(0).multi_processor_count
-yy = y.view(-1, 32 * d)[:cus, :2].double().cpu()
+yy = y.view(-1, 32 * d)[:cus, :12].double().cpu()
+print('barrier wait per wave (cycles per tile, median over workgroups):', [round(float(v), 0) for v in (yy[:, 4:12].median(dim=0).values / (n // 32 / cus))])
+pro, entry = yy[:, 2], yy[:, 3]
+print("prologue median %.1f us max %.1f us; entry-time spread over workgroups %.1f us; loop end spread %.1f us"
+      % (pro.median() / 100, pro.max() / 100, (entry.max() - entry.min()) / 100,
+         ((entry + pro + yy[:, 1]).max() - (entry + pro + yy[:, 1]).min()) / 100))
 cyc, rt = yy[:, 0], yy[:, 1]
 ghz = (cyc / rt * 0.1)
 tiles = n // 32 / cus
