@@ -1,4 +1,4 @@
-// Hidden layers of the ResidualNet conditioner as ONE kernel on the exact-f32 matrix cores, gfx950.
+// Hidden layers of the ResidualNet conditioner as ONE kernel on the f16 matrix cores (split-f32), gfx950.
 //
 //   h = W0 x_id + b0;   for each block:  h += W2 relu(W1 relu(h) + b1) + b2          -> h [N, 64]
 //
@@ -7,177 +7,285 @@
 //  kernels + a gather per layer, each a full pass over [N, 64] in HBM; here the only HBM traffic is
 //  the x rows in and the h rows out.  The conditioner stays a PyTorch nn.Module (parameters,
 //  state_dict, CPU execution); this kernel is the device fast path for its inference forward when
-//  the shapes match: hidden = 64, <= 2 blocks, ReLU, <= 64 (even) input features.
+//  the shapes match: hidden = 64, <= 2 blocks, ReLU, <= 64 input features.
 //
-// One 256-thread workgroup owns 64 rows; wave w computes the 32x32 output tile (row block w>>1,
-// column tile w&1) of every layer with v_mfma_f32_32x32x2_f32.  All layer weights live in the wave's
-// registers as B fragments for the whole kernel (16 + 4*32 = 144 VGPRs at two blocks).  The residual
-// stream h never leaves the accumulator registers: W2's product is accumulated straight onto it.
-// Only relu(.) activations cross waves, through a double-buffered LDS tile that turns the MFMA C
-// layout (column on the lane) into the A layout (row on the lane).
+// Every product runs as three v_mfma_f32_16x16x32_f16 terms on scaled two-piece f16 splits of both
+// operands (fc_split.h): f32-GEMM accuracy at 3/16 of the f32-MFMA cycles.
+//
+// A wave owns 16 samples and pushes them through ALL layers by itself -- no LDS hand-off of
+// activations, no barrier in the loop.  The products are taken transposed (A = weight rows, B = act^T),
+// so the C layout gives lane (s = lane & 15, g = lane >> 4) 16 features of sample s; the weight rows of
+// each layer are ordered so that these are exactly the 16 k-values the lane must supply as B operand
+// of the next layer:   tile t, row 4g + r  <->  feature 32 (t >> 1) + 8 g + 4 (t & 1) + r
+//                      B fragment of k-step ks, element j  =  accumulator tile 2 ks + (j >> 2), register j & 3.
+// Between layers a lane therefore only does bias + ReLU + split on its own 16 registers; the row maximum
+// for the scaling takes two cross-lane steps.  The residual stream h lives in 16 registers per lane.
+// Weights: both f16 pieces of all layers as ready-made A fragments in LDS (72 KB at <= 32 inputs),
+// built once per workgroup from the row-major f32 weights.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "fc_split.h"
 #include "../../include/flowcon_hip.h"
 
 namespace fc {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kHidRows = 64;
 constexpr int kHid = 64;
-constexpr int kHidStride = kHid + 1;
+constexpr int kHidThreads = 512;
 
 struct HiddenArgs {
   const float* x;         // [N, D]
   float* h;               // [N, 64]
   const int32_t* id_cols; // [k0] identity columns of x feeding the conditioner
-  const float* w0;        // [2 col tiles][64 lanes][k0/2]   B fragments of initial_layer.weight [64, k0]
+  const float* w0;        // [64, k0]      initial_layer.weight, row-major
   const float* b0;        // [64]
-  const float* wb;        // [blocks][2 linears][2 col tiles][64 lanes][32]
+  const float* wb;        // [blocks][2][64][64]  linear_layers[0/1].weight of each block, row-major
   const float* bb;        // [blocks][2][64]
-  int64_t tiles;
+  int64_t blocks16;       // number of 16-row blocks
   int D;
-  int k0;                 // conditioner input features (even, <= 64)
+  int k0;                 // conditioner input features (<= 64)
 };
 
-__device__ __forceinline__ int c_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+// feature held by accumulator tile t, register r of a lane in group g
+__host__ __device__ constexpr int hid_feat(int t, int g, int r) { return 32 * (t >> 1) + 8 * g + 4 * (t & 1) + r; }
 
-template <int NB>
-__global__ __launch_bounds__(256) void resnet_hidden_kernel(HiddenArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int D = a.D, Dp = D + 1, k0 = a.k0;
-  float* xbuf = smem;                                   // [64][D+1]
-  float* abuf = xbuf + ((kHidRows * Dp + 3) & ~3);       // [2][64][65]
-  int* ids = reinterpret_cast<int*>(abuf + 2 * kHidRows * kHidStride);  // [k0]
+// LDS: [layer][k-step][tile][piece][lane] f16x8 fragments, then bias [layer][g][16], unscale [layer], ids
+template <int NB, int K0S>
+struct HiddenLds {
+  static constexpr int kLayers = 1 + 2 * NB;
+  static constexpr int kFrag0 = K0S * 4 * 2;              // fragments of the initial layer
+  static constexpr int kFragL = 2 * 4 * 2;                // fragments of a 64 x 64 layer
+  static constexpr int kFrags = kFrag0 + 2 * NB * kFragL;
+  static constexpr size_t kBytes = (size_t)kFrags * 64 * 16 + kLayers * 64 * 4 + 8 * 4 + 32 * K0S * 4 + 64;
+};
+
+template <int NB, int K0S>
+__global__ __launch_bounds__(kHidThreads, 4) void resnet_hidden_kernel(HiddenArgs a) {
+  using L = HiddenLds<NB, K0S>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char hsmem[];
+  f16x8* wfrag = reinterpret_cast<f16x8*>(hsmem);
+  float* bias = reinterpret_cast<float*>(hsmem + (size_t)L::kFrags * 64 * 16);   // [layer][g][16]
+  float* wun = bias + L::kLayers * 64;                                             // [layer] (padded to 8)
+  int* ids = reinterpret_cast<int*>(wun + 8);                                      // [32 K0S]
+  float* red = reinterpret_cast<float*>(ids + 32 * K0S);                           // [8] + pad
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rb = wave >> 1, ct = wave & 1;
-  const int arow = rb * 32 + (lane & 31);   // A-operand row of this lane
-  const int khalf = lane >> 5;               // A/B-operand k offset of this lane within a k-step
-  const int ccol = ct * 32 + (lane & 31);    // C-layout column of this lane
-  for (int i = tid; i < k0; i += 256) ids[i] = a.id_cols[i];
+  const int s16 = lane & 15, g = lane >> 4;
+  const int k0 = a.k0, D = a.D;
 
-  // ---- resident weights -------------------------------------------------------------------------
-  float w0r[32];
-  {
-    const float* p = a.w0 + ((int64_t)ct * 64 + lane) * (k0 >> 1);
+  // ---- once per workgroup: scale, split and lay out the weights -----------------------------------
+  for (int i = tid; i < 32 * K0S; i += kHidThreads) ids[i] = i < k0 ? a.id_cols[i] : -1;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) w0r[s] = s < (k0 >> 1) ? p[s] : 0.f;
-  }
-  float wr[NB > 0 ? NB : 1][2][32];
+  for (int l = 0; l < L::kLayers; ++l) {
+    const float* w = l == 0 ? a.w0 : a.wb + (size_t)(l - 1) * kHid * kHid;
+    const float* b = l == 0 ? a.b0 : a.bb + (size_t)(l - 1) * kHid;
+    const int kin = l == 0 ? k0 : kHid;
+    float m = 0.f;
+    for (int i = tid; i < kHid * kin; i += kHidThreads) m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __syncthreads();   // red is free again
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
 #pragma unroll
-    for (int l = 0; l < 2; ++l) {
-      const float4* p = reinterpret_cast<const float4*>(a.wb + ((((int64_t)b * 2 + l) * 2 + ct) * 64 + lane) * 32);
+    for (int i = 1; i < kHidThreads / 64; ++i) m = fmaxf(m, red[i]);
+    float sc, un;
+    pow2_scale(m, sc, un);
+    if (tid == 0) wun[l] = un;
+    // fragment entry e = (ks * 4 + t) * 64 + lane': W[feat(t, lane' & 15)][32 ks + 8 (lane' >> 4) + j]
+    const int nks = l == 0 ? K0S : 2;
+    const int base = l == 0 ? 0 : L::kFrag0 + (l - 1) * L::kFragL;
+    for (int e = tid; e < nks * 4 * 64; e += kHidThreads) {
+      const int ln = e & 63, t = (e >> 6) & 3, ks = e >> 8;
+      const int rho = ln & 15, f = hid_feat(t, rho >> 2, rho & 3);
+      f16x8 hi, lo;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float4 v = p[q];
-        wr[b][l][4 * q] = v.x; wr[b][l][4 * q + 1] = v.y; wr[b][l][4 * q + 2] = v.z; wr[b][l][4 * q + 3] = v.w;
+      for (int j = 0; j < 8; ++j) {
+        const int k = 32 * ks + 8 * (ln >> 4) + j;
+        const float v = k < kin ? w[(size_t)f * kin + k] * sc : 0.f;
+        _Float16 ph, pl;
+        split2(v, ph, pl);
+        hi[j] = ph;
+        lo[j] = pl;
       }
+      wfrag[(base + (ks * 4 + t) * 2 + 0) * 64 + ln] = hi;
+      wfrag[(base + (ks * 4 + t) * 2 + 1) * 64 + ln] = lo;
     }
-  const float bias0 = a.b0[ccol];
-  float biasb[NB > 0 ? NB : 1][2];
-#pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    biasb[b][0] = a.bb[(b * 2 + 0) * 64 + ccol];
-    biasb[b][1] = a.bb[(b * 2 + 1) * 64 + ccol];
+    // bias in accumulator order: [g][t * 4 + r]
+    for (int i = tid; i < 64; i += kHidThreads) {
+      const int gg = i >> 4, t = (i >> 2) & 3, r = i & 3;
+      bias[l * 64 + i] = b[hid_feat(t, gg, r)];
+    }
   }
   __syncthreads();
 
-  const int xvec = kHidRows * D / 4;  // float4 per tile; D % 4 == 0, D <= 128 -> at most 8 per thread
-  float4 xv[8];
-  auto fetch_x = [&](int64_t t) {
-    const float4* xg = reinterpret_cast<const float4*>(a.x + t * kHidRows * D);
+  // B operand of one layer from this lane's 16 activations v[t][r]: scale by the row maximum, split
+  auto make_operand = [&](const f32x4 (&v)[4], f16x8 (&bh)[2], f16x8 (&bl)[2]) {
+    float m = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) xv[k] = xg[tid + k * 256 < xvec ? tid + k * 256 : 0];
-  };
-  auto park_x = [&]() {
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = tid + k * 256;
-      if (i < xvec) {
-        const int e = i * 4, r = e / D, c = e - r * D;
-        float* dst = xbuf + r * Dp + c;
-        dst[0] = xv[k].x; dst[1] = xv[k].y; dst[2] = xv[k].z; dst[3] = xv[k].w;
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(v[t][r]));
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sc, un;
+    pow2_scale(m, sc, un);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        _Float16 ph, pl;
+        split2(v[t][r] * sc, ph, pl);
+        bh[t >> 1][4 * (t & 1) + r] = ph;
+        bl[t >> 1][4 * (t & 1) + r] = pl;
       }
+    return un;
+  };
+  // acc = (scaled W_l) (scaled act)^T : three split terms, small ones first
+  auto layer = [&](int base, int nks, const f16x8 (&bh)[2], const f16x8 (&bl)[2], f32x4 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f16x8* wf = wfrag + base * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      if (ks < nks) {
+        f16x8 wl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wl[t] = wf[((ks * 4 + t) * 2 + 1) * 64];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh[ks], acc[t], 0, 0, 0);
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      if (ks < nks) {
+        f16x8 wh[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wh[t] = wf[((ks * 4 + t) * 2 + 0) * 64];
+        // consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl[ks], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh[ks], acc[t], 0, 0, 0);
+      }
+  };
+  // Linear output of layer l: undo both scalings and add the bias in one fma (one rounding, as the GEMM's
+  // own bias epilogue)
+  auto finish = [&](int l, float un_act, const f32x4 (&acc)[4], f32x4 (&out)[4]) {
+    const float c = un_act * wun[l];
+    const f32x4* bsrc = reinterpret_cast<const f32x4*>(bias + l * 64 + g * 16);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 b = bsrc[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[t][r] = __builtin_fmaf(acc[t][r], c, b[r]);
     }
   };
-  // relu(v + bias) of a C-layout accumulator into activation buffer `buf`
-  auto put_act = [&](const f32x16& v, float bias, int buf) {
-    float* dst = abuf + buf * kHidRows * kHidStride + (rb * 32) * kHidStride + ccol;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dst[c_row(r, lane) * kHidStride] = fmaxf(v[r] + bias, 0.f);
-  };
-  // acc += W . act[buf]   (32 k-steps over the 64 activations)
-  auto gemm_act = [&](f32x16 acc, const float (&w)[32], int buf) {
-    const float* src = abuf + buf * kHidRows * kHidStride + arow * kHidStride + khalf;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(src[2 * s], w[s], acc, 0, 0, 0);
-    return acc;
-  };
 
-  const int64_t stride = gridDim.x;
-  int64_t tile = blockIdx.x;
-  if (tile < a.tiles) fetch_x(tile);
-  for (; tile < a.tiles; tile += stride) {
-    park_x();
-    __syncthreads();
-    if (tile + stride < a.tiles) fetch_x(tile + stride);  // travels during the five GEMM stages
-
-    // initial layer: h = W0 x_id (+ b0 folded in below)
-    f32x16 hacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    {
-      const float* xr = xbuf + arow * Dp;
+  // identity columns this lane reads: k = 32 ks + 8 g + j
+  int mycol[K0S][8];
 #pragma unroll
-      for (int s = 0; s < 32; ++s)
-        if (2 * s < k0) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[ids[2 * s + khalf]], w0r[s], hacc, 0, 0, 0);
-    }
-    float hbias = bias0;  // bias not yet added into hacc (kept out of the accumulator start value)
+  for (int ks = 0; ks < K0S; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mycol[ks][j] = ids[32 * ks + 8 * g + j];
+
+  const int64_t nwaves = (int64_t)gridDim.x * (kHidThreads / 64);
+  for (int64_t blk = (int64_t)blockIdx.x * (kHidThreads / 64) + wave; blk < a.blocks16; blk += nwaves) {
+    // the weight fragments are loop-invariant LDS loads: without this fence the compiler hoists all of them
+    // out of the loop and spills
+    asm volatile("" ::: "memory");
+    const float* xrow = a.x + (blk * 16 + s16) * D;
+    // x operand: 8 (16) identity features of sample s per lane, laid out like an activation tile
+    f32x4 xin[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ks = t >> 1, j = 4 * (t & 1) + r;
+        float v = 0.f;
+        if (ks < K0S) {
+          const int c = mycol[ks < K0S ? ks : 0][j];
+          v = c >= 0 ? xrow[c] : 0.f;
+        }
+        xin[t][r] = v;
+      }
+    f16x8 bh[2], bl[2];
+    f32x4 acc[4], h[4], tmid[4];
+    float un = make_operand(xin, bh, bl);
+    layer(0, K0S, bh, bl, acc);
+    finish(0, un, acc, h);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      put_act(hacc, hbias, 0);
-      __syncthreads();
-      f32x16 tacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      tacc = gemm_act(tacc, wr[b][0], 0);
-      put_act(tacc, biasb[b][0], 1);
-      __syncthreads();
-      hacc = gemm_act(hacc, wr[b][1], 1);
-      hbias += biasb[b][1];
-    }
-    // h rows out: for a fixed register the 32 lanes of a half-wave hold 32 consecutive floats of a row
-    float* hg = a.h + (tile * kHidRows + rb * 32) * kHid + ccol;
+      f32x4 act[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hg[c_row(r, lane) * kHid] = hacc[r] + hbias;
-    __syncthreads();  // xbuf / abuf are rewritten by the next tile
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) act[t][r] = fmaxf(h[t][r], 0.f);
+      un = make_operand(act, bh, bl);
+      layer(L::kFrag0 + (2 * b) * L::kFragL, 2, bh, bl, acc);
+      finish(1 + 2 * b, un, acc, tmid);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) act[t][r] = fmaxf(tmid[t][r], 0.f);
+      un = make_operand(act, bh, bl);
+      layer(L::kFrag0 + (2 * b + 1) * L::kFragL, 2, bh, bl, acc);
+      finish(2 + 2 * b, un, acc, tmid);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] += tmid[t][r];   // resnet.py:52 `inputs + temps`
+    }
+    // lane (s, g) holds features 8g..8g+7 (tiles 0, 1) and 32+8g..32+8g+7 (tiles 2, 3) of sample s
+    float4* hrow = reinterpret_cast<float4*>(a.h + (blk * 16 + s16) * kHid);
+    hrow[2 * g] = float4{h[0][0], h[0][1], h[0][2], h[0][3]};
+    hrow[2 * g + 1] = float4{h[1][0], h[1][1], h[1][2], h[1][3]};
+    hrow[8 + 2 * g] = float4{h[2][0], h[2][1], h[2][2], h[2][3]};
+    hrow[8 + 2 * g + 1] = float4{h[3][0], h[3][1], h[3][2], h[3][3]};
   }
+}
+
+template <int NB, int K0S>
+hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
+  using L = HiddenLds<NB, K0S>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S>), dim3((unsigned)grid), dim3(kHidThreads), L::kBytes, s, a);
+  return hipGetLastError();
 }
 
 }  // namespace fc
 
-extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const float* w0_frag,
-                                const float* b0, const float* wb_frag, const float* bb, int64_t n, int32_t d,
+extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const float* w0,
+                                const float* b0, const float* wb, const float* bb, int64_t n, int32_t d,
                                 int32_t in_features, int32_t hidden, int32_t num_blocks, void* stream) {
   if (n < 0 || d <= 0 || hidden != fc::kHid || num_blocks < 0 || num_blocks > 2) return hipErrorInvalidValue;
-  if (in_features <= 0 || in_features > 64 || (in_features & 1) || in_features > d) return hipErrorInvalidValue;
-  if (d % 4 != 0 || d > 128 || n % fc::kHidRows != 0) return hipErrorInvalidValue;
+  if (in_features <= 0 || in_features > 64 || in_features > d) return hipErrorInvalidValue;
+  if (n % 16 != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
-  if (!x || !h || !id_cols || !w0_frag || !b0 || (num_blocks > 0 && (!wb_frag || !bb))) return hipErrorInvalidValue;
-  if ((((uintptr_t)x | (uintptr_t)wb_frag) & 15u) != 0) return hipErrorInvalidValue;
-  fc::HiddenArgs a{x, h, id_cols, w0_frag, b0, wb_frag, bb, n / fc::kHidRows, d, in_features};
-  const size_t lds = sizeof(float) * (size_t)(((fc::kHidRows * (d + 1) + 3) & ~3) + 2 * fc::kHidRows * fc::kHidStride) +
-                     sizeof(int) * 64;
+  if (!x || !h || !id_cols || !w0 || !b0 || (num_blocks > 0 && (!wb || !bb))) return hipErrorInvalidValue;
+  if (((uintptr_t)h & 15u) != 0) return hipErrorInvalidValue;
+  fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features};
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
     cus = prop.multiProcessorCount;
-  int64_t grid = (int64_t)cus * 2;
-  if (grid > a.tiles) grid = a.tiles;
+  // two 512-thread workgroups per CU when their weight images fit (<= 32 inputs), else one
+  const bool wide = in_features > 32;
+  int64_t grid = (int64_t)cus * (wide ? 1 : 2);
+  const int64_t need = (a.blocks16 + 7) / 8;
+  if (grid > need) grid = need;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  switch (num_blocks) {
-    case 0: hipLaunchKernelGGL(fc::resnet_hidden_kernel<0>, dim3((unsigned)grid), dim3(256), lds, s, a); break;
-    case 1: hipLaunchKernelGGL(fc::resnet_hidden_kernel<1>, dim3((unsigned)grid), dim3(256), lds, s, a); break;
-    default: hipLaunchKernelGGL(fc::resnet_hidden_kernel<2>, dim3((unsigned)grid), dim3(256), lds, s, a); break;
+  switch (num_blocks * 2 + (wide ? 1 : 0)) {
+    case 0: return fc::launch_hidden<0, 1>(a, grid, s);
+    case 1: return fc::launch_hidden<0, 2>(a, grid, s);
+    case 2: return fc::launch_hidden<1, 1>(a, grid, s);
+    case 3: return fc::launch_hidden<1, 2>(a, grid, s);
+    case 4: return fc::launch_hidden<2, 1>(a, grid, s);
+    default: return fc::launch_hidden<2, 2>(a, grid, s);
   }
-  return hipGetLastError();
 }

@@ -36,6 +36,7 @@
 #include "fc_math.h"
 #include "fc_rq_op.h"
 #include "fc_rq_fused.h"
+#include "fc_split.h"
 #include "../../include/flowcon_hip.h"
 
 // tools/probe/build_fused_variants.sh only: ablation builds (1 no evaluation, 4 no MFMAs, 8 loads from L2,
@@ -54,10 +55,6 @@ namespace fc {
 #endif
 #define FC_F2 f2
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
 constexpr int kCt3 = 6;                       // 16-feature tiles per wave: 4 dims x 24 padded params
 constexpr int kHB = kH + 8;                   // f16 per h row in LDS (144 B: conflict-free b128 reads)
 constexpr int kHPiece = kR * kHB;             // f16 per piece per buffer
@@ -68,21 +65,6 @@ constexpr int kHscaleBytes = 2 * kR * 4;           // [buf][row] 2^-T of the h r
 
 size_t fused3_lds_bytes(int d) {
   return (size_t)kHbufBytes + kBiasBytes + kLpartBytes + kHscaleBytes + 2 * kR * (d + 4) * 4 + kDt * 4;
-}
-
-// Power-of-two scale that lifts m = max|x| into [2^10, 2^11), and its inverse.  Tiny or zero maxima are left
-// alone (their pieces underflow to an absolute error far below f32 resolution of any O(1) result).
-__device__ __forceinline__ void pow2_scale(float m, float& scale, float& unscale) {
-  const uint32_t e = (__float_as_uint(m) >> 23) & 255u;      // biased exponent, floor(log2 m) = e - 127
-  const bool ok = e >= 11u && e < 255u;
-  scale = ok ? __uint_as_float((264u - e) << 23) : 1.f;       // 2^(10 - (e - 127))
-  unscale = ok ? __uint_as_float((e - 10u) << 23) : 1.f;
-}
-
-// x = h + l (+ residual <= 2^-22 |x|) with f16 pieces, round-to-nearest-even; the difference is exact in f32
-__device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
-  h = (_Float16)x;
-  l = (_Float16)(x - (float)h);
 }
 
 template <bool kInv>

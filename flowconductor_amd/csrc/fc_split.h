@@ -1,0 +1,34 @@
+// f32 products on the f16 matrix cores: exact power-of-two scaling + two-piece f16 split.
+//
+// v_mfma_f32_*_f32 (f32 in, f32 out) runs at the f32 VALU rate and does not overlap with VALU work; the
+// 16-bit matrix pipe is 16x faster.  A value x, scaled by a power of two so that the maximum of its row
+// sits in [2^10, 2^11), is split as x = xh + xl + e, xh = f16(x), xl = f16(x - xh), |e| <= 2^-22 max|x|;
+// a product sum a.b is taken as  al.bh + ah.bl + ah.bh  (the al.bl term, <= 2^-22 |a||b|, is dropped),
+// three f16 MFMAs accumulating in f32.  Against float64 the error of a 64-term product is max 1.7e-7 /
+// rms 2.2e-8 of sum|a||b|; an f32 GEMM's own rounding is 4.1e-7 / 3.4e-8 (tools/probe/split_accuracy.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Power-of-two scale that lifts m = max|x| into [2^10, 2^11), and its inverse.  Tiny or zero maxima are left
+// alone (their pieces underflow to an absolute error far below f32 resolution of any O(1) result).
+__device__ __forceinline__ void pow2_scale(float m, float& scale, float& unscale) {
+  const uint32_t e = (__float_as_uint(m) >> 23) & 255u;      // biased exponent, floor(log2 m) = e - 127
+  const bool ok = e >= 11u && e < 255u;
+  scale = ok ? __uint_as_float((264u - e) << 23) : 1.f;       // 2^(10 - (e - 127))
+  unscale = ok ? __uint_as_float((e - 10u) << 23) : 1.f;
+}
+
+// x = h + l (+ residual <= 2^-22 |x|) with f16 pieces, round-to-nearest-even; the difference is exact in f32
+__device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
+  h = (_Float16)x;
+  l = (_Float16)(x - (float)h);
+}
+
+}  // namespace fc

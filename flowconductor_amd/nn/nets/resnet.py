@@ -79,14 +79,14 @@ class ResidualNet(nn.Module):
     # ---- device fast path for the hidden layers (inference) ------------------------------------------
     def hip_hidden_supported(self, features_total):
         """True when ``fc_resnet_hidden`` covers this net: hidden 64, <= 2 blocks, ReLU, no context, no
-        batch norm, dropout inactive, even input width <= 64, input rows of <= 128 features (multiple of 4)."""
+        batch norm, dropout inactive, input width <= 64."""
         def is_relu(f):
             return isinstance(f, torch.nn.ReLU) or f is F.relu or f is torch.relu
 
         if self.context_features is not None or self.hidden_features != 64 or len(self.blocks) > 2:
             return False
         in_f = self.initial_layer.in_features
-        if in_f % 2 or in_f > 64 or features_total % 4 or features_total > 128:
+        if in_f > 64 or in_f > features_total:
             return False
         for block in self.blocks:
             if block.use_batch_norm or not is_relu(block.activation):
@@ -96,7 +96,7 @@ class ResidualNet(nn.Module):
         return True
 
     def hidden_hip(self, rows, id_cols):
-        """h [N, 64] from FULL input rows + the identity column indices (N a multiple of 64)."""
+        """h [N, 64] from FULL input rows + the identity column indices (N a multiple of 16)."""
         from flowconductor_amd import ops
 
         key = tuple((p._version, p.data_ptr()) for p in self.parameters())

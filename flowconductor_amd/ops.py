@@ -237,36 +237,29 @@ def fused_linear_supported(n, d, d_t, hidden, num_bins, tails):
             and d % 4 == 0 and d <= 128 and n >= FUSED_ROWS)
 
 
-def pack_linear_frag(weight):
-    """nn.Linear weight [out, in] (out % 32 == 0, in even) -> MFMA B fragments [out/32, 64, in/2]:
-    frag[t][l][s] = W[t*32 + (l & 31)][2*s + (l >> 5)]."""
-    out_f, in_f = weight.shape
-    w = weight.detach().reshape(out_f // 32, 32, in_f // 2, 2)       # [tile, col, s, kk]
-    return w.permute(0, 3, 1, 2).reshape(out_f // 32, 64, in_f // 2).contiguous()  # lane = kk*32 + col
-
-
-HIDDEN_ROWS = 64
+HIDDEN_ROWS = 16
 
 
 def pack_resnet_hidden(net):
-    """Pack the hidden layers of a ResidualNet (hidden 64, <= 2 blocks) for ``fc_resnet_hidden``."""
-    w0 = pack_linear_frag(net.initial_layer.weight)
+    """Weights of the hidden layers of a ResidualNet (hidden 64, <= 2 blocks) as ``fc_resnet_hidden`` takes
+    them: the nn.Linear tensors row-major, the block layers stacked [blocks, 2, 64, 64] / [blocks, 2, 64]."""
+    w0 = net.initial_layer.weight.detach().contiguous()
     b0 = net.initial_layer.bias.detach().contiguous()
-    frags, biases = [], []
+    ws, bs = [], []
     for block in net.blocks:
         for lin in block.linear_layers:
-            frags.append(pack_linear_frag(lin.weight))
-            biases.append(lin.bias.detach())
-    if frags:
-        wb = torch.stack(frags).contiguous()
-        bb = torch.stack(biases).contiguous()
+            ws.append(lin.weight.detach())
+            bs.append(lin.bias.detach())
+    if ws:
+        wb = torch.stack(ws).contiguous()
+        bb = torch.stack(bs).contiguous()
     else:
         wb = bb = None
     return w0, b0, wb, bb
 
 
 def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks):
-    """Hidden layers of the conditioner on the rows of ``inputs`` (multiple of 64 rows) -> h [N, 64]."""
+    """Hidden layers of the conditioner on the rows of ``inputs`` (multiple of 16 rows) -> h [N, 64]."""
     lib = _hip.load()
     x = _prep_2d(inputs)
     _hip.require_no_grad(inputs)

@@ -274,15 +274,15 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         self._check(inputs)
         net = self.transform_net
         n = inputs.shape[0]
-        body64 = n - n % ops.HIDDEN_ROWS
+        body16 = n - n % ops.HIDDEN_ROWS
         identity_split = logabsdet_identity = None
-        if (self.unconditional_transform is None and context is None and body64 > 0
+        if (self.unconditional_transform is None and context is None and body16 > 0
                 and os.environ.get("FC_FUSED_HIDDEN", "1") != "0" and net.hip_hidden_supported(inputs.shape[1])):
-            # hidden layers of the conditioner in one MFMA kernel straight from the full input rows: the
+            # hidden layers of the conditioner in one matrix-core kernel straight from the full input rows: the
             # identity half is never gathered into a separate tensor
-            hidden = net.hidden_hip(inputs[:body64], self._id_cols(inputs.device))
-            if body64 < n:
-                hidden = torch.cat((hidden, net.hidden(inputs[body64:, self.identity_features], context)))
+            hidden = net.hidden_hip(inputs[:body16], self._id_cols(inputs.device))
+            if body16 < n:
+                hidden = torch.cat((hidden, net.hidden(inputs[body16:, self.identity_features], context)))
         else:
             identity_split = inputs[:, self.identity_features]
             if inverse and self.unconditional_transform is not None:

@@ -78,14 +78,14 @@ int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const fl
 
 /* Hidden layers of the ResidualNet conditioner (flowcon/nn/nets/resnet.py:39-53, 93-99) as one kernel:
  *   h = W0 x[:, id_cols] + b0;  per block: h += W2 relu(W1 relu(h) + b1) + b2          -> h [n, 64]
- * exact-f32 MFMA, weights resident in registers, residual stream resident in the accumulators.
+ * Products on the f16 matrix cores as three-term scaled two-piece splits (f32-GEMM accuracy); a wave carries
+ * 16 samples through all layers in registers; the only HBM traffic is x in and h out.
  * Specialised: hidden == 64, num_blocks <= 2, ReLU, no context / batch norm / active dropout,
- * in_features even and <= 64, d % 4 == 0, d <= 128, n % 64 == 0.
- * Weight fragments: frag[t][l][s] = W[t*32 + (l & 31)][2*s + (l >> 5)] for each Linear weight W [64, in]
- * (t: 32-column tile, l: lane, s: k-step); w0_frag [2][64][in/2]; wb_frag [blocks][2][2][64][32];
- * bb [blocks][2][64]. */
-int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const float* w0_frag,
-                     const float* b0, const float* wb_frag, const float* bb, int64_t n, int32_t d,
+ * in_features <= 64, n % 16 == 0, h 16-byte aligned.
+ * Weights are the nn.Linear tensors as they are, row-major f32: w0 [64, in_features]; wb [blocks][2][64][64]
+ * (linear_layers[0], linear_layers[1] of each block); b0 [64]; bb [blocks][2][64]. */
+int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const float* w0,
+                     const float* b0, const float* wb, const float* bb, int64_t n, int32_t d,
                      int32_t in_features, int32_t hidden, int32_t num_blocks, void* stream);
 
 /* ---- linear / quadratic / cubic splines ------------------------------------------------------ */

@@ -46,7 +46,7 @@ def test_fused_matches_unfused_and_oracle(n, inverse, device, monkeypatch):
 
 
 @pytest.mark.parametrize("in_f,blocks,d,n", [(32, 2, 64, 64), (32, 2, 64, 6400), (16, 1, 32, 128), (6, 0, 12, 64),
-                                            (64, 2, 128, 192)])
+                                            (64, 2, 128, 192), (7, 1, 15, 48), (33, 2, 70, 16), (32, 2, 64, 100000)])
 def test_resnet_hidden_kernel_matches_torch(in_f, blocks, d, n, device):
     """fc_resnet_hidden vs the same nn.Module evaluated by PyTorch on the CPU."""
     from flowconductor_amd.nn import nets
@@ -64,6 +64,30 @@ def test_resnet_hidden_kernel_matches_torch(in_f, blocks, d, n, device):
         got = net.to(device).hidden_hip(x.to(device), ids.to(device))
     assert got.shape == (n, 64)
     assert maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("xscale", [1e-6, 1.0, 3e5])
+def test_resnet_hidden_kernel_input_scales(xscale, device):
+    """Rows far outside the f16 range: the per-row power-of-two scaling keeps the split products at f32-GEMM
+    accuracy.  Reference: the same layers in float64."""
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(3)
+    net = nets.ResidualNet(32, 8, hidden_features=64, num_blocks=2).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+        net.initial_layer.weight.div_(xscale)   # activations stay O(1) behind inputs of any magnitude
+    ids = torch.arange(0, 64, 2)
+    x = torch.randn(256, 64) * xscale
+    x[::3] *= 1e-3   # rows of very different magnitude side by side
+    with torch.no_grad():
+        ref = net.double().hidden(x.double()[:, ids]).float()
+        net = net.float()
+        ref32 = net.hidden(x[:, ids])
+        got = net.to(device).hidden_hip(x.to(device), ids.to(device))
+    floor = maxdiff(ref32, ref)   # what f32 GEMMs lose on this input
+    assert maxdiff(got, ref) <= 1e-5 * max(1.0, float(ref.abs().max())) + 4 * floor
 
 
 def test_fused_hidden_path_in_coupling(device, monkeypatch):

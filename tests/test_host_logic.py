@@ -153,11 +153,13 @@ def test_pack_final_layer_layout():
         assert float(bpad[prow]) == (0.0 if i == 23 else float(b[j * 23 + i]))
 
 
-def test_pack_linear_frag_layout():
+def test_pack_resnet_hidden_stacks_linear_weights():
     from flowconductor_amd import ops
+    from flowconductor_amd.nn import nets
 
-    w = torch.arange(64 * 32, dtype=torch.float32).reshape(64, 32)
-    frag = ops.pack_linear_frag(w)
-    assert frag.shape == (2, 64, 16)
-    for (t_, l_, s_) in [(0, 0, 0), (1, 37, 9), (1, 63, 15)]:
-        assert float(frag[t_, l_, s_]) == float(w[t_ * 32 + (l_ & 31), 2 * s_ + (l_ >> 5)])
+    net = nets.ResidualNet(32, 8, hidden_features=64, num_blocks=2)
+    w0, b0, wb, bb = ops.pack_resnet_hidden(net)
+    assert w0.shape == (64, 32) and b0.shape == (64,) and wb.shape == (4, 64, 64) and bb.shape == (4, 64)
+    assert torch.equal(wb[1], net.blocks[0].linear_layers[1].weight) and torch.equal(bb[2], net.blocks[1].linear_layers[0].bias)
+    w0, b0, wb, bb = ops.pack_resnet_hidden(nets.ResidualNet(6, 8, hidden_features=64, num_blocks=0))
+    assert wb is None and bb is None and w0.shape == (64, 6)
