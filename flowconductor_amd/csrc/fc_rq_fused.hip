@@ -247,6 +247,7 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
   q.beta = cfg->softplus_beta;
   q.tail_const = cfg->tail_constant;
   op.inv_div = 1.f / q.wh_div;
+  op.inv_beta = 1.f / q.beta;
 
   const char* dbg = getenv("FC_FUSED_DEBUG");
   fc::FusedArgs a{x, y, h, w_pad, bias_pad, cols, logabsdet, err_flag, n / fc::kR, d, dbg ? atoi(dbg) : 0};

@@ -59,20 +59,18 @@ constexpr int kCt3 = 6;                       // 16-feature tiles per wave: 4 di
 constexpr int kHB = kH + 8;                   // f16 per h row in LDS (144 B: conflict-free b128 reads)
 constexpr int kHPiece = kR * kHB;             // f16 per piece per buffer
 constexpr int kHbufBytes = 2 * 2 * kHPiece * 2;    // [buf][piece][row][kHB] f16
-constexpr int kBiasBytes = 8 * kCt3 * 4 * 16;      // [wave][tile][g] float4
 constexpr int kLpartBytes = 2 * 8 * kR * 4;        // [buf][wave][row]
 constexpr int kHscaleBytes = 2 * kR * 4;           // [buf][row] 2^-T of the h row
 
 size_t fused3_lds_bytes(int d) {
-  return (size_t)kHbufBytes + kBiasBytes + kLpartBytes + kHscaleBytes + 2 * kR * (d + 4) * 4 + kDt * 4;
+  return (size_t)kHbufBytes + kLpartBytes + kHscaleBytes + 2 * kR * (d + 4) * 4 + kDt * 4;
 }
 
 template <bool kInv>
 __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   _Float16* hbuf = reinterpret_cast<_Float16*>(smem3);                               // [2][2][kR][kHB]
-  f32x4* bbuf = reinterpret_cast<f32x4*>(smem3 + kHbufBytes);                         // [8][6][4]
-  float* lpart = reinterpret_cast<float*>(smem3 + kHbufBytes + kBiasBytes);           // [2][8][kR]
+  float* lpart = reinterpret_cast<float*>(smem3 + kHbufBytes);           // [2][8][kR]
   float* hscale = lpart + 2 * 8 * kR;                                                 // [2][kR]
   float* xbuf = hscale + 2 * kR;                                                      // [2][kR][D + 4]
   const int D = a.D, XS = D + 4;
@@ -128,18 +126,16 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
           wl[t][ks][j] = pl;
         }
   }
-  // bias of lane (s, g), register r of tile t: feature (dim 4w + g, param 4t + r).  The width / height
-  // logits are divided by sqrt(hidden_features) (rational_quadratic.py:26-29 callers, coupling.py:565-566);
-  // the division is folded into the fma that also undoes the scaling, so their bias is stored pre-divided.
-  if (s16 == 0) {
+  // bias of lane (s, g), register r of tile t: feature (dim 4w + g, param 4t + r), resident (24 registers).
+  // The width / height logits are divided by sqrt(hidden_features) (coupling.py:565-566); the division is
+  // folded into the fma that also undoes the scaling, so their bias is kept pre-divided.
+  f32x4 bw[kCt3];
 #pragma unroll
-    for (int t = 0; t < kCt3; ++t) {
-      const float* bsrc = a.bias + (4 * wave + g) * kPP + 4 * t;
-      const float m = t < 4 ? inv_div : 1.f;   // params 0..15 are widths and heights
-      bbuf[(wave * kCt3 + t) * 4 + g] = f32x4{bsrc[0] * m, bsrc[1] * m, bsrc[2] * m, bsrc[3] * m};
-    }
+  for (int t = 0; t < kCt3; ++t) {
+    const float* bsrc = a.bias + (4 * wave + g) * kPP + 4 * t;
+    const float m = t < 4 ? inv_div : 1.f;   // params 0..15 are widths and heights
+    bw[t] = f32x4{bsrc[0] * m, bsrc[1] * m, bsrc[2] * m, bsrc[3] * m};
   }
-  const f32x4* bb_w = bbuf + wave * kCt3 * 4 + g;           // + t * 4
 
   uint32_t err = 0;
   const int xvec = kR * D / 4;
@@ -217,9 +213,6 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     const float x = *xr;
     const float c_d = hscale[xb * kR + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
     const float c_wh = c_d * inv_div;
-    f32x4 bw[kCt3];
-#pragma unroll
-    for (int t = 0; t < kCt3; ++t) bw[t] = bb_w[t * 4];
     // h^T fragments are read one group of 6 MFMAs ahead of their use
     f16x8 bcur, bnext = hfrag(hb, pblk, term_h(0), 0);
     auto hook = [&](auto N) {
@@ -237,6 +230,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
       __builtin_amdgcn_sched_barrier(FC_HOOK_MASK);
     };
     const RQParams& q = op.q;
+    const float inv_beta = op.inv_beta;   // softplus(x, beta) = log1p(exp(beta x)) * (1 / beta): exact at beta = 1
     float y, lad;
     __builtin_amdgcn_s_setprio(3);
     __builtin_amdgcn_sched_barrier(0);

@@ -165,6 +165,7 @@ struct RQOp {
   static constexpr bool kHasPrepare = false;
   __device__ void prepare(float*, int, int) const {}
   RQParams q;
+  float inv_beta; // 1 / softplus beta (the fused kernel multiplies instead of dividing; exact at the default 1)
   float inv_div;  // unnormalised widths/heights are multiplied by 1/wh_div (exact for the usual
                   // power-of-two sqrt(hidden_features); otherwise within 1 ulp of the reference's division)
 

@@ -97,6 +97,7 @@ static hipError_t launch_rq(const RQParams& q, TileArgs a, hipStream_t stream) {
   RQOp<KS> op;
   op.q = q;
   op.inv_div = 1.f / q.wh_div;
+  op.inv_beta = 1.f / q.beta;
   const bool pow2 = (a.d_t & (a.d_t - 1)) == 0 && a.d_t <= 64;
   const char* force = getenv("FC_RQ_PATH");  // "tile" / "wave": pin one structure (A/B measurements)
   if constexpr (KS > 0 && KS <= 10)

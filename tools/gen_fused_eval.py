@@ -32,8 +32,9 @@ for j in range(K - 1):
     add("const float ud%d = FC_UD(%d);" % (j, j), 1)
 add("const FC_F2 m = {mx, my};\nFC_F2 sum = {0.f, 0.f};", 0)
 for i in range(K):
-    add("t%d = t%d - m;" % (i, i), 1)
-    add("t%d = FC_F2{exp_softmax(t%d.x), exp_softmax(t%d.y)};" % (i, i, i), 5)
+    # exp_softmax(d) = exp2(d * log2e): the multiply as one packed op for both axes
+    add("t%d = (t%d - m) * FC_F2{1.4426950408889634f, 1.4426950408889634f};" % (i, i), 2)
+    add("t%d = FC_F2{__builtin_amdgcn_exp2f(t%d.x), __builtin_amdgcn_exp2f(t%d.y)};" % (i, i, i), 4)
     add("sum += t%d;" % i, 1)
 add("const float rsx = div_lean(1.f, sum.x);", 5)
 add("const float rsy = div_lean(1.f, sum.y);\nconst FC_F2 rs = {rsx, rsy};", 5)
@@ -53,8 +54,11 @@ for i in range(K):
     hi_d = "q.tail_const" if i == K - 1 else "ud%d" % i
     add("u0 = take%d ? %s : u0;\nu1 = take%d ? %s : u1;" % (i, lo_d, i, hi_d), 2)
 add("const float xk = sel_lo.x, yk = sel_lo.y;\nconst float wk = sel_hi.x - sel_lo.x, hk = sel_hi.y - sel_lo.y;", 2)
-add("const float delta = div_lean(hk, wk);", 5)
-add("float theta;\nif constexpr (!kInv) theta = div_lean(xc - xk, wk);", 3)
+# one v_rcp of the bin width serves both divisions (div_lean: q = a * r, then one residual correction)
+add("const float rwk = __builtin_amdgcn_rcpf(wk);\nconst float dq = hk * rwk;\n"
+    "const float delta = __builtin_fmaf(__builtin_fmaf(-wk, dq, hk), rwk, dq);", 5)
+add("float theta;\nif constexpr (!kInv) {\n  const float tq = (xc - xk) * rwk;\n"
+    "  theta = __builtin_fmaf(__builtin_fmaf(-wk, tq, xc - xk), rwk, tq);\n}", 4)
 # two softplus evaluations (softplus_lean_sel of fc_math.h), written out so hooks can sit inside them
 for n in (0, 1):
     add("const float xb%d = u%d * q.beta;\nconst float xm%d = fminf(xb%d, 20.f);\nconst float e%d_hi = xm%d * 1.4426950216293335f;"
@@ -67,8 +71,7 @@ for n in (0, 1):
     add("const float lg%d = log_lean(up%d);" % (n, n), 5)
     add("const float dv%d = div_lean(ex%d, dd%d == 0.f ? 1.f : dd%d);" % (n, n, n, n), 6)
     add("const float l1p%d = dd%d == 0.f ? ex%d : lg%d * dv%d;" % (n, n, n, n, n), 2)
-    add("const float sp%d = q.beta == 1.f ? l1p%d : div_lean(l1p%d, q.beta);\nconst float d%d = q.min_d + (xb%d > 20.f ? u%d : sp%d);"
-        % (n, n, n, n, n, n, n), 6)
+    add("const float d%d = q.min_d + (xb%d > 20.f ? u%d : l1p%d * inv_beta);" % (n, n, n, n), 3)
 add("const float dsum = d0 + d1 - 2.f * delta;", 3)
 add("""if constexpr (kInv) {
   const float rr = xc - yk;
@@ -97,7 +100,7 @@ add("y = inside ? ys : x;\nlad = inside ? (kInv ? -lval : lval) : 0.f;", 3)
 total = sum(w for _, w in chunks)
 out = ["// GENERATED by tools/gen_fused_eval.py -- do not edit by hand.",
        "// Straight-line RQ-spline evaluation (K = %d, linear tails) of one element with %d MFMA hook points." % (K, HOOKS),
-       "// Expects in scope: FC_WH(i) / FC_UD(j) (logits of the element), FC_F2, FC_CUM_T, x, q (RQParams), err,",
+       "// Expects in scope: FC_WH(i) / FC_UD(j) (logits of the element), FC_F2, FC_CUM_T, x, q (RQParams), inv_beta, err,",
        "// kInv (constexpr bool), outputs y / lad, and FC_HOOK(n)."]
 acc = 0.0
 hook = 0
