@@ -8,10 +8,11 @@ on synthetic Gaussian batches, one process per GPU, batch-sharded (BASELINE.json
 One "step" = one ``Flow.log_prob`` pass of every rank's 2^20-sample shard through all 32
 layers (conditioners on PyTorch-ROCm, bijectors in the HIP kernels) + the RCCL all-reduce of
 {sum log_prob, count}.  Inputs are resident in HBM before the timed region.  Prints ONE JSON
-line on rank 0 (contract in the task statement), carrying ``roofline`` (the HBM-bound stand-alone
-spline kernel fc_rq_spline), ``roofline_fused`` / ``roofline_hidden`` (the MFMA-bound kernels that
-carry the timed flow since the conditioner fusion) and ``cpu_baseline`` (the CPU oracle timed on the
-host cores, rank 0, N=1).
+line on rank 0 (contract in the task statement), carrying ``roofline`` (the dominant kernel of the timed
+region: the fused final-Linear + spline kernel, against its algorithmic HBM bytes), ``roofline_hidden``
+(the conditioner's hidden-layer kernel), ``roofline_unfused_rq_spline`` (the HBM-bound stand-alone
+bijector kernel, timed in an extra pass) and ``cpu_baseline`` (the CPU oracle timed on the host cores,
+rank 0, N=1).
 """
 import argparse
 import json
@@ -30,7 +31,7 @@ from flowconductor_amd.nn import nets  # noqa: E402
 
 FEATURES, LAYERS, BINS, HIDDEN, BLOCKS, TAIL_BOUND = 64, 32, 8, 64, 2, 3.0
 HBM_PEAK_GBS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA peak, same guide (v_mfma_f32_32x32x2_f32)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16 / bf16 MFMA peak, same guide (2:1-sparsity figures excluded)
 
 
 def build_flow():
@@ -46,18 +47,20 @@ def build_flow():
     return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([FEATURES])).eval()
 
 
-def measured_traffic_per_launch(rows_per_launch):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (tools/profile_bench.sh: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs).  PMC counters
-    cannot be read from inside this process, so the number comes from profiles/; None if absent or if
-    this run's launch shape differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_rq_spline_hbm_traffic.json")
+TRAFFIC_PROFILE = "profiles/r01c_hbm_traffic.json"
+
+
+def measured_traffic_per_launch(entry, rows_per_launch):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
+    (tools/profile_bench.sh: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs).  PMC counters cannot be
+    read from inside this process, so the number comes from profiles/; None if absent or if this run's
+    launch shape differs from the profiled one."""
     try:
-        rec = json.load(open(path))
+        rec = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
         if rows_per_launch != (1 << 20):
             return None
-        return rec.get("traffic_bytes_per_launch")
-    except (OSError, ValueError):
+        return rec[entry]["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
         return None
 
 
@@ -232,35 +235,56 @@ def main():
                        "samples_per_gpu": n_local, "global_batch": n_local * world,
                        "chunk_rows": rows_per_launch, "parallelism": "batch-sharded dp%d" % world,
                        "mean_log_prob": mean_lp},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_per_launch(rows_per_launch),
-                         "traffic_source": "profiles/r01_rq_spline_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                                           "WRITE_SIZE passes of this command; FETCH_SIZE x2 gfx950 correction)",
-                         "kernel": "fc_rq_spline -> fc::rq_wave_kernel<8, true>", "launches_timed": launches,
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "measured_in": "extra untimed pass with FC_FUSED=0" if fused_path else "timed region"},
         }
-        if fused_path:
-            # dominant kernel of the timed region: final conditioner Linear (64 -> 736) fused with the spline.
-            # Algorithmic flops = the GEMM's 2*64*736 per sample (the spline arithmetic rides on the VALU).
+        src = TRAFFIC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 gfx950 correction)"
+        unfused = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_per_launch("fc_rq_spline", rows_per_launch),
+                   "traffic_source": src,
+                   "kernel": "fc_rq_spline -> fc::rq_wave_kernel<8, true>", "launches_timed": launches,
+                   "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                   "measured_in": "extra untimed pass with FC_FUSED=0" if fused_path else "timed region"}
+        if not fused_path:
+            out["roofline"] = unfused
+        else:
+            # Dominant kernel of the timed region: the conditioner's final Linear (64 -> 736) fused with the
+            # spline.  Its algorithmic HBM bytes per sample: h in (4*64) + x in (4*D) + y out (4*D) + logabsdet (4);
+            # the [N, 736] parameter tensor never exists in memory.  The kernel is bound by VALU issue (the
+            # spline arithmetic, ~335 VALU instructions per element), not by HBM or the matrix pipe: DESIGN.md 4.
             f_avg = sum(fused_ms) / len(fused_ms)
+            f_bytes = (4 * HIDDEN + 8 * FEATURES + 4) * rows_per_launch
+            f_gbs = f_bytes / (f_avg * 1e-3) / 1e9
             flops = 2.0 * HIDDEN * (FEATURES // 2) * (3 * BINS - 1) * rows_per_launch
-            tf = flops / (f_avg * 1e-3) / 1e12
-            out["roofline_fused"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                     "frac": tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                                     "kernel": "fc_rq_spline_fused_linear -> fc::rq_fused_linear_kernel",
-                                     "launches_timed": len(fused_ms), "avg_launch_ms": f_avg,
-                                     "algorithmic_flops_per_launch": flops,
-                                     "share_of_step": sum(fused_ms) / (1e3 * elapsed)}
+            out["roofline"] = {"bound": "hbm", "achieved": f_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": f_gbs / HBM_PEAK_GBS,
+                               "traffic": measured_traffic_per_launch("fc_rq_spline_fused_linear", rows_per_launch),
+                               "traffic_source": src,
+                               "kernel": "fc_rq_spline_fused_linear -> fc::rq_fused_linear_kernel3<false>",
+                               "launches_timed": len(fused_ms), "avg_launch_ms": f_avg,
+                               "algorithmic_bytes_per_launch": f_bytes,
+                               "share_of_step": sum(fused_ms) / (1e3 * elapsed),
+                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01c_fused_sq_counters.txt",
+                               "matrix_pipe": {"algorithmic_tflops": flops / (f_avg * 1e-3) / 1e12,
+                                               "executed_tflops": 3.0 * (24.0 / 23.0) * flops / (f_avg * 1e-3) / 1e12,
+                                               "peak_f16_dense_tflops": MFMA_F16_PEAK_TFLOPS,
+                                               "note": "f32 product as 3 split-f16 MFMA terms, 23 -> 24 padded rows per dim"}}
             if hidden_ms:
                 h_avg = sum(hidden_ms) / len(hidden_ms)
+                h_bytes = (4 * FEATURES + 4 * HIDDEN) * rows_per_launch
                 hflops = 2.0 * (HIDDEN * (FEATURES // 2) + 2 * BLOCKS * HIDDEN * HIDDEN) * rows_per_launch
-                out["roofline_hidden"] = {"bound": "mfma", "achieved": hflops / (h_avg * 1e-3) / 1e12,
-                                          "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                          "frac": hflops / (h_avg * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                                          "kernel": "fc_resnet_hidden -> fc::resnet_hidden_kernel<2>",
+                h_gbs = h_bytes / (h_avg * 1e-3) / 1e9
+                out["roofline_hidden"] = {"bound": "hbm", "achieved": h_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": h_gbs / HBM_PEAK_GBS,
+                                          "traffic": measured_traffic_per_launch("fc_resnet_hidden", rows_per_launch),
+                                          "kernel": "fc_resnet_hidden -> fc::resnet_hidden_kernel<2, 1>",
                                           "launches_timed": len(hidden_ms), "avg_launch_ms": h_avg,
-                                          "share_of_step": sum(hidden_ms) / (1e3 * elapsed)}
+                                          "algorithmic_bytes_per_launch": h_bytes,
+                                          "share_of_step": sum(hidden_ms) / (1e3 * elapsed),
+                                          "matrix_pipe": {"algorithmic_tflops": hflops / (h_avg * 1e-3) / 1e12,
+                                                          "executed_tflops": 3.0 * hflops / (h_avg * 1e-3) / 1e12,
+                                                          "peak_f16_dense_tflops": MFMA_F16_PEAK_TFLOPS}}
+            # the stand-alone bijector kernel (one thread per (sample, dim), parameters read from HBM: the
+            # north-star's own definition of the hot kernel), which the fused flow no longer launches
+            out["roofline_unfused_rq_spline"] = unfused
         if world == 1:
             flow_cpu = build_flow()
             out["parity"] = parity(flow, flow_cpu, device)

@@ -176,10 +176,11 @@ struct RQOp {
     eval_core<false>(prow + j * P, x, y, lad, err);
   }
 
-  // Branch-free evaluation for linear tails with the parameters in LDS (used by the fused kernel's
-  // consumers): no early return for out-of-interval inputs (evaluated on a clamped copy, selected away at
-  // the end), select-form softplus, direction fixed at compile time.  One straight-line block per element,
-  // so two elements per thread interleave and hide each other's transcendental / LDS latencies.
+  // Branch-free evaluation for linear tails: no early return for out-of-interval inputs (evaluated on a
+  // clamped copy, selected away at the end), select-form softplus, direction fixed at compile time.  This is
+  // the readable form of what the fused kernel executes: fc_rq_fused3_eval.inc is this function written out
+  // statement by statement (tools/gen_fused_eval.py) with MFMA hook points in between and the parameters
+  // taken from accumulator registers instead of `p`.
   template <bool kInverse>
   __device__ __forceinline__ void eval_tails_straight(const float* __restrict__ p, float x, float& y, float& lad,
                                                       uint32_t& err) const {

@@ -1,5 +1,5 @@
 """Condense rocprofv3 output of tools/profile_bench.sh into profiles/<tag>_*: the kernel-stats table and
-the per-launch HBM traffic of the dominant kernel (FETCH_SIZE doubled: on gfx950 it reports half of a
+the per-launch HBM traffic of the hot kernels (FETCH_SIZE doubled: on gfx950 it reports half of a
 wide coalesced read stream, MI355X_MICROARCH.md section HBM; WRITE_SIZE as is; both in KiB)."""
 import csv
 import glob
@@ -19,14 +19,25 @@ for name in ("bench_trace.json",):
     if os.path.exists(src):
         shutil.copy(src, os.path.join(prof, "%s_bench_n1_under_rocprof.json" % tag))
 
-DOMINANT = ("rq_wave_kernel", "tile_kernel_pf", "tile_kernel")
+# C-ABI entry -> substring of the kernel symbol it launches in bench.py's flow
+KERNELS = {
+    "fc_rq_spline_fused_linear": "rq_fused_linear_kernel3",
+    "fc_resnet_hidden": "resnet_hidden_kernel",
+    "fc_rq_spline": "rq_wave_kernel",          # only in the extra FC_FUSED=0 pass
+}
+EXPECTED = {
+    "fc_rq_spline_fused_linear": "reads h [2^20,64] + x [2^20,64] = 536.9 MB; writes y [2^20,64] + logabsdet = 272.6 MB; "
+                                 "the [2^20,736] parameter tensor (3.09 GB written + read back when unfused) never reaches HBM",
+    "fc_resnet_hidden": "reads x [2^20,64] = 268.4 MB; writes h [2^20,64] = 268.4 MB",
+    "fc_rq_spline": "reads params [2^20,736] + x = 3.36 GB; writes y + logabsdet = 272.6 MB",
+}
 
 
-def per_launch(counter):
+def per_launch(counter, key):
     vals = []
     for f in glob.glob(os.path.join(out, "pmc_" + counter, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in DOMINANT) and "RQOp" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and key in r["Kernel_Name"]:
                 vals.append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     if not vals:
         return None, 0
@@ -35,15 +46,18 @@ def per_launch(counter):
     return sum(sel) / len(sel), len(sel)
 
 
-fetch_kib, nf = per_launch("FETCH_SIZE")
-write_kib, nw = per_launch("WRITE_SIZE")
-summary = {"tag": tag, "kernel": "fc_rq_spline (dominant bijector kernel)",
-           "FETCH_SIZE_KiB_per_launch_raw": fetch_kib, "WRITE_SIZE_KiB_per_launch_raw": write_kib,
-           "launches_averaged": [nf, nw]}
-if fetch_kib is not None and write_kib is not None:
-    summary["hbm_read_bytes_per_launch"] = 2.0 * fetch_kib * 1024.0
-    summary["hbm_write_bytes_per_launch"] = write_kib * 1024.0
-    summary["traffic_bytes_per_launch"] = summary["hbm_read_bytes_per_launch"] + summary["hbm_write_bytes_per_launch"]
-    summary["correction"] = "FETCH_SIZE x2 (gfx950 wide-stream under-count), WRITE_SIZE x1; separate --pmc passes"
-json.dump(summary, open(os.path.join(prof, "%s_rq_spline_hbm_traffic.json" % tag), "w"), indent=1)
+summary = {"tag": tag,
+           "source": "tools/profile_bench.sh %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of "
+                     "bench.py --steps 3 --warmup 1, per-launch means over the full-batch (2^20-row) launches; "
+                     "FETCH_SIZE x2 (gfx950 wide-stream correction), KiB -> bytes" % tag}
+for entry, key in KERNELS.items():
+    fetch_kib, nf = per_launch("FETCH_SIZE", key)
+    write_kib, nw = per_launch("WRITE_SIZE", key)
+    if fetch_kib is None or write_kib is None:
+        continue
+    rd, wr = 2.0 * fetch_kib * 1024.0, write_kib * 1024.0
+    summary[entry] = {"kernel": key, "FETCH_SIZE_KiB_raw": fetch_kib, "WRITE_SIZE_KiB_raw": write_kib,
+                      "launches_averaged": [nf, nw], "hbm_read_bytes": rd, "hbm_write_bytes": wr,
+                      "traffic_bytes_per_launch": rd + wr, "expected": EXPECTED[entry]}
+json.dump(summary, open(os.path.join(prof, "%s_hbm_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(summary))
