@@ -258,8 +258,15 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #if FC_ABL & 16   // ablation: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, stamped around the loop
   const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-#if FC_ABL & 16   // cycles each wave spends waiting at the two barriers of the loop
-  uint64_t barrier_wait = 0;
+#if FC_ABL & 16   // cycles each wave spends in the phases of the loop / waiting at its two barriers
+  uint64_t barrier_wait = 0, phase_cyc[6] = {0, 0, 0, 0, 0, 0}, phase_t = __builtin_amdgcn_s_memtime();
+  // phase k ends at FC_PHASE(k): 0 write-out + loop overhead, 1 step A, 2 park, 3 barrier 1, 4 step B, 5 barrier 2
+#define FC_PHASE(k)                                              \
+  do {                                                           \
+    const uint64_t now = __builtin_amdgcn_s_memtime();           \
+    phase_cyc[k] += now - phase_t;                               \
+    phase_t = now;                                               \
+  } while (0)
 #define FC_TIMED_BARRIER()                                        \
   do {                                                            \
     const uint64_t b0 = __builtin_amdgcn_s_memtime();             \
@@ -268,6 +275,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   } while (0)
 #else
 #define FC_TIMED_BARRIER() __syncthreads()
+#define FC_PHASE(k)
 #endif
   f32x4 acc0[kCt3], acc1[kCt3];
 #pragma unroll
@@ -279,14 +287,20 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   int tb = 0;
   for (int64_t tile = tile0; tile < a.tiles; tile += stride) {
     const bool has_next = tile + stride < a.tiles;
+    FC_PHASE(0);
     if (has_next) fetch(tile + stride);
     step(acc0, tb, 0, acc1, tb, 1);        // A: evaluate block 0 of `tile`, produce its block 1
+    FC_PHASE(1);
     if (has_next) park(tb ^ 1);
+    FC_PHASE(2);
     FC_TIMED_BARRIER();
+    FC_PHASE(3);
     // B: evaluate block 1, produce block 0 of the next tile (unconditional: on the last tile the MFMAs work
     // on stale h rows into accumulators nobody reads -- a branch would split the interleaved block).
     step(acc1, tb, 1, acc0, tb ^ 1, 0);
+    FC_PHASE(4);
     FC_TIMED_BARRIER();
+    FC_PHASE(5);
     // Every thread writes out exactly the float4 slots it parks, and lpart is double-buffered, so no third
     // barrier is needed before the next iteration.
     {
@@ -310,12 +324,17 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     a.y[tile0 * kR * D + 2] = (float)(stamp_r0 - stamp_r_entry);                 // prologue, 10 ns ticks
     a.y[tile0 * kR * D + 3] = (float)(stamp_r_entry & 0xffffff);                  // entry time (for launch skew)
   }
-  if (lane == 0) a.y[tile0 * kR * D + 4 + wave] = (float)barrier_wait;
+  if (lane == 0) {
+    a.y[tile0 * kR * D + 4 + wave] = (float)barrier_wait;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.y[tile0 * kR * D + 12 + wave * 6 + k] = (float)phase_cyc[k];
+  }
 #endif
   if (err && a.err) atomicOr(a.err, err);
 }
 #undef FC_ALL36
 #undef FC_TIMED_BARRIER
+#undef FC_PHASE
 
 hipError_t launch_fused3(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
   const size_t lds = fused3_lds_bytes(a.D);

@@ -26,7 +26,11 @@ with torch.no_grad():
             y, lad = ops.rq_spline_fused_linear(x, h, wp, bp, cols, num_bins=k, tail_bound=3.0, wh_divisor=8.0)
         torch.cuda.synchronize()
 cus = torch.cuda.get_device_properties(0).multi_processor_count
-yy = y.view(-1, 32 * d)[:cus, :12].double().cpu()
+yy = y.view(-1, 32 * d)[:cus, :60].double().cpu()
+ph = (yy[:, 12:60].median(dim=0).values / (n // 32 / cus)).view(8, 6)
+print('phase cycles per tile [write-out, step A, park, barrier 1, step B, barrier 2] per wave:')
+for w in range(8):
+    print('  wave', w, [int(v) for v in ph[w]])
 print('barrier wait per wave (cycles per tile, median over workgroups):', [round(float(v), 0) for v in (yy[:, 4:12].median(dim=0).values / (n // 32 / cus))])
 pro, entry = yy[:, 2], yy[:, 3]
 print("prologue median %.1f us max %.1f us; entry-time spread over workgroups %.1f us; loop end spread %.1f us"
