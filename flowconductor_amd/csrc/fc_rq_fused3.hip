@@ -61,9 +61,12 @@ constexpr int kHPiece = kR * kHB;             // f16 per piece per buffer
 constexpr int kHbufBytes = 2 * 2 * kHPiece * 2;    // [buf][piece][row][kHB] f16
 constexpr int kLpartBytes = 2 * 8 * kR * 4;        // [buf][wave][row]
 constexpr int kHscaleBytes = 2 * kR * 4;           // [buf][row] 2^-T of the h row
+constexpr int kKnotFloats = (kK + 1) * 64 * 2;     // per wave: [slot][lane] (x, y) knots
+constexpr int kDerFloats = (kK + 1) * 64;          // per wave: [slot][lane] derivative logits
+constexpr int kTabBytes = 8 * (kKnotFloats + kDerFloats) * 4;
 
 size_t fused3_lds_bytes(int d) {
-  return (size_t)kHbufBytes + kLpartBytes + kHscaleBytes + 2 * kR * (d + 4) * 4 + kDt * 4;
+  return (size_t)kHbufBytes + kLpartBytes + kHscaleBytes + kTabBytes + 2 * kR * (d + 4) * 4 + kDt * 4;
 }
 
 template <bool kInv>
@@ -72,7 +75,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   _Float16* hbuf = reinterpret_cast<_Float16*>(smem3);                               // [2][2][kR][kHB]
   float* lpart = reinterpret_cast<float*>(smem3 + kHbufBytes);           // [2][8][kR]
   float* hscale = lpart + 2 * 8 * kR;                                                 // [2][kR]
-  float* xbuf = hscale + 2 * kR;                                                      // [2][kR][D + 4]
+  float* tabs = hscale + 2 * kR;                                                      // [8 waves][knots | derivs]
+  float* xbuf = tabs + kTabBytes / 4;                                                 // [2][kR][D + 4]
   const int D = a.D, XS = D + 4;
   int* cs = reinterpret_cast<int*>(xbuf + 2 * kR * XS);                               // [kDt]
 
@@ -136,6 +140,16 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     const float m = t < 4 ? inv_div : 1.f;   // params 0..15 are widths and heights
     bw[t] = f32x4{bsrc[0] * m, bsrc[1] * m, bsrc[2] * m, bsrc[3] * m};
   }
+
+  // Lane-private bin tables (fc_rq_fused3_eval.inc): slots 0 and K are the interval ends / the linear-tail
+  // derivative constant (rational_quadratic.py:33-36) and never change; slots 1..K-1 are rewritten per element.
+  // [slot][lane] layout: every access of a wave is conflict-free whatever the lanes' bin indices are.
+  float* ktab = tabs + wave * (kKnotFloats + kDerFloats) + lane * 2;
+  float* dtab = tabs + wave * (kKnotFloats + kDerFloats) + kKnotFloats + lane;
+  *reinterpret_cast<f2*>(ktab) = f2{op.q.left, op.q.bottom};
+  *reinterpret_cast<f2*>(ktab + kK * 128) = f2{op.q.right, op.q.top};
+  dtab[0] = op.q.tail_const;
+  dtab[kK * 64] = op.q.tail_const;
 
   uint32_t err = 0;
   const int xvec = kR * D / 4;
@@ -237,6 +251,10 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #define FC_HOOK(n) hook(std::integral_constant<int, n>{});
 #define FC_WH(i) __builtin_fmaf(pa[(i) >> 2][(i) & 3], c_wh, bw[(i) >> 2][(i) & 3])
 #define FC_UD(j) __builtin_fmaf(pa[((j) + 16) >> 2][((j) + 16) & 3], c_d, bw[((j) + 16) >> 2][((j) + 16) & 3])
+#define FC_KNOT_ST(slot, v) *reinterpret_cast<f2*>(ktab + (slot) * 128) = (v)
+#define FC_KNOT_LD(i, off) *reinterpret_cast<const f2*>(ktab + ((i) + (off)) * 128)
+#define FC_DER_ST(slot, v) dtab[(slot) * 64] = (v)
+#define FC_DER_LD(i, off) dtab[((i) + (off)) * 64]
 #if FC_ABL & 1
     FC_ALL36(FC_HOOK)
     y = x + (FC_WH(0) + FC_WH(5) + FC_WH(10) + FC_WH(15) + FC_UD(0) + FC_UD(5)) * 0.f + q.left * 0.f;
@@ -244,6 +262,10 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #else
 #include "fc_rq_fused3_eval.inc"
 #endif
+#undef FC_DER_LD
+#undef FC_DER_ST
+#undef FC_KNOT_LD
+#undef FC_KNOT_ST
 #undef FC_UD
 #undef FC_WH
 #undef FC_HOOK

@@ -1,5 +1,5 @@
 """Times one bijector kernel in isolation on the BASELINE.json cfg-3 layer shape and prints achieved
-algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [rq|rq_inv|affine]"""
+algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [rq|rq_inv|affine|fused|fused_inv|hidden]"""
 import os
 import sys
 
@@ -24,15 +24,22 @@ def main():
         fn = lambda: ops.rq_spline(x, params, cols, num_bins=k, tails="linear", tail_bound=3.0,  # noqa: E731
                                    wh_divisor=8.0, inverse=which == "rq_inv")
         name = "fc_rq_spline"
-    elif which == "fused":
+    elif which in ("fused", "fused_inv"):
         p = 3 * k - 1
         h = torch.randn(n, 64, device=dev)
         w = torch.randn(d_t * p, 64, device=dev) * 0.2
         b = torch.randn(d_t * p, device=dev) * 0.1
         frag, bpad = ops.pack_final_layer(w, b)
         fn = lambda: ops.rq_spline_fused_linear(x, h, frag, bpad, cols, num_bins=k, tail_bound=3.0,  # noqa: E731
-                                                wh_divisor=8.0)
+                                                wh_divisor=8.0, inverse=which == "fused_inv")
         name = "fc_rq_spline_fused_linear"
+    elif which == "hidden":
+        from flowconductor_amd.nn import nets
+        p = 0
+        net = nets.ResidualNet(32, 8, hidden_features=64, num_blocks=2).eval().to(dev)
+        ids = torch.arange(1, d, 2, device=dev)
+        fn = lambda: net.hidden_hip(x, ids)  # noqa: E731
+        name = "fc_resnet_hidden"
     else:
         p = 2
         params = torch.randn(n, d_t * p, device=dev)

@@ -29,7 +29,7 @@ for i in range(K):
     add("FC_F2 t%d = FC_F2{FC_WH(%d), FC_WH(%d)};\nmx = fmaxf(mx, t%d.x);\nmy = fmaxf(my, t%d.y);" % (i, i, K + i, i, i), 3)
 # the derivative logits leave the accumulators early, so the next block's MFMAs can reuse those registers
 for j in range(K - 1):
-    add("const float ud%d = FC_UD(%d);" % (j, j), 1)
+    add("FC_DER_ST(%d, FC_UD(%d));" % (j + 1, j), 1)
 add("const FC_F2 m = {mx, my};\nFC_F2 sum = {0.f, 0.f};", 0)
 for i in range(K):
     # exp_softmax(d) = exp2(d * log2e): the multiply as one packed op for both axes
@@ -38,21 +38,18 @@ for i in range(K):
     add("sum += t%d;" % i, 1)
 add("const float rsx = div_lean(1.f, sum.x);", 5)
 add("const float rsy = div_lean(1.f, sum.y);\nconst FC_F2 rs = {rsx, rsy};", 5)
-add("FC_CUM_T cx = 0, cy = 0;\nFC_F2 prev = lo, sel_lo = lo, sel_hi = lo;\nfloat u0 = q.tail_const, u1 = q.tail_const;", 1)
-for i in range(K):
+# Bin search without per-knot selects: the interior knots go to a lane-private LDS table as they are produced
+# (slots 0 and K hold the interval ends, written once per kernel), the bin index is a count of compares, and
+# the two knots / two derivative logits of the bin come back with four LDS reads.
+add("FC_CUM_T cx = 0, cy = 0;\nint idx = 0;", 1)
+for i in range(K - 1):   # the last knot is pinned to the interval end: bin K - 1's width is never summed
     add("const FC_F2 w%d = minb + c1 * (t%d * rs);" % (i, i), 3)
-    add("cx += (FC_CUM_T)w%d.x;\ncy += (FC_CUM_T)w%d.y;" % (i, i), 4)
-    if i == K - 1:
-        add("const FC_F2 next%d = hi;" % i, 0)
-    else:
-        add("const FC_F2 next%d = span * FC_F2{(float)cx, (float)cy} + lo;" % i, 4)
-    add("const bool take%d = xc >= (kInv ? prev.y : prev.x);" % i, 1)
-    add("sel_lo.x = take%d ? prev.x : sel_lo.x;\nsel_lo.y = take%d ? prev.y : sel_lo.y;" % (i, i), 2)
-    add("sel_hi.x = take%d ? next%d.x : sel_hi.x;\nsel_hi.y = take%d ? next%d.y : sel_hi.y;\nprev = next%d;" % (i, i, i, i, i), 2)
-    # derivative knots of the selected bin: the boundary ones are the linear-tail constant
-    lo_d = "q.tail_const" if i == 0 else "ud%d" % (i - 1)
-    hi_d = "q.tail_const" if i == K - 1 else "ud%d" % i
-    add("u0 = take%d ? %s : u0;\nu1 = take%d ? %s : u1;" % (i, lo_d, i, hi_d), 2)
+    if True:
+        add("cx += (FC_CUM_T)w%d.x;\ncy += (FC_CUM_T)w%d.y;" % (i, i), 4)
+        add("const FC_F2 next%d = span * FC_F2{(float)cx, (float)cy} + lo;\nFC_KNOT_ST(%d, next%d);" % (i, i + 1, i), 4)
+        add("idx += (xc >= (kInv ? next%d.y : next%d.x)) ? 1 : 0;" % (i, i), 2)
+add("const FC_F2 sel_lo = FC_KNOT_LD(idx, 0), sel_hi = FC_KNOT_LD(idx, 1);\n"
+    "const float u0 = FC_DER_LD(idx, 0), u1 = FC_DER_LD(idx, 1);", 3)
 add("const float xk = sel_lo.x, yk = sel_lo.y;\nconst float wk = sel_hi.x - sel_lo.x, hk = sel_hi.y - sel_lo.y;", 2)
 # one v_rcp of the bin width serves both divisions (div_lean: q = a * r, then one residual correction)
 add("const float rwk = __builtin_amdgcn_rcpf(wk);\nconst float dq = hk * rwk;\n"
@@ -100,7 +97,8 @@ add("y = inside ? ys : x;\nlad = inside ? (kInv ? -lval : lval) : 0.f;", 3)
 total = sum(w for _, w in chunks)
 out = ["// GENERATED by tools/gen_fused_eval.py -- do not edit by hand.",
        "// Straight-line RQ-spline evaluation (K = %d, linear tails) of one element with %d MFMA hook points." % (K, HOOKS),
-       "// Expects in scope: FC_WH(i) / FC_UD(j) (logits of the element), FC_F2, FC_CUM_T, x, q (RQParams), inv_beta, err,",
+       "// Expects in scope: FC_WH(i) / FC_UD(j) (logits of the element), FC_KNOT_ST / FC_KNOT_LD / FC_DER_ST / FC_DER_LD",
+       "// (lane-private LDS tables of K + 1 knots and K + 1 derivative logits), FC_F2, FC_CUM_T, x, q, inv_beta, err,",
        "// kInv (constexpr bool), outputs y / lad, and FC_HOOK(n)."]
 acc = 0.0
 hook = 0
