@@ -31,7 +31,7 @@ class RQConfig(ctypes.Structure):
         ("num_bins", ctypes.c_int32),
         ("tails", ctypes.c_int32),
         ("inverse", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
         ("left", ctypes.c_float),
         ("right", ctypes.c_float),
         ("bottom", ctypes.c_float),

@@ -24,6 +24,7 @@ struct FusedArgs {
   uint32_t* err;
   int64_t tiles;         // full 32-row tiles
   int D;
+  int accumulate;        // logabsdet[n] += instead of = (FC_RQ_ACCUMULATE_LOGABSDET)
 };
 
 size_t fused3_lds_bytes(int d);

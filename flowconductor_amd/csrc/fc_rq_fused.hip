@@ -47,7 +47,8 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
   op.inv_div = 1.f / q.wh_div;
   op.inv_beta = 1.f / q.beta;
 
-  fc::FusedArgs a{x, y, h, w_pad, bias_pad, cols, logabsdet, err_flag, n / fc::kR, d};
+  fc::FusedArgs a{x, y, h, w_pad, bias_pad, cols, logabsdet, err_flag, n / fc::kR, d,
+                  (cfg->flags & FC_RQ_ACCUMULATE_LOGABSDET) ? 1 : 0};
   int64_t grid = fc::device_cu_count();   // one persistent 512-thread workgroup per CU
   if (grid > a.tiles) grid = a.tiles;
   return fc::launch_fused3(op, a, (unsigned)grid, static_cast<hipStream_t>(stream));

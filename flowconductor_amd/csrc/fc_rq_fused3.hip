@@ -334,7 +334,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
         float l = lp[0];
 #pragma unroll
         for (int w = 1; w < 8; ++w) l += lp[w * kR];
-        a.logabsdet[tile * kR + tid] = l;
+        // running total of the composite (base.py:51 `total_logabsdet += logabsdet`) or a fresh value
+        a.logabsdet[tile * kR + tid] = a.accumulate ? a.logabsdet[tile * kR + tid] + l : l;
       }
     }
     tb ^= 1;

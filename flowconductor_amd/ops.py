@@ -289,9 +289,12 @@ def pack_final_layer(weight, bias, num_bins=FUSED_BINS):
 
 def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, tail_bound,
                            min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
-                           min_derivative=DEFAULT_MIN_DERIVATIVE, wh_divisor=1.0, inverse=False):
+                           min_derivative=DEFAULT_MIN_DERIVATIVE, wh_divisor=1.0, inverse=False,
+                           logabsdet_accum=None):
     """RQ-spline coupling bijector with the conditioner's final Linear fused in (rows must be a multiple
-    of 32).  ``hidden``: [N, 64] input of that Linear.  Returns ``(outputs [N, D], logabsdet [N])``."""
+    of 32).  ``hidden``: [N, 64] input of that Linear.  Returns ``(outputs [N, D], logabsdet [N])``; with
+    ``logabsdet_accum`` (f32 [N], contiguous) the kernel adds the layer's logabsdet onto it in place and that
+    tensor is returned."""
     lib = _hip.load()
     x = _prep_2d(inputs)
     h = _hip.dev_f32(hidden, "hidden")
@@ -308,7 +311,13 @@ def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, t
     cfg.softplus_beta = 1.0
     cfg.tail_constant = float(np.log(np.exp(1 - min_derivative) - 1))
     y = torch.empty_like(x)
-    lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    if logabsdet_accum is not None:
+        lad = logabsdet_accum
+        if lad.dtype != torch.float32 or lad.shape != (n,) or not lad.is_contiguous() or lad.device != x.device:
+            raise ValueError("logabsdet_accum must be a contiguous float32 [N] tensor on the inputs' device")
+        cfg.flags = 1  # FC_RQ_ACCUMULATE_LOGABSDET
+    else:
+        lad = torch.empty(n, dtype=torch.float32, device=x.device)
     err = _err_word(x.device, True)
     _call("fc_rq_spline_fused_linear", lib.fc_rq_spline_fused_linear, x.device, _hip.ptr(x), _hip.ptr(y),
           _hip.ptr(h), _hip.ptr(w_pad), _hip.ptr(bias_pad), _hip.ptr(cols), _hip.ptr(lad), _hip.ptr(err), n, d,

@@ -29,20 +29,27 @@ class CompositeTransform(Transform):
         self._transforms = nn.ModuleList(transforms)
 
     @staticmethod
-    def _cascade(inputs, funcs, context):
+    def _cascade(inputs, transforms, context, inverse):
+        """base.py:44-60 of the reference.  A transform may offer ``_apply_accumulate(inputs, context, inverse,
+        total)`` -> outputs, which adds its logabsdet onto the running total inside its own kernel (one
+        element-wise pass over [N] saved per layer); everything else goes through forward / inverse."""
         outputs = inputs
         total_logabsdet = inputs.new_zeros(inputs.shape[0])
         with ops.deferred_errors():
-            for func in funcs:
-                outputs, logabsdet = func(outputs, context)
-                total_logabsdet += logabsdet
+            for t in transforms:
+                fused = getattr(t, "_apply_accumulate", None)
+                if fused is not None and total_logabsdet.dtype == torch.float32:
+                    outputs = fused(outputs, context, inverse, total_logabsdet)
+                else:
+                    outputs, logabsdet = (t.inverse if inverse else t)(outputs, context)
+                    total_logabsdet += logabsdet
         return outputs, total_logabsdet
 
     def forward(self, inputs, context=None):
-        return self._cascade(inputs, self._transforms, context)
+        return self._cascade(inputs, self._transforms, context, False)
 
     def inverse(self, inputs, context=None):
-        return self._cascade(inputs, (t.inverse for t in self._transforms[::-1]), context)
+        return self._cascade(inputs, self._transforms[::-1], context, True)
 
 
 class InverseTransform(Transform):

@@ -268,7 +268,16 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             self._packed = (key,) + ops.pack_final_layer(lin.weight, lin.bias, self.num_bins)
         return self._packed[1], self._packed[2]
 
-    def _run(self, inputs, context, inverse):
+    def _apply_accumulate(self, inputs, context, inverse, total):
+        """CompositeTransform fast path: the fused kernel adds this layer's logabsdet onto ``total`` itself."""
+        if not self._fused_ok(inputs) or self.unconditional_transform is not None:
+            outputs, logabsdet = self._run(inputs, context, inverse)
+            total += logabsdet
+            return outputs
+        outputs, _ = self._run(inputs, context, inverse, total=total)
+        return outputs
+
+    def _run(self, inputs, context, inverse, total=None):
         if not self._fused_ok(inputs):
             return super()._run(inputs, context, inverse)
         self._check(inputs)
@@ -295,12 +304,19 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         body = n - n % ops.FUSED_ROWS
         cols = self._cols(inputs.device)
         if body == n:
-            outputs, logabsdet = ops.rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, **kw)
+            outputs, logabsdet = ops.rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols,
+                                                            logabsdet_accum=total, **kw)
         else:
             # the < 32 leftover rows go through the final Linear + the stand-alone kernel
-            out_a, lad_a = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_pad, bias_pad, cols, **kw)
+            out_a, lad_a = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_pad, bias_pad, cols,
+                                                      logabsdet_accum=None if total is None else total[:body], **kw)
             out_b, lad_b = self._coupling_kernel(inputs[body:].contiguous(), net.final_layer(hidden[body:]), inverse)
-            outputs, logabsdet = torch.cat((out_a, out_b)), torch.cat((lad_a, lad_b))
+            outputs = torch.cat((out_a, out_b))
+            if total is None:
+                logabsdet = torch.cat((lad_a, lad_b))
+            else:
+                total[body:] += lad_b
+                logabsdet = total
         if self.unconditional_transform is not None:
             if not inverse:
                 identity_split, logabsdet_identity = self.unconditional_transform(identity_split, context)

@@ -39,11 +39,14 @@ extern "C" {
 int fc_abi_version(void);
 
 /* ---- rational-quadratic spline ------------------------------------------------------- */
+#define FC_RQ_ACCUMULATE_LOGABSDET 1 /* fc_rq_spline_fused_linear: logabsdet[n] += sum (the caller's running
+                                       total of CompositeTransform._cascade, transforms/base.py:45-52) */
+
 typedef struct fc_rq_config {
   int32_t num_bins;       /* K */
   int32_t tails;          /* 0: none, 1: "linear" (rational_quadratic.py:32-42) */
   int32_t inverse;        /* 0 forward, 1 inverse */
-  int32_t reserved;
+  int32_t flags;          /* FC_RQ_* bits */
   float left, right, bottom, top; /* linear tails: -B, B, -B, B */
   double min_bin_width, min_bin_height, min_derivative; /* python floats of the reference */
   float wh_divisor;       /* sqrt(hidden_features) or 1 (coupling.py:554-559) */

@@ -157,3 +157,25 @@ def test_fused_linear_scaling_edge_cases(case, device):
     assert maxdiff(y, ref_y) <= 2e-5 * max(1.0, float(ref_y.abs().max())) + 4 * floor_y
     assert maxdiff(lad, ref_lad) <= 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10) + 4 * floor_lad
     assert torch.isfinite(y).all() and torch.isfinite(lad).all()
+
+
+@pytest.mark.parametrize("n", [64, 1000])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_composite_accumulates_logabsdet_in_kernel(n, inverse, device):
+    """CompositeTransform hands its running total to the fused kernel (FC_RQ_ACCUMULATE_LOGABSDET); the result
+    must be bit-identical to summing the layers' logabsdets with separate adds (base.py:45-52 order)."""
+    from flowconductor_amd import transforms
+
+    layers = [build_case("rq_coupling_linear_tails_d64_k8_h64")[0] for _ in range(3)]
+    comp = transforms.CompositeTransform(layers).to(device).eval()
+    x = (torch.randn(n, 64, generator=torch.Generator().manual_seed(5)) * 1.5).to(device)
+    with torch.no_grad():
+        with ops.KernelTimer("fc_rq_spline_fused_linear") as timer:
+            y, total = (comp.inverse if inverse else comp)(x)
+        assert len(timer.pairs) == 3
+        out, ref_total = x, torch.zeros(n, device=device)
+        for t in (layers[::-1] if inverse else layers):
+            out, lad = (t.inverse if inverse else t)(out)
+            ref_total += lad
+    assert torch.equal(y, out)
+    assert torch.equal(total, ref_total)
