@@ -7,7 +7,7 @@
 
 namespace fc {
 
-constexpr int kR = 32;            // rows per tile
+constexpr int kRowsMin = 32;      // the entry takes multiples of 32 rows (tiles of 64 rows + one of 32)
 constexpr int kH = 64;            // hidden width (GEMM K)
 constexpr int kDt = 32;           // transformed dims
 constexpr int kK = 8;             // spline bins
@@ -22,12 +22,12 @@ struct FusedArgs {
   const int32_t* cols;   // [32]
   float* logabsdet;      // [N]
   uint32_t* err;
-  int64_t tiles;         // full 32-row tiles
+  int64_t tiles;         // full tiles (64 or 32 rows, see launch_fused3)
   int D;
   int accumulate;        // logabsdet[n] += instead of = (FC_RQ_ACCUMULATE_LOGABSDET)
 };
 
-size_t fused3_lds_bytes(int d);
-hipError_t launch_fused3(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream);
+size_t fused3_lds_bytes(int d, int rows);
+hipError_t launch_fused3(const RQOp<kK>& op, const FusedArgs& a, int rows, unsigned grid, hipStream_t stream);
 
 }  // namespace fc

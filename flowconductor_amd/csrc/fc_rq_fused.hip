@@ -29,7 +29,7 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
   if (!cfg || n < 0 || d < d_t) return hipErrorInvalidValue;
   if (hidden != fc::kH || d_t != fc::kDt || cfg->num_bins != fc::kK || cfg->tails != 1 || d % 4 != 0 || d > 128)
     return hipErrorInvalidValue;  // only the north-star layer shape is fused; callers fall back otherwise
-  if (n % fc::kR != 0) return hipErrorInvalidValue;
+  if (n % fc::kRowsMin != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
   if (!x || !y || !h || !w_pad || !bias_pad || !cols || !logabsdet) return hipErrorInvalidValue;
   if ((((uintptr_t)h | (uintptr_t)x | (uintptr_t)y) & 15u) != 0) return hipErrorInvalidValue;
@@ -47,9 +47,22 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
   op.inv_div = 1.f / q.wh_div;
   op.inv_beta = 1.f / q.beta;
 
-  fc::FusedArgs a{x, y, h, w_pad, bias_pad, cols, logabsdet, err_flag, n / fc::kR, d,
-                  (cfg->flags & FC_RQ_ACCUMULATE_LOGABSDET) ? 1 : 0};
-  int64_t grid = fc::device_cu_count();   // one persistent 512-thread workgroup per CU
-  if (grid > a.tiles) grid = a.tiles;
-  return fc::launch_fused3(op, a, (unsigned)grid, static_cast<hipStream_t>(stream));
+  const int acc = (cfg->flags & FC_RQ_ACCUMULATE_LOGABSDET) ? 1 : 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int64_t cus = fc::device_cu_count();   // one persistent 512-thread workgroup per CU
+  // 64-row tiles (fewer barriers and tile hand-overs per row) when their LDS image fits, 32-row tiles for very
+  // wide inputs and for the last 32 rows of an odd multiple of 32
+  const bool wide_ok = fc::fused3_lds_bytes(d, 64) <= 160 * 1024;
+  const int64_t n64 = wide_ok ? n - n % 64 : 0;
+  if (n64 > 0) {
+    fc::FusedArgs a{x, y, h, w_pad, bias_pad, cols, logabsdet, err_flag, n64 / 64, d, acc};
+    const hipError_t e = fc::launch_fused3(op, a, 64, (unsigned)(cus < a.tiles ? cus : a.tiles), s);
+    if (e != hipSuccess) return e;
+  }
+  if (n64 < n) {
+    fc::FusedArgs a{x + n64 * d, y + n64 * d, h + n64 * fc::kH, w_pad, bias_pad, cols, logabsdet + n64, err_flag,
+                    (n - n64) / 32, d, acc};
+    return fc::launch_fused3(op, a, 32, (unsigned)(cus < a.tiles ? cus : a.tiles), s);
+  }
+  return hipSuccess;
 }

@@ -57,28 +57,39 @@ namespace fc {
 
 constexpr int kCt3 = 6;                       // 16-feature tiles per wave: 4 dims x 24 padded params
 constexpr int kHB = kH + 8;                   // f16 per h row in LDS (144 B: conflict-free b128 reads)
-constexpr int kHPiece = kR * kHB;             // f16 per piece per buffer
-constexpr int kHbufBytes = 2 * 2 * kHPiece * 2;    // [buf][piece][row][kHB] f16
-constexpr int kLpartBytes = 2 * 8 * kR * 4;        // [buf][wave][row]
-constexpr int kHscaleBytes = 2 * kR * 4;           // [buf][row] 2^-T of the h row
 constexpr int kKnotFloats = (kK + 1) * 64 * 2;     // per wave: [slot][lane] (x, y) knots
 constexpr int kDerFloats = (kK + 1) * 64;          // per wave: [slot][lane] derivative logits
 constexpr int kTabBytes = 8 * (kKnotFloats + kDerFloats) * 4;
 
-size_t fused3_lds_bytes(int d) {
-  return (size_t)kHbufBytes + kLpartBytes + kHscaleBytes + kTabBytes + 2 * kR * (d + 4) * 4 + kDt * 4;
-}
+// LDS image for tiles of R rows (R = 64 unless the x tile of a wide input does not fit, then 32)
+template <int R>
+struct Fused3Lds {
+  static constexpr int kHPiece = R * kHB;                  // f16 per piece per buffer
+  static constexpr int kHbufBytes = 2 * 2 * kHPiece * 2;   // [buf][piece][row][kHB] f16
+  static constexpr int kLpartBytes = 2 * 8 * R * 4;        // [buf][wave][row]
+  static constexpr int kHscaleBytes = 2 * R * 4;           // [buf][row] 2^-T of the h row
+  static constexpr size_t bytes(int d) {
+    return (size_t)kHbufBytes + kLpartBytes + kHscaleBytes + kTabBytes + 2 * R * (d + 4) * 4 + kDt * 4;
+  }
+};
 
-template <bool kInv>
+size_t fused3_lds_bytes(int d, int rows) { return rows == 64 ? Fused3Lds<64>::bytes(d) : Fused3Lds<32>::bytes(d); }
+
+// R: rows per tile (64, or 32), NB = R / 16 sample blocks per tile; XV: float4 of the x tile per thread
+template <bool kInv, int R, int XV>
 __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, FusedArgs a) {
+  using L = Fused3Lds<R>;
+  constexpr int kHPiece = L::kHPiece;
+  constexpr int NB = R / 16;      // sample blocks per tile
+  constexpr int HV = R / 32;      // float4 of the h tile per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  _Float16* hbuf = reinterpret_cast<_Float16*>(smem3);                               // [2][2][kR][kHB]
-  float* lpart = reinterpret_cast<float*>(smem3 + kHbufBytes);           // [2][8][kR]
-  float* hscale = lpart + 2 * 8 * kR;                                                 // [2][kR]
-  float* tabs = hscale + 2 * kR;                                                      // [8 waves][knots | derivs]
-  float* xbuf = tabs + kTabBytes / 4;                                                 // [2][kR][D + 4]
+  _Float16* hbuf = reinterpret_cast<_Float16*>(smem3);                               // [2][2][R][kHB]
+  float* lpart = reinterpret_cast<float*>(smem3 + L::kHbufBytes);                    // [2][8][R]
+  float* hscale = lpart + 2 * 8 * R;                                                  // [2][R]
+  float* tabs = hscale + 2 * R;                                                       // [8 waves][knots | derivs]
+  float* xbuf = tabs + kTabBytes / 4;                                                 // [2][R][D + 4]
   const int D = a.D, XS = D + 4;
-  int* cs = reinterpret_cast<int*>(xbuf + 2 * kR * XS);                               // [kDt]
+  int* cs = reinterpret_cast<int*>(xbuf + 2 * R * XS);                                // [kDt]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s16 = lane & 15, g = lane >> 4;
@@ -152,23 +163,29 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   dtab[kK * 64] = op.q.tail_const;
 
   uint32_t err = 0;
-  const int xvec = kR * D / 4;
-  float4 hv, xv0, xv1;
-  auto fetch = [&](int64_t t) {
+  const int xvec = R * D / 4;     // float4 per x tile: thread tid owns slots tid + 512 k, k < XV
+  // (named scalars, not arrays: hipcc keeps register arrays that are written under `if (has_next)` in scratch)
+  float4 hv0, hv1, xv0, xv1, xv2, xv3;
+  hv0 = hv1 = xv0 = xv1 = xv2 = xv3 = float4{0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int64_t t) __attribute__((always_inline)) {
     if (FC_ABL & 8) t = tile0;   // ablation: every tile's loads hit in L2
-    hv = reinterpret_cast<const float4*>(a.h + t * kR * kH)[tid];
-    const float4* xg = reinterpret_cast<const float4*>(a.x + t * kR * D);
+    const float4* hg = reinterpret_cast<const float4*>(a.h + t * R * kH);
+    hv0 = hg[tid];
+    if constexpr (HV > 1) hv1 = hg[tid + 512];
+    const float4* xg = reinterpret_cast<const float4*>(a.x + t * R * D);
     xv0 = xg[tid < xvec ? tid : 0];
-    xv1 = xg[tid + 512 < xvec ? tid + 512 : 0];
+    if constexpr (XV > 1) xv1 = xg[tid + 512 < xvec ? tid + 512 : 0];
+    if constexpr (XV > 2) xv2 = xg[tid + 1024 < xvec ? tid + 1024 : 0];
+    if constexpr (XV > 3) xv3 = xg[tid + 1536 < xvec ? tid + 1536 : 0];
   };
-  auto xslot = [&](int buf, int i) {   // float4 index i of a [kR, D] tile -> its padded LDS position
+  auto xslot = [&](int buf, int i) __attribute__((always_inline)) {   // float4 index i of a [R, D] tile -> its padded LDS position
     const int e = i * 4, r = e / D, c = e - r * D;
-    return reinterpret_cast<float4*>(xbuf + (buf * kR + r) * XS + c);
+    return reinterpret_cast<float4*>(xbuf + (buf * R + r) * XS + c);
   };
-  auto park = [&](int buf) {
-    // thread tid holds h[row tid >> 4][4 (tid & 15) ..]: the 16 threads of a row are 16 adjacent lanes
-    const int r = tid >> 4, c = (tid & 15) * 4;
-    const float v[4] = {hv.x, hv.y, hv.z, hv.w};
+  // thread tid holds h[row (tid >> 4) + 32 k][4 (tid & 15) ..]: the 16 threads of a row are 16 adjacent lanes
+  auto park_h = [&](int buf, int k, const float4& hvk) __attribute__((always_inline)) {
+    const int c = (tid & 15) * 4, r = (tid >> 4) + 32 * k;
+    const float v[4] = {hvk.x, hvk.y, hvk.z, hvk.w};
     float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
@@ -181,17 +198,23 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
       split2(v[j] * sc, ph, pl);
       p0[j] = ph; p1[j] = pl;
     }
-    _Float16* dst = hbuf + (buf * 2 * kR + r) * kHB + c;
+    _Float16* dst = hbuf + (buf * 2 * R + r) * kHB + c;
     *reinterpret_cast<f16x4*>(dst) = p0;
     *reinterpret_cast<f16x4*>(dst + kHPiece) = p1;
-    if ((tid & 15) == 0) hscale[buf * kR + r] = un;
+    if ((tid & 15) == 0) hscale[buf * R + r] = un;
+  };
+  auto park = [&](int buf) __attribute__((always_inline)) {
+    park_h(buf, 0, hv0);
+    if constexpr (HV > 1) park_h(buf, 1, hv1);
     if (tid < xvec) *xslot(buf, tid) = xv0;
-    if (tid + 512 < xvec) *xslot(buf, tid + 512) = xv1;
+    if constexpr (XV > 1) if (tid + 512 < xvec) *xslot(buf, tid + 512) = xv1;
+    if constexpr (XV > 2) if (tid + 1024 < xvec) *xslot(buf, tid + 1024) = xv2;
+    if constexpr (XV > 3) if (tid + 1536 < xvec) *xslot(buf, tid + 1536) = xv3;
   };
   // B operand (h^T piece `hp`, k-step ks) of block `blk` in buffer `hb`:
   // lane holds h[sample 16 blk + (lane & 15)][k = 32 ks + 8 (lane >> 4) + j]
   auto hfrag = [&](int hb, int blk, int hp, int ks) {
-    return *reinterpret_cast<const f16x8*>(hbuf + ((hb * 2 + hp) * kR + 16 * blk + s16) * kHB + 32 * ks + 8 * g);
+    return *reinterpret_cast<const f16x8*>(hbuf + ((hb * 2 + hp) * R + 16 * blk + s16) * kHB + 32 * ks + 8 * g);
   };
 
   // MFMA number n of a block: term n / 12 (0: Wl hh, 1: Wh hl, 2: Wh hh -- small products first),
@@ -223,9 +246,9 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   // One step: evaluate this lane's element of block `cblk` of the tile in buffer `xb` from the accumulators
   // `pa`, and produce into `acc` the accumulators of block `pblk` of the tile in buffer `hb`.
   auto step = [&](const f32x4 (&pa)[kCt3], int xb, int cblk, f32x4 (&acc)[kCt3], int hb, int pblk) {
-    float* xr = xbuf + (xb * kR + 16 * cblk + s16) * XS + cs[4 * wave + g];
+    float* xr = xbuf + (xb * R + 16 * cblk + s16) * XS + cs[4 * wave + g];
     const float x = *xr;
-    const float c_d = hscale[xb * kR + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
+    const float c_d = hscale[xb * R + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
     const float c_wh = c_d * inv_div;
     // h^T fragments are read one group of 6 MFMAs ahead of their use
     f16x8 bcur, bnext = hfrag(hb, pblk, term_h(0), 0);
@@ -274,7 +297,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     float l = lad;
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
-    if (g == 0) lpart[(xb * 8 + wave) * kR + 16 * cblk + s16] = l;
+    if (g == 0) lpart[(xb * 8 + wave) * R + 16 * cblk + s16] = l;
   };
 
 #if FC_ABL & 16   // ablation: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, stamped around the loop
@@ -311,46 +334,53 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     const bool has_next = tile + stride < a.tiles;
     FC_PHASE(0);
     if (has_next) fetch(tile + stride);
-    step(acc0, tb, 0, acc1, tb, 1);        // A: evaluate block 0 of `tile`, produce its block 1
+    // Steps 0 .. NB-2: evaluate block j of `tile`, produce its block j + 1.  (acc0 / acc1 alternate; NB is
+    // even, so every tile starts with its block 0 in acc0.)
+    step(acc0, tb, 0, acc1, tb, 1);
+    if constexpr (NB == 4) {
+      step(acc1, tb, 1, acc0, tb, 2);
+      step(acc0, tb, 2, acc1, tb, 3);
+    }
     FC_PHASE(1);
     if (has_next) park(tb ^ 1);
     FC_PHASE(2);
     FC_TIMED_BARRIER();
     FC_PHASE(3);
-    // B: evaluate block 1, produce block 0 of the next tile (unconditional: on the last tile the MFMAs work
-    // on stale h rows into accumulators nobody reads -- a branch would split the interleaved block).
-    step(acc1, tb, 1, acc0, tb ^ 1, 0);
+    // Last step: evaluate block NB-1, produce block 0 of the next tile (unconditional: on the last tile the
+    // MFMAs work on stale h rows into accumulators nobody reads -- a branch would split the interleaved block).
+    step(acc1, tb, NB - 1, acc0, tb ^ 1, 0);
     FC_PHASE(4);
     FC_TIMED_BARRIER();
     FC_PHASE(5);
     // Every thread writes out exactly the float4 slots it parks, and lpart is double-buffered, so no third
     // barrier is needed before the next iteration.
     {
-      float4* yg = reinterpret_cast<float4*>(a.y + tile * kR * D);
-      if (tid < xvec) yg[tid] = *xslot(tb, tid);
-      if (tid + 512 < xvec) yg[tid + 512] = *xslot(tb, tid + 512);
-      if (tid < kR) {
-        const float* lp = lpart + tb * 8 * kR + tid;
+      float4* yg = reinterpret_cast<float4*>(a.y + tile * R * D);
+#pragma unroll
+      for (int k = 0; k < XV; ++k)
+        if (tid + 512 * k < xvec) yg[tid + 512 * k] = *xslot(tb, tid + 512 * k);
+      if (tid < R) {
+        const float* lp = lpart + tb * 8 * R + tid;
         float l = lp[0];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) l += lp[w * kR];
+        for (int w = 1; w < 8; ++w) l += lp[w * R];
         // running total of the composite (base.py:51 `total_logabsdet += logabsdet`) or a fresh value
-        a.logabsdet[tile * kR + tid] = a.accumulate ? a.logabsdet[tile * kR + tid] + l : l;
+        a.logabsdet[tile * R + tid] = a.accumulate ? a.logabsdet[tile * R + tid] + l : l;
       }
     }
     tb ^= 1;
   }
 #if FC_ABL & 16   // the stamps overwrite two outputs of the workgroup's first tile: probe builds only
   if (tid == 0) {
-    a.y[tile0 * kR * D] = (float)(__builtin_amdgcn_s_memtime() - stamp_c0);
-    a.y[tile0 * kR * D + 1] = (float)(__builtin_amdgcn_s_memrealtime() - stamp_r0);
-    a.y[tile0 * kR * D + 2] = (float)(stamp_r0 - stamp_r_entry);                 // prologue, 10 ns ticks
-    a.y[tile0 * kR * D + 3] = (float)(stamp_r_entry & 0xffffff);                  // entry time (for launch skew)
+    a.y[tile0 * R * D] = (float)(__builtin_amdgcn_s_memtime() - stamp_c0);
+    a.y[tile0 * R * D + 1] = (float)(__builtin_amdgcn_s_memrealtime() - stamp_r0);
+    a.y[tile0 * R * D + 2] = (float)(stamp_r0 - stamp_r_entry);                 // prologue, 10 ns ticks
+    a.y[tile0 * R * D + 3] = (float)(stamp_r_entry & 0xffffff);                  // entry time (for launch skew)
   }
   if (lane == 0) {
-    a.y[tile0 * kR * D + 4 + wave] = (float)barrier_wait;
+    a.y[tile0 * R * D + 4 + wave] = (float)barrier_wait;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) a.y[tile0 * kR * D + 12 + wave * 6 + k] = (float)phase_cyc[k];
+    for (int k = 0; k < 6; ++k) a.y[tile0 * R * D + 12 + wave * 6 + k] = (float)phase_cyc[k];
   }
 #endif
   if (err && a.err) atomicOr(a.err, err);
@@ -359,24 +389,31 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #undef FC_TIMED_BARRIER
 #undef FC_PHASE
 
-hipError_t launch_fused3(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
-  const size_t lds = fused3_lds_bytes(a.D);
+template <bool kInv, int R, int XV>
+static hipError_t launch_one(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
+  const size_t lds = Fused3Lds<R>::bytes(a.D);
   if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rq_fused_linear_kernel3<false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rq_fused_linear_kernel3<kInv, R, XV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rq_fused_linear_kernel3<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  if (op.q.inverse)
-    hipLaunchKernelGGL(rq_fused_linear_kernel3<true>, dim3(grid), dim3(512), lds, stream, op, a);
-  else
-    hipLaunchKernelGGL(rq_fused_linear_kernel3<false>, dim3(grid), dim3(512), lds, stream, op, a);
+  hipLaunchKernelGGL((rq_fused_linear_kernel3<kInv, R, XV>), dim3(grid), dim3(512), lds, stream, op, a);
   return hipGetLastError();
+}
+
+// `a.tiles` counts tiles of `rows` rows (64 or 32)
+hipError_t launch_fused3(const RQOp<kK>& op, const FusedArgs& a, int rows, unsigned grid, hipStream_t stream) {
+  const bool inv = op.q.inverse != 0;
+  if (rows == 64) {
+    if (a.D <= 32) return inv ? launch_one<true, 64, 1>(op, a, grid, stream) : launch_one<false, 64, 1>(op, a, grid, stream);
+    if (a.D <= 64) return inv ? launch_one<true, 64, 2>(op, a, grid, stream) : launch_one<false, 64, 2>(op, a, grid, stream);
+    return inv ? launch_one<true, 64, 4>(op, a, grid, stream) : launch_one<false, 64, 4>(op, a, grid, stream);
+  }
+  if (a.D <= 64) return inv ? launch_one<true, 32, 1>(op, a, grid, stream) : launch_one<false, 32, 1>(op, a, grid, stream);
+  return inv ? launch_one<true, 32, 2>(op, a, grid, stream) : launch_one<false, 32, 2>(op, a, grid, stream);
 }
 
 }  // namespace fc

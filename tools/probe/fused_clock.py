@@ -26,18 +26,18 @@ with torch.no_grad():
             y, lad = ops.rq_spline_fused_linear(x, h, wp, bp, cols, num_bins=k, tail_bound=3.0, wh_divisor=8.0)
         torch.cuda.synchronize()
 cus = torch.cuda.get_device_properties(0).multi_processor_count
-yy = y.view(-1, 32 * d)[:cus, :60].double().cpu()
-ph = (yy[:, 12:60].median(dim=0).values / (n // 32 / cus)).view(8, 6)
-print('phase cycles per tile [write-out, step A, park, barrier 1, step B, barrier 2] per wave:')
+yy = y.view(-1, 64 * d)[:cus, :60].double().cpu()
+ph = (yy[:, 12:60].median(dim=0).values / (n // 64 / cus)).view(8, 6)
+print('phase cycles per 64-row tile [write-out, steps 0-2, park, barrier 1, step 3, barrier 2] per wave:')
 for w in range(8):
     print('  wave', w, [int(v) for v in ph[w]])
-print('barrier wait per wave (cycles per tile, median over workgroups):', [round(float(v), 0) for v in (yy[:, 4:12].median(dim=0).values / (n // 32 / cus))])
+print('barrier wait per wave (cycles per tile, median over workgroups):', [round(float(v), 0) for v in (yy[:, 4:12].median(dim=0).values / (n // 64 / cus))])
 pro, entry = yy[:, 2], yy[:, 3]
 print("prologue median %.1f us max %.1f us; entry-time spread over workgroups %.1f us; loop end spread %.1f us"
       % (pro.median() / 100, pro.max() / 100, (entry.max() - entry.min()) / 100,
          ((entry + pro + yy[:, 1]).max() - (entry + pro + yy[:, 1]).min()) / 100))
 cyc, rt = yy[:, 0], yy[:, 1]
 ghz = (cyc / rt * 0.1)
-tiles = n // 32 / cus
-print("workgroups %d  tiles/wg %.0f  cycles median %.0f  realtime median %.1f us  clock median %.3f GHz (min %.3f max %.3f)  cycles/tile %.0f"
-      % (cus, tiles, cyc.median(), rt.median() / 100.0, ghz.median(), ghz.min(), ghz.max(), cyc.median() / tiles))
+tiles = n // 64 / cus
+print("workgroups %d  tiles/wg %.0f  cycles median %.0f  realtime median %.1f us  clock median %.3f GHz (min %.3f max %.3f)  cycles per 64-row tile %.0f (%.0f per 32 rows)"
+      % (cus, tiles, cyc.median(), rt.median() / 100.0, ghz.median(), ghz.min(), ghz.max(), cyc.median() / tiles, cyc.median() / tiles / 2))
