@@ -1,0 +1,39 @@
+// Cross-lane reductions on the VALU (DPP row rotations, gfx950 permlane swaps) instead of ds_bpermute round
+// trips through the LDS pipe.  Semantics checked on hardware by tools/probe/dpp_permlane_check.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fc {
+
+// max over the 16 lanes of a DPP row (lanes 16r .. 16r+15); every lane of the row gets the result
+__device__ __forceinline__ float row16_allmax(float m) {
+#define FC_ROR(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x120 + (n), 0xf, 0xf, false))
+  m = fmaxf(m, FC_ROR(8));
+  m = fmaxf(m, FC_ROR(4));
+  m = fmaxf(m, FC_ROR(2));
+  m = fmaxf(m, FC_ROR(1));
+#undef FC_ROR
+  return m;
+}
+
+// value of lane ^ 32 / lane ^ 16
+__device__ __forceinline__ float lane_xor32(float v, int lane) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, (lane & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float lane_xor16(float v, int lane) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  return __builtin_bit_cast(float, (lane & 16) ? r[0] : r[1]);
+}
+
+// sum / max over the four lanes s, s + 16, s + 32, s + 48 of a wave; every lane gets the result
+__device__ __forceinline__ float rows4_allsum(float v, int lane) {
+  v += lane_xor32(v, lane);
+  return v + lane_xor16(v, lane);
+}
+__device__ __forceinline__ float rows4_allmax(float v, int lane) {
+  v = fmaxf(v, lane_xor32(v, lane));
+  return fmaxf(v, lane_xor16(v, lane));
+}
+
+}  // namespace fc

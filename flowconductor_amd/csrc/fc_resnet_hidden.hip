@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fc_split.h"
+#include "fc_lane.h"
 #include "../../include/flowcon_hip.h"
 
 namespace fc {
@@ -126,8 +127,7 @@ __global__ __launch_bounds__(kHidThreads, 4) void resnet_hidden_kernel(HiddenArg
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(v[t][r]));
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    m = rows4_allmax(m, lane);
     float sc, un;
     pow2_scale(m, sc, un);
 #pragma unroll

@@ -37,6 +37,7 @@
 #include "fc_rq_op.h"
 #include "fc_rq_fused.h"
 #include "fc_split.h"
+#include "fc_lane.h"
 #include "../../include/flowcon_hip.h"
 
 // tools/probe/build_fused_variants.sh only: ablation builds (1 no evaluation, 4 no MFMAs, 8 loads from L2,
@@ -186,9 +187,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   auto park_h = [&](int buf, int k, const float4& hvk) __attribute__((always_inline)) {
     const int c = (tid & 15) * 4, r = (tid >> 4) + 32 * k;
     const float v[4] = {hvk.x, hvk.y, hvk.z, hvk.w};
-    float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 16));
+    const float m = row16_allmax(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     float sc, un;
     pow2_scale(m, sc, un);
     f16x4 p0, p1;
@@ -294,9 +293,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #undef FC_HOOK
     *xr = y;
     // logabsdet partial of this wave's 4 dims: lanes s, s+16, s+32, s+48 hold the same sample
-    float l = lad;
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    const float l = rows4_allsum(lad, lane);
     if (g == 0) lpart[(xb * 8 + wave) * R + 16 * cblk + s16] = l;
   };
 
