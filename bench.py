@@ -47,7 +47,7 @@ def build_flow():
     return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([FEATURES])).eval()
 
 
-TRAFFIC_PROFILE = "profiles/r01c_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r01d_hbm_traffic.json"
 
 
 def measured_traffic_per_launch(entry, rows_per_launch):
@@ -249,7 +249,7 @@ def main():
             # Dominant kernel of the timed region: the conditioner's final Linear (64 -> 736) fused with the
             # spline.  Its algorithmic HBM bytes per sample: h in (4*64) + x in (4*D) + y out (4*D) + logabsdet (4);
             # the [N, 736] parameter tensor never exists in memory.  The kernel is bound by VALU issue (the
-            # spline arithmetic, ~335 VALU instructions per element), not by HBM or the matrix pipe: DESIGN.md 4.
+            # spline arithmetic, ~290 VALU instructions per element), not by HBM or the matrix pipe: DESIGN.md 4.
             f_avg = sum(fused_ms) / len(fused_ms)
             f_bytes = (4 * HIDDEN + 8 * FEATURES + 4) * rows_per_launch
             f_gbs = f_bytes / (f_avg * 1e-3) / 1e9
@@ -258,11 +258,11 @@ def main():
                                "frac": f_gbs / HBM_PEAK_GBS,
                                "traffic": measured_traffic_per_launch("fc_rq_spline_fused_linear", rows_per_launch),
                                "traffic_source": src,
-                               "kernel": "fc_rq_spline_fused_linear -> fc::rq_fused_linear_kernel3<false>",
+                               "kernel": "fc_rq_spline_fused_linear -> fc::rq_fused_linear_kernel3<false, 64, 2>",
                                "launches_timed": len(fused_ms), "avg_launch_ms": f_avg,
                                "algorithmic_bytes_per_launch": f_bytes,
                                "share_of_step": sum(fused_ms) / (1e3 * elapsed),
-                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01c_fused_sq_counters.txt",
+                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01d_fused_sq_counters.txt",
                                "matrix_pipe": {"algorithmic_tflops": flops / (f_avg * 1e-3) / 1e12,
                                                "executed_tflops": 3.0 * (24.0 / 23.0) * flops / (f_avg * 1e-3) / 1e12,
                                                "peak_f16_dense_tflops": MFMA_F16_PEAK_TFLOPS,
