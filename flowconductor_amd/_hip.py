@@ -77,6 +77,7 @@ SIGNATURES = {
     "fc_abi_version": [],
     "fc_rq_spline": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32,
                      ctypes.POINTER(RQConfig), _P],
+    "fc_rq_spline_backward": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, ctypes.POINTER(RQConfig), _P],
     "fc_standard_normal_log_prob": [_P, _P, _P, _I64, _I32, _F, _P],
     "fc_permute": [_P, _P, _P, _I64, _I32, _I64, _P],
     "fc_pointwise_affine": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],

@@ -170,6 +170,25 @@ DEFAULT_MIN_BIN_HEIGHT = 1e-3
 DEFAULT_MIN_DERIVATIVE = 1e-3
 
 
+def _rq_config(num_bins, tails, tail_bound, box, min_bin_width, min_bin_height, min_derivative,
+               enable_identity_init, wh_divisor, inverse):
+    cfg = _hip.RQConfig()
+    cfg.num_bins = num_bins
+    cfg.tails = 0 if tails is None else 1
+    cfg.inverse = 1 if inverse else 0
+    if tails == "linear":
+        cfg.left, cfg.right, cfg.bottom, cfg.top = -tail_bound, tail_bound, -tail_bound, tail_bound
+    else:
+        cfg.left, cfg.right, cfg.bottom, cfg.top = box
+    cfg.min_bin_width = min_bin_width
+    cfg.min_bin_height = min_bin_height
+    cfg.min_derivative = min_derivative
+    cfg.wh_divisor = wh_divisor
+    cfg.softplus_beta = (math.log(2) / (1 - min_derivative)) if enable_identity_init else 1.0
+    cfg.tail_constant = float(np.log(np.exp(1 - min_derivative) - 1))
+    return cfg
+
+
 def rq_spline(inputs, params, cols=None, *, num_bins, tails=None, tail_bound=1.0,
               left=0.0, right=1.0, bottom=0.0, top=1.0,
               min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
@@ -203,20 +222,8 @@ def rq_spline(inputs, params, cols=None, *, num_bins, tails=None, tail_bound=1.0
     if p.numel() != want:
         raise ValueError("params has %d elements, expected %d" % (p.numel(), want))
 
-    cfg = _hip.RQConfig()
-    cfg.num_bins = num_bins
-    cfg.tails = 0 if tails is None else 1
-    cfg.inverse = 1 if inverse else 0
-    if tails == "linear":
-        cfg.left, cfg.right, cfg.bottom, cfg.top = -tail_bound, tail_bound, -tail_bound, tail_bound
-    else:
-        cfg.left, cfg.right, cfg.bottom, cfg.top = left, right, bottom, top
-    cfg.min_bin_width = min_bin_width
-    cfg.min_bin_height = min_bin_height
-    cfg.min_derivative = min_derivative
-    cfg.wh_divisor = wh_divisor
-    cfg.softplus_beta = (math.log(2) / (1 - min_derivative)) if enable_identity_init else 1.0
-    cfg.tail_constant = float(np.log(np.exp(1 - min_derivative) - 1))
+    cfg = _rq_config(num_bins, tails, tail_bound, (left, right, bottom, top), min_bin_width, min_bin_height,
+                     min_derivative, enable_identity_init, wh_divisor, inverse)
 
     y = torch.empty_like(x) if out is None else out
     lad = torch.empty(n, dtype=torch.float32, device=x.device)
@@ -226,6 +233,63 @@ def rq_spline(inputs, params, cols=None, *, num_bins, tails=None, tail_bound=1.0
           LAD_STORE, cfg, _hip.stream_ptr(x.device))
     _finish(True)
     return y, lad
+
+
+def rq_spline_backward(inputs, params, cols, grad_outputs, grad_logabsdet, **kw):
+    """Gradients of ``rq_spline(inputs, params, cols, **kw)`` (forward direction, per-sample params):
+    returns ``(grad_inputs [N, D], grad_params [N, d_t * P])``; identity columns pass ``grad_outputs`` through."""
+    lib = _hip.load()
+    x = _prep_2d(inputs.detach())
+    p = _hip.dev_f32(params.detach(), "params")
+    gy = _hip.dev_f32(grad_outputs, "grad_outputs")
+    n, d = x.shape
+    cols = _as_cols(cols, x.device)
+    d_t = d if cols is None else cols.numel()
+    tails = kw.get("tails")
+    cfg = _rq_config(kw["num_bins"], tails, kw.get("tail_bound", 1.0),
+                     (kw.get("left", 0.0), kw.get("right", 1.0), kw.get("bottom", 0.0), kw.get("top", 1.0)),
+                     kw.get("min_bin_width", DEFAULT_MIN_BIN_WIDTH), kw.get("min_bin_height", DEFAULT_MIN_BIN_HEIGHT),
+                     kw.get("min_derivative", DEFAULT_MIN_DERIVATIVE), kw.get("enable_identity_init", False),
+                     kw.get("wh_divisor", 1.0), False)
+    gl = None if grad_logabsdet is None else _hip.dev_f32(grad_logabsdet, "grad_logabsdet")
+    gx = gy.clone()                       # identity columns: d out / d in = 1
+    gp = torch.empty_like(p)
+    _call("fc_rq_spline_backward", lib.fc_rq_spline_backward, x.device, _hip.ptr(x), _hip.ptr(p), _hip.ptr(cols),
+          _hip.ptr(gy), _hip.ptr(gl), _hip.ptr(gx), _hip.ptr(gp), n, d, d_t, cfg, _hip.stream_ptr(x.device))
+    return gx, gp.view_as(params)
+
+
+class _RQSplineFunction(torch.autograd.Function):
+    """``rq_spline`` with gradients (forward direction): the HIP forward and backward kernels behind autograd, so
+    that ``-flow.log_prob(x).mean().backward()`` trains through this path (reference: examples/toy_2d.py:57-68)."""
+
+    @staticmethod
+    def forward(ctx, inputs, params, cols, kw):
+        with torch.no_grad():
+            outputs, logabsdet = rq_spline(inputs, params, cols, **kw)
+        ctx.save_for_backward(inputs, params)
+        ctx.cols, ctx.kw = cols, kw
+        return outputs, logabsdet
+
+    @staticmethod
+    def backward(ctx, grad_outputs, grad_logabsdet):
+        inputs, params = ctx.saved_tensors
+        if grad_outputs is None:
+            grad_outputs = torch.zeros_like(inputs)
+        gx, gp = rq_spline_backward(inputs, params, ctx.cols, grad_outputs.contiguous(), grad_logabsdet, **ctx.kw)
+        return gx, gp, None, None
+
+
+def rq_spline_autograd(inputs, params, cols=None, **kw):
+    """``rq_spline`` that records an autograd node when gradients are required (forward direction, per-sample
+    parameters); otherwise exactly ``rq_spline``."""
+    needs = torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad)
+    if not needs:
+        return rq_spline(inputs, params, cols, **kw)
+    if kw.get("inverse") or kw.get("shared_params"):
+        raise RuntimeError("flowconductor_amd: gradients are implemented for the forward direction of the RQ "
+                           "spline with per-sample parameters; wrap other calls in torch.no_grad().")
+    return _RQSplineFunction.apply(inputs, params, cols, kw)
 
 
 FUSED_ROWS, FUSED_HIDDEN, FUSED_DT, FUSED_BINS = 32, 64, 32, 8
@@ -365,7 +429,7 @@ def affine_coupling(inputs, params, cols=None, *, activation=AFFINE_SIGMOID_PLUS
 
 # ---- base-distribution epilogue -----------------------------------------------------------------
 
-def standard_normal_log_prob(noise, log_z, add=None):
+def _standard_normal_log_prob_nograd(noise, log_z, add=None):
     """``-0.5 * sum(noise**2, 1) - log_z (+ add)`` -> [N]  (reference distributions/normal.py:23-33)."""
     lib = _hip.load()
     z = _hip.dev_f32(noise, "inputs")
@@ -380,6 +444,32 @@ def standard_normal_log_prob(noise, log_z, add=None):
     _call("fc_standard_normal_log_prob", lib.fc_standard_normal_log_prob, z.device, _hip.ptr(z2),
           _hip.ptr(add), _hip.ptr(out), n, z2.shape[1], float(log_z), _hip.stream_ptr(z.device))
     return out
+
+
+class _StdNormalLogProbFunction(torch.autograd.Function):
+    """Gradient of ``-0.5 * sum(z**2) - log_z + add``: ``-z`` per element, 1 for ``add`` (plain torch ops)."""
+
+    @staticmethod
+    def forward(ctx, noise, add, log_z):
+        with torch.no_grad():
+            out = _standard_normal_log_prob_nograd(noise, log_z, add)
+        ctx.save_for_backward(noise)
+        ctx.has_add = add is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (noise,) = ctx.saved_tensors
+        gz = -noise * grad.reshape((-1,) + (1,) * (noise.dim() - 1))
+        return gz, (grad if ctx.has_add else None), None
+
+
+def standard_normal_log_prob(noise, log_z, add=None):
+    """``-0.5 * sum(noise**2, 1) - log_z (+ add)`` -> [N]  (reference distributions/normal.py:23-33); records
+    an autograd node when gradients are required."""
+    if torch.is_grad_enabled() and (noise.requires_grad or (add is not None and add.requires_grad)):
+        return _StdNormalLogProbFunction.apply(noise, add, log_z)
+    return _standard_normal_log_prob_nograd(noise, log_z, add)
 
 
 # ---- permutation ----------------------------------------------------------------------------------

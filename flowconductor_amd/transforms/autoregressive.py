@@ -145,7 +145,7 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         divisor = 1.0
         if hasattr(self.autoregressive_net, "hidden_features"):
             divisor = float(np.sqrt(self.autoregressive_net.hidden_features))
-        return ops.rq_spline(
+        return ops.rq_spline_autograd(
             inputs, autoregressive_params, None, num_bins=self.num_bins, tails=self.tails,
             tail_bound=self.tail_bound, left=-1.2, right=1.2, bottom=-1.2, top=1.2,
             min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,

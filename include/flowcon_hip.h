@@ -79,6 +79,17 @@ int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const fl
                               uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t, int32_t hidden,
                               const fc_rq_config* cfg, void* stream);
 
+/* Backward of fc_rq_spline in the forward direction (what torch.autograd yields for the reference's op
+ * sequence, rational_quadratic.py:13-181; the reference trains through it, examples/toy_2d.py:57-68):
+ *   grad_x[n, cols[j]]            = gy dy/dx + gl dlogabsdet/dx      (other columns of grad_x are NOT written:
+ *                                                                      the caller passes grad_y's identity part on)
+ *   grad_params[n, j*P .. j*P+P)  = gy dy/dp + gl dlogabsdet/dp      for the P = 3K-1 (3K+1) raw values of dim j
+ * x [n, d], params [n, d_t*P] (per-sample rows only), grad_y [n, d], grad_logabsdet [n] or NULL (zeros).
+ * cfg->inverse must be 0; num_bins <= 32. */
+int fc_rq_spline_backward(const float* x, const float* params, const int32_t* cols, const float* grad_y,
+                          const float* grad_logabsdet, float* grad_x, float* grad_params, int64_t n,
+                          int32_t d, int32_t d_t, const fc_rq_config* cfg, void* stream);
+
 /* Hidden layers of the ResidualNet conditioner (flowcon/nn/nets/resnet.py:39-53, 93-99) as one kernel:
  *   h = W0 x[:, id_cols] + b0;  per block: h += W2 relu(W1 relu(h) + b1) + b2          -> h [n, 64]
  * Products on the f16 matrix cores as three-term scaled two-piece splits (f32-GEMM accuracy); a wave carries

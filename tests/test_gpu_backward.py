@@ -1,0 +1,117 @@
+"""Gradients through the HIP RQ-spline path (fc_rq_spline_backward behind torch.autograd) against
+torch.autograd on the CPU oracle -- the gradient-consistency check of SURVEY section 8(f) #3."""
+import copy
+
+import pytest
+import torch
+
+from _util import build_case, maxdiff
+from flowconductor_amd import ops
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_grads(x, params, cols, gy, gl, dtype, **kw):
+    """dL/dx[:, cols], dL/dparams for L = sum(gy * y) + sum(gl * logabsdet) by autograd on the oracle."""
+    n, d_t = x.shape[0], len(cols)
+    xt = x[:, cols].to(dtype).clone().requires_grad_(True)
+    p = params.to(dtype).clone().requires_grad_(True)
+    rows = p.view(n, d_t, -1) * 1.0     # (rq_from_rows divides slices of its argument in place)
+    out, lad = O.rq_from_rows(xt, rows, kw["num_bins"], kw.get("tails"), kw.get("tail_bound", 1.0), False,
+                              wh_divisor=kw.get("wh_divisor"), box=kw.get("box", (0.0, 1.0, 0.0, 1.0)),
+                              enable_identity_init=kw.get("enable_identity_init", False))
+    loss = (out * gy[:, cols].to(dtype)).sum() + (lad.sum(dim=1) * gl.to(dtype)).sum()
+    loss.backward()
+    return xt.grad, p.grad
+
+
+@pytest.mark.parametrize("case", ["k8_tails", "k5_tails_generic", "k8_box_identity_init", "k16_tails"])
+def test_rq_spline_backward_matches_oracle_autograd(case, device):
+    torch.manual_seed(11)
+    n, d = 512, 12
+    cols = [1, 2, 4, 5, 7, 8, 9, 11]
+    d_t = len(cols)
+    if case == "k8_tails":
+        kw = dict(num_bins=8, tails="linear", tail_bound=3.0, wh_divisor=8.0)
+        x = torch.randn(n, d) * 1.8     # some inputs beyond the tail bound
+    elif case == "k5_tails_generic":
+        kw = dict(num_bins=5, tails="linear", tail_bound=2.0, wh_divisor=1.0)
+        x = torch.randn(n, d) * 1.2
+    elif case == "k16_tails":
+        kw = dict(num_bins=16, tails="linear", tail_bound=4.0, wh_divisor=4.0)
+        x = torch.randn(n, d) * 2.0
+    else:
+        kw = dict(num_bins=8, tails=None, left=-1.2, right=1.2, bottom=-1.2, top=1.2, enable_identity_init=True)
+        x = (torch.rand(n, d) * 2 - 1) * 1.15
+    mult = 3 * kw["num_bins"] - 1 if kw.get("tails") else 3 * kw["num_bins"] + 1
+    params = torch.randn(n, d_t * mult)
+    gy, gl = torch.randn(n, d), torch.randn(n)
+    okw = dict(kw)
+    if kw.get("tails") is None:
+        okw["box"] = (kw["left"], kw["right"], kw["bottom"], kw["top"])
+        okw["wh_divisor"] = None
+    ref_gx, ref_gp = _oracle_grads(x, params, cols, gy, gl, torch.float64, **okw)
+    f32_gx, f32_gp = _oracle_grads(x, params, cols, gy, gl, torch.float32, **okw)
+
+    xd = x.to(device).requires_grad_(True)
+    pd = params.to(device).requires_grad_(True)
+    cd = torch.tensor(cols, dtype=torch.int32, device=device)
+    y, lad = ops.rq_spline_autograd(xd, pd, cd, **kw)
+    ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
+    gx, gp = xd.grad.cpu(), pd.grad.cpu()
+    # identity columns: the bijector copies them, so their gradient is the upstream one
+    idc = [c for c in range(d) if c not in cols]
+    assert torch.equal(gx[:, idc], gy[:, idc])
+    # tolerance: 1e-4 of the gradient scale + 8 x what float32 autograd on the oracle loses against float64
+    sx, sp = float(ref_gx.abs().max()), float(ref_gp.abs().max())
+    assert maxdiff(gx[:, cols].double(), ref_gx) <= 1e-4 * sx + 8 * maxdiff(f32_gx.double(), ref_gx)
+    assert maxdiff(gp.double(), ref_gp) <= 1e-4 * sp + 8 * maxdiff(f32_gp.double(), ref_gp)
+
+
+def test_coupling_layer_trains_through_hip_path(device):
+    """Parameter gradients of one RQ coupling layer (conditioner on PyTorch autograd, spline forward + backward in
+    HIP) against the oracle walked by torch.autograd on the CPU."""
+    t_cpu, _ = build_case("rq_coupling_linear_tails_d64_k8_h64")
+    t_gpu = copy.deepcopy(t_cpu).to(device).train()
+    t_cpu = t_cpu.double().train()
+    x = torch.randn(256, 64, generator=torch.Generator().manual_seed(3)) * 1.5
+    gy = torch.randn(256, 64, generator=torch.Generator().manual_seed(4))
+    gl = torch.randn(256, generator=torch.Generator().manual_seed(5))
+
+    y_ref, lad_ref = O.transform_apply(t_cpu, x.double())
+    ((y_ref * gy.double()).sum() + (lad_ref * gl.double()).sum()).backward()
+
+    with ops.KernelTimer("fc_rq_spline_backward") as timer:
+        y, lad = t_gpu(x.to(device))
+        ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
+    assert len(timer.pairs) == 1, "the backward kernel did not run"
+    assert maxdiff(y.detach().cpu().double(), y_ref.detach()) <= 2e-5 * float(y_ref.abs().max())
+    for (name, p_ref), (_, p) in zip(t_cpu.named_parameters(), t_gpu.named_parameters()):
+        assert p.grad is not None, name
+        scale = max(1e-6, float(p_ref.grad.abs().max()))
+        assert maxdiff(p.grad.cpu().double(), p_ref.grad) <= 2e-4 * scale, name
+
+
+def test_flow_loss_backward_step(device):
+    """-log_prob(x).mean().backward() + an SGD step through a 4-layer HIP flow lowers the loss (toy_2d.py:57-68)."""
+    from flowconductor_amd import distributions, flows, transforms, utils
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(0)
+    layers = [transforms.PiecewiseRationalQuadraticCouplingTransform(
+        utils.create_alternating_binary_mask(8, even=(i % 2 == 0)),
+        lambda a, b: nets.ResidualNet(a, b, hidden_features=16, num_blocks=1), num_bins=6, tails="linear",
+        tail_bound=3.0) for i in range(4)]
+    flow = flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([8])).to(device).train()
+    x = (torch.randn(2048, 8) * 0.5 + 0.7).to(device)
+    opt = torch.optim.SGD(flow.parameters(), lr=0.05)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = -flow.log_prob(x).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert losses[-1] < losses[0]
