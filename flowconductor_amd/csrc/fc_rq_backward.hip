@@ -73,7 +73,7 @@ __device__ __forceinline__ Dual7 operator*(float s, const Dual7& a) {
 }
 __device__ __forceinline__ Dual7 operator/(const Dual7& a, const Dual7& b) {
   Dual7 r;
-  const float inv = 1.f / b.v;
+  const float inv = div_lean(1.f, b.v);
   r.v = a.v * inv;
 #pragma unroll
   for (int i = 0; i < 7; ++i) r.g[i] = (a.g[i] - r.v * b.g[i]) * inv;
@@ -81,8 +81,8 @@ __device__ __forceinline__ Dual7 operator/(const Dual7& a, const Dual7& b) {
 }
 __device__ __forceinline__ Dual7 dlog(const Dual7& a) {
   Dual7 r;
-  const float inv = 1.f / a.v;
-  r.v = logf(a.v);
+  const float inv = div_lean(1.f, a.v);
+  r.v = log_lean(a.v);
 #pragma unroll
   for (int i = 0; i < 7; ++i) r.g[i] = a.g[i] * inv;
   return r;
@@ -162,13 +162,50 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(RQParams q, float inv_
     const float x = a.x[row * a.d + col];
     const float gy = a.gy[row * a.d + col];
     const float gl = a.gl ? a.gl[row] : 0.f;
-    const float* u = a.params + (row * a.d_t + j) * P;
-    float* gp = a.gp + (row * a.d_t + j) * P;
+    // The P raw values of this element are one contiguous chunk, consecutive threads own consecutive chunks:
+    // with a compile-time K they are moved as 16-byte accesses through a 4-byte aligned vector type
+    // (~P/4 memory instructions instead of P), parameters and gradients both living in registers.
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    constexpr int PS = KS > 0 ? 3 * KS + 1 : 1;   // register image (large enough for both tail modes)
+    float ureg[PS], greg[PS];
+    const float* uglob = a.params + (row * a.d_t + j) * P;
+    float* gglob = a.gp + (row * a.d_t + j) * P;
+    const float* u = uglob;
+    float* gp = gglob;
+    if constexpr (KS > 0) {
+#pragma unroll
+      for (int i = 0; i + 4 <= PS; i += 4)
+        if (i + 4 <= P) {
+          const f4u v = *reinterpret_cast<const f4u*>(uglob + i);
+          ureg[i] = v.x; ureg[i + 1] = v.y; ureg[i + 2] = v.z; ureg[i + 3] = v.w;
+        }
+#pragma unroll
+      for (int i = 0; i < PS; ++i)
+        if (i >= (P & ~3) && i < P) ureg[i] = uglob[i];
+      u = ureg;
+      gp = greg;
+    }
 
     const bool inside = (x >= q.left) && (x <= q.right);
+    auto flush = [&]() {   // register gradients -> memory
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int i = 0; i + 4 <= PS; i += 4)
+          if (i + 4 <= P) *reinterpret_cast<f4u*>(gglob + i) = f4u{greg[i], greg[i + 1], greg[i + 2], greg[i + 3]};
+#pragma unroll
+        for (int i = 0; i < PS; ++i)
+          if (i >= (P & ~3) && i < P) gglob[i] = greg[i];
+      }
+    };
     if (!inside) {   // identity tails (or, without tails, an input the forward already rejected)
       a.gx[row * a.d + col] = gy;
-      for (int i = 0; i < P; ++i) gp[i] = 0.f;
+      if constexpr (KS > 0) {
+#pragma unroll
+        for (int i = 0; i < PS; ++i) greg[i] = 0.f;
+      } else {
+        for (int i = 0; i < P; ++i) gp[i] = 0.f;
+      }
+      flush();
       continue;
     }
     float pw[KS > 0 ? KS : kMaxBinsBwd], ph[KS > 0 ? KS : kMaxBinsBwd];
@@ -183,10 +220,20 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(RQParams q, float inv_
     const float* ud = u + 2 * K;
     const int i0 = q.tails ? idx - 1 : idx, i1 = q.tails ? idx : idx + 1;      // positions in ud
     const bool has0 = !q.tails || idx > 0, has1 = !q.tails || idx < K - 1;
-    const float u0 = has0 ? ud[i0] : q.tail_const, u1 = has1 ? ud[i1] : q.tail_const;
+    float u0 = q.tail_const, u1 = q.tail_const;
+    if constexpr (KS > 0) {   // register image: static indices only
+#pragma unroll
+      for (int i = 0; i < KS + 1; ++i) {
+        if (has0 && i == i0) u0 = ud[i];
+        if (has1 && i == i1) u1 = ud[i];
+      }
+    } else {
+      if (has0) u0 = ud[i0];
+      if (has1) u1 = ud[i1];
+    }
     const float d0v = q.min_d + softplus_lean(u0, q.beta), d1v = q.min_d + softplus_lean(u1, q.beta);
-    const float s0 = (u0 * q.beta > 20.f) ? 1.f : 1.f / (1.f + expf(-u0 * q.beta));
-    const float s1 = (u1 * q.beta > 20.f) ? 1.f : 1.f / (1.f + expf(-u1 * q.beta));
+    const float s0 = (u0 * q.beta > 20.f) ? 1.f : div_lean(1.f, 1.f + exp_lean(fminf(-u0 * q.beta, 80.f)));
+    const float s1 = (u1 * q.beta > 20.f) ? 1.f : div_lean(1.f, 1.f + exp_lean(fminf(-u1 * q.beta, 80.f)));
 
     // (y, lad) as functions of (x, x_k, x_k+1, y_k, y_k+1, d_k, d_k+1): rational_quadratic.py:162-181
     const Dual7 X = dvar(x, 0), XK = dvar(xk, 1), XK1 = dvar(xk1, 2), YK = dvar(yk, 3), YK1 = dvar(yk1, 4);
@@ -220,12 +267,15 @@ __global__ __launch_bounds__(256) void rq_backward_kernel(RQParams q, float inv_
         gp[K + m] = cy * ph[m] * (gyk * (below_lo - phk) + gyk1 * (below_hi - phk1));
       }
     const int nd = P - 2 * K;
-    for (int i = 0; i < nd; ++i) {
-      float v = 0.f;
-      if (has0 && i == i0) v += gq[5] * s0;
-      if (has1 && i == i1) v += gq[6] * s1;
-      gp[2 * K + i] = v;
-    }
+#pragma unroll
+    for (int i = 0; i < (KS > 0 ? KS + 1 : kMaxBinsBwd + 1); ++i)
+      if (i < nd) {
+        float v = 0.f;
+        if (has0 && i == i0) v += gq[5] * s0;
+        if (has1 && i == i1) v += gq[6] * s1;
+        gp[2 * K + i] = v;
+      }
+    flush();
   }
 }
 

@@ -1,5 +1,5 @@
 """Times one bijector kernel in isolation on the BASELINE.json cfg-3 layer shape and prints achieved
-algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [rq|rq_inv|affine|fused|fused_inv|hidden]"""
+algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [rq|rq_inv|rq_bwd|affine|fused|fused_inv|hidden]"""
 import os
 import sys
 
@@ -18,7 +18,7 @@ def main():
     torch.manual_seed(0)
     x = torch.randn(n, d, device=dev) * 1.5
     cols = torch.arange(0, d, 2, dtype=torch.int32, device=dev)
-    if which.startswith("rq"):
+    if which in ("rq", "rq_inv"):
         p = 3 * k - 1
         params = torch.randn(n, d_t * p, device=dev)
         fn = lambda: ops.rq_spline(x, params, cols, num_bins=k, tails="linear", tail_bound=3.0,  # noqa: E731
@@ -33,6 +33,13 @@ def main():
         fn = lambda: ops.rq_spline_fused_linear(x, h, frag, bpad, cols, num_bins=k, tail_bound=3.0,  # noqa: E731
                                                 wh_divisor=8.0, inverse=which == "fused_inv")
         name = "fc_rq_spline_fused_linear"
+    elif which == "rq_bwd":
+        p = 3 * k - 1
+        params = torch.randn(n, d_t * p, device=dev)
+        gy, gl = torch.randn(n, d, device=dev), torch.randn(n, device=dev)
+        kw = dict(num_bins=k, tails="linear", tail_bound=3.0, wh_divisor=8.0)
+        fn = lambda: ops.rq_spline_backward(x, params, cols, gy, gl, **kw)  # noqa: E731
+        name = "fc_rq_spline_backward"
     elif which == "hidden":
         from flowconductor_amd.nn import nets
         p = 0
