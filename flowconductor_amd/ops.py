@@ -403,6 +403,47 @@ AFFINE_SCALE_SOFTPLUS = 6
 
 def affine_coupling(inputs, params, cols=None, *, activation=AFFINE_SIGMOID_PLUS2, inverse=False,
                     shared_params=False):
+    """Affine bijector on ``inputs[:, cols]`` with per-sample ``params`` rows; records an autograd node when
+    gradients are required (forward direction, per-sample parameters).  See ``_affine_coupling_nograd``."""
+    if torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad):
+        if inverse or shared_params:
+            raise RuntimeError("flowconductor_amd: gradients are implemented for the forward direction of the "
+                               "affine bijector with per-sample parameters; wrap other calls in torch.no_grad().")
+        return _AffineFunction.apply(inputs, params, cols, activation)
+    return _affine_coupling_nograd(inputs, params, cols, activation=activation, inverse=inverse,
+                                   shared_params=shared_params)
+
+
+class _AffineFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, params, cols, activation):
+        with torch.no_grad():
+            outputs, logabsdet = _affine_coupling_nograd(inputs, params, cols, activation=activation)
+        ctx.save_for_backward(inputs, params)
+        ctx.cols, ctx.activation = cols, activation
+        return outputs, logabsdet
+
+    @staticmethod
+    def backward(ctx, grad_outputs, grad_logabsdet):
+        inputs, params = ctx.saved_tensors
+        lib = _hip.load()
+        x = _prep_2d(inputs.detach())
+        p = _hip.dev_f32(params.detach(), "params")
+        gy = _hip.dev_f32(grad_outputs if grad_outputs is not None else torch.zeros_like(x), "grad_outputs")
+        gl = None if grad_logabsdet is None else _hip.dev_f32(grad_logabsdet, "grad_logabsdet")
+        n, d = x.shape
+        cols = _as_cols(ctx.cols, x.device)
+        d_t = d if cols is None else cols.numel()
+        gx = gy.clone()                   # identity columns pass the upstream gradient through
+        gp = torch.zeros_like(p)
+        _call("fc_affine_backward", lib.fc_affine_backward, x.device, _hip.ptr(x), _hip.ptr(p), _hip.ptr(cols),
+              _hip.ptr(gy), _hip.ptr(gl), _hip.ptr(gx), _hip.ptr(gp), n, d, d_t, ctx.activation,
+              _hip.stream_ptr(x.device))
+        return gx, gp.view_as(params), None, None
+
+
+def _affine_coupling_nograd(inputs, params, cols=None, *, activation=AFFINE_SIGMOID_PLUS2, inverse=False,
+                            shared_params=False):
     """Affine bijector on ``inputs[:, cols]`` with per-sample ``params`` rows.
 
     Row layouts per ``activation``: see ``FC_AFFINE_*`` in include/flowcon_hip.h.
@@ -474,8 +515,31 @@ def standard_normal_log_prob(noise, log_z, add=None):
 
 # ---- permutation ----------------------------------------------------------------------------------
 
+class _PermuteFunction(torch.autograd.Function):
+    """Gradient of a gather along ``dim`` = the gather by the inverse permutation (same HIP kernel)."""
+
+    @staticmethod
+    def forward(ctx, inputs, permutation, dim):
+        with torch.no_grad():
+            out = _permute_nograd(inputs, permutation, dim)
+        ctx.permutation, ctx.dim = permutation, dim
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        inverse = torch.argsort(torch.as_tensor(ctx.permutation).to(grad.device).long())
+        return _permute_nograd(grad.contiguous(), inverse, ctx.dim), None, None
+
+
 def permute(inputs, permutation, dim=1):
-    """``index_select(inputs, dim, permutation)`` bit-exactly (reference permutations.py:27-46)."""
+    """``index_select(inputs, dim, permutation)`` bit-exactly (reference permutations.py:27-46); records an
+    autograd node when gradients are required."""
+    if torch.is_grad_enabled() and inputs.requires_grad:
+        return _PermuteFunction.apply(inputs, permutation, dim)
+    return _permute_nograd(inputs, permutation, dim)
+
+
+def _permute_nograd(inputs, permutation, dim=1):
     lib = _hip.load()
     x = _hip.dev_f32(inputs, "inputs")
     _hip.require_no_grad(inputs)

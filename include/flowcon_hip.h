@@ -79,6 +79,13 @@ int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const fl
                               uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t, int32_t hidden,
                               const fc_rq_config* cfg, void* stream);
 
+/* Backward of fc_affine in the forward direction, per-sample parameters (coupling.py:234-252,
+ * autoregressive.py:97-129 under torch.autograd): grad_x[n, cols[j]] = gy s; grad_params in the layout of
+ * `params` for the same `activation`.  Other columns of grad_x are NOT written. */
+int fc_affine_backward(const float* x, const float* params, const int32_t* cols, const float* grad_y,
+                       const float* grad_logabsdet, float* grad_x, float* grad_params, int64_t n,
+                       int32_t d, int32_t d_t, int32_t activation, void* stream);
+
 /* Backward of fc_rq_spline in the forward direction (what torch.autograd yields for the reference's op
  * sequence, rational_quadratic.py:13-181; the reference trains through it, examples/toy_2d.py:57-68):
  *   grad_x[n, cols[j]]            = gy dy/dx + gl dlogabsdet/dx      (other columns of grad_x are NOT written:
