@@ -38,7 +38,8 @@ class CompositeTransform(Transform):
         with ops.deferred_errors():
             for t in transforms:
                 fused = getattr(t, "_apply_accumulate", None)
-                if fused is not None and total_logabsdet.dtype == torch.float32:
+                hooked = t._forward_hooks or t._forward_pre_hooks   # the fast path does not go through __call__
+                if fused is not None and not hooked and total_logabsdet.dtype == torch.float32:
                     outputs = fused(outputs, context, inverse, total_logabsdet)
                 else:
                     outputs, logabsdet = (t.inverse if inverse else t)(outputs, context)

@@ -179,3 +179,29 @@ def test_composite_accumulates_logabsdet_in_kernel(n, inverse, device):
             ref_total += lad
     assert torch.equal(y, out)
     assert torch.equal(total, ref_total)
+
+
+@pytest.mark.parametrize("d,n", [(36, 96), (48, 4096), (64, 32), (96, 2080), (112, 640), (128, 1056)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fused_linear_input_widths(d, n, inverse, device):
+    """The fused kernel's tile variants: 64-row tiles with 1 / 2 / 4 float4 of x per thread (D <= 32 / 64 /
+    112), 32-row tiles for wider inputs and for the last 32 rows of an odd multiple of 32."""
+    torch.manual_seed(d)
+    d_t, k, hidden = 32, 8, 64
+    x = torch.randn(n, d) * 1.5
+    h = torch.relu(torch.randn(n, hidden)) * 1.5 + torch.randn(n, hidden) * 0.2
+    w = torch.randn(d_t * (3 * k - 1), hidden) * 0.2
+    b = torch.randn(d_t * (3 * k - 1)) * 0.1
+    cols = torch.randperm(d)[:d_t].sort().values
+    rows = (h.double() @ w.double().T + b.double()).float().view(n, d_t, 3 * k - 1).clone()
+    out, lad_e = O.rq_from_rows(x[:, cols], rows, k, "linear", 3.0, inverse, wh_divisor=float(hidden) ** 0.5)
+    ref_y = x.clone()
+    ref_y[:, cols] = out
+    ref_lad = lad_e.sum(dim=1)
+    wp, bp = ops.pack_final_layer(w.to(device), b.to(device))
+    with torch.no_grad():
+        y, lad = ops.rq_spline_fused_linear(x.to(device), h.to(device), wp, bp, cols.to(device), num_bins=k,
+                                            tail_bound=3.0, wh_divisor=float(hidden) ** 0.5, inverse=inverse)
+    tol_y, tol_l = (2e-5, 2e-4) if not inverse else (3e-4, 3e-3)
+    assert maxdiff(y, ref_y) <= tol_y * max(1.0, float(ref_y.abs().max()))
+    assert maxdiff(lad, ref_lad) <= tol_l * max(1.0, float(ref_lad.abs().max()) / 10)
