@@ -1,11 +1,13 @@
 #!/bin/bash
-# SQ counters of the fused kernel (tools/bench_kernel.py fused), a few counters per pass.
-# Usage on the GPU box: bash tools/probe/pmc_fused.sh <tag>   -> gpurun_out/pmc_fused_<tag>/summary.txt
+# SQ counters of one kernel of tools/bench_kernel.py <kind> (kernel symbol substring <match>), a few counters per pass.
+# Usage on the GPU box: bash tools/probe/pmc_kernel.sh <tag> <kind> <match>
 set -u
 TAG=${1:-x}
+KIND=${2:-fused}
+MATCH=${3:-rq_fused_linear}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-OUT=$R/gpurun_out/pmc_fused_$TAG
+OUT=$R/gpurun_out/pmc_${KIND}_$TAG
 mkdir -p $OUT
 cd /tmp
 i=0
@@ -16,7 +18,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS_F32" \
            "GRBM_GUI_ACTIVE SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  LOG2N=${LOG2N:-20} rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/bench_kernel.py fused > $OUT/p$i.log 2>&1
+  LOG2N=${LOG2N:-20} rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/bench_kernel.py $KIND > $OUT/p$i.log 2>&1
   echo "pass $i exit $?"
 done
 cd $R
@@ -25,7 +27,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "rq_fused_linear" in r["Kernel_Name"]:
+        if "$MATCH" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as o:
     for k in sorted(acc):
