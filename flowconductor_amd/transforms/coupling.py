@@ -96,7 +96,7 @@ class CouplingTransform(Transform):
         if inverse and self.unconditional_transform is not None:
             identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
 
-        transform_params = self.transform_net(identity_split, context)
+        transform_params = self._conditioner(inputs, identity_split, context)
 
         if inputs.dim() == 4:
             rows, shape = _rows_from_nchw(inputs)
@@ -113,6 +113,27 @@ class CouplingTransform(Transform):
             outputs[:, self.identity_features, ...] = identity_split
             logabsdet = logabsdet + logabsdet_identity
         return outputs, logabsdet
+
+    def _conditioner(self, inputs, identity_split, context):
+        """``transform_net(identity_split, context)``.  For this package's ResidualNet with the shape
+        ``fc_resnet_hidden`` covers (hidden 64, <= 2 blocks, ReLU) the hidden layers run in that one kernel,
+        straight from the full input rows, and only the final Linear stays a library GEMM -- for every coupling
+        bijector (affine, additive, all splines), inference only."""
+        from flowconductor_amd.nn.nets.resnet import ResidualNet
+
+        net = self.transform_net
+        n = inputs.shape[0]
+        if (type(net) is ResidualNet and context is None and self.unconditional_transform is None
+                and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32 and n >= ops.HIDDEN_ROWS
+                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0" and net.hip_hidden_supported(inputs.shape[1])
+                and not (torch.is_grad_enabled()
+                         and (inputs.requires_grad or any(p.requires_grad for p in net.parameters())))):
+            body = n - n % ops.HIDDEN_ROWS
+            hidden = net.hidden_hip(inputs[:body], self._id_cols(inputs.device))
+            if body < n:
+                hidden = torch.cat((hidden, net.hidden(identity_split[body:], context)))
+            return net.final_layer(hidden)
+        return net(identity_split, context)
 
     def forward(self, inputs, context=None):
         return self._run(inputs, context, inverse=False)
