@@ -4,6 +4,8 @@
 sequential MADE passes, each followed by the element-wise inverse kernel on all dims
 (reference autoregressive.py:39-53 -- same fixed-point iteration, same cost model).
 """
+import os
+
 import numpy as np
 import torch
 from torch.nn import functional as F
@@ -23,8 +25,26 @@ class AutoregressiveTransform(Transform):
         super().__init__()
         self.autoregressive_net = autoregressive_net
 
+    def _conditioner(self, inputs, context):
+        """``autoregressive_net(inputs, context)``; a MADE whose hidden stack ``fc_resnet_hidden`` covers (hidden
+        64, residual blocks, ReLU, no context) runs it there on pre-masked weights -- inference only."""
+        net = self.autoregressive_net
+        n = inputs.shape[0]
+        if (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and n >= ops.HIDDEN_ROWS and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
+                and getattr(net, "hip_hidden_supported", None) is not None and net.hip_hidden_supported()
+                and hasattr(net, "final_layer")
+                and not (torch.is_grad_enabled()
+                         and (inputs.requires_grad or any(p.requires_grad for p in net.parameters())))):
+            body = n - n % ops.HIDDEN_ROWS
+            hidden = net.hidden_hip(inputs[:body].contiguous())
+            if body < n:
+                hidden = torch.cat((hidden, net.hidden(inputs[body:])))
+            return net.final_layer(hidden)
+        return net(inputs, context)
+
     def forward(self, inputs, context=None):
-        autoregressive_params = self.autoregressive_net(inputs, context)
+        autoregressive_params = self._conditioner(inputs, context)
         return self._elementwise_forward(inputs, autoregressive_params)
 
     def inverse(self, inputs, context=None):
@@ -33,7 +53,7 @@ class AutoregressiveTransform(Transform):
         logabsdet = None
         with ops.deferred_errors():
             for _ in range(num_inputs):
-                autoregressive_params = self.autoregressive_net(outputs, context)
+                autoregressive_params = self._conditioner(outputs, context)
                 outputs, logabsdet = self._elementwise_inverse(inputs, autoregressive_params)
         return outputs, logabsdet
 

@@ -149,7 +149,8 @@ class MADE(nn.Module):
                                         autoregressive_features=features, random_mask=random_mask,
                                         is_output=True)
 
-    def forward(self, inputs, context=None):
+    def hidden(self, inputs, context=None):
+        """Everything before the final masked Linear."""
         h = self.initial_layer(inputs)
         if context is not None:
             h = h + self.activation(self.context_layer(context))
@@ -157,4 +158,42 @@ class MADE(nn.Module):
             h = self.activation(h)
         for block in self.blocks:
             h = block(h, context)
-        return self.final_layer(h)
+        return h
+
+    def forward(self, inputs, context=None):
+        return self.final_layer(self.hidden(inputs, context))
+
+    # ---- device fast path for the hidden layers (inference) ------------------------------------------
+    # With residual blocks a MADE has exactly the layer structure of the ResidualNet (made.py:205-283 vs
+    # nn/nets/resnet.py:55-100); with the masks multiplied into the weights once its
+    # hidden stack runs in the same kernel, fc_resnet_hidden.
+    def hip_hidden_supported(self):
+        def is_relu(f):
+            return isinstance(f, torch.nn.ReLU) or f is F.relu or f is torch.relu
+
+        if (not self.use_residual_blocks or hasattr(self, "context_layer") or len(self.blocks) > 2
+                or self.initial_layer.out_features != 64 or self.initial_layer.in_features > 64
+                or not is_relu(self.activation)):
+            return False
+        for block in self.blocks:
+            if block.use_batch_norm or not is_relu(block.activation) or hasattr(block, "context_layer"):
+                return False
+            if block.dropout.p > 0 and self.training:
+                return False
+        return True
+
+    def hidden_hip(self, rows):
+        """h [N, 64] of ``rows`` [N, features] (N a multiple of 16) by ``fc_resnet_hidden`` on pre-masked weights."""
+        from flowconductor_amd import ops
+
+        layers = [self.initial_layer] + [lin for block in self.blocks for lin in block.linear_layers]
+        key = tuple((lin.weight._version, lin.bias._version, lin.weight.data_ptr()) for lin in layers)
+        if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
+            masked = [(lin.weight * lin.mask).detach().contiguous() for lin in layers]
+            biases = [lin.bias.detach() for lin in layers]
+            wb = torch.stack(masked[1:]).contiguous() if len(masked) > 1 else None
+            bb = torch.stack(biases[1:]).contiguous() if len(biases) > 1 else None
+            ids = torch.arange(self.initial_layer.in_features, dtype=torch.int32, device=rows.device)
+            self._hip_packed = (key, (masked[0], biases[0].contiguous(), wb, bb), ids)
+        return ops.resnet_hidden(rows, self._hip_packed[2], self._hip_packed[1], self.initial_layer.in_features,
+                                 len(self.blocks))

@@ -205,3 +205,40 @@ def test_fused_linear_input_widths(d, n, inverse, device):
     tol_y, tol_l = (2e-5, 2e-4) if not inverse else (3e-4, 3e-3)
     assert maxdiff(y, ref_y) <= tol_y * max(1.0, float(ref_y.abs().max()))
     assert maxdiff(lad, ref_lad) <= tol_l * max(1.0, float(ref_lad.abs().max()) / 10)
+
+
+@pytest.mark.parametrize("kind", ["maf", "rq_ar"])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_made_hidden_stack_on_hip_kernel(kind, inverse, device, monkeypatch):
+    """A MADE with hidden 64 / residual blocks runs its hidden stack in fc_resnet_hidden on pre-masked weights
+    (both for the single forward pass and for each of the D passes of the inverse); result vs the oracle and vs
+    the PyTorch-ROCm conditioner."""
+    from flowconductor_amd import transforms
+
+    torch.manual_seed(21)
+    if kind == "maf":
+        t = transforms.MaskedAffineAutoregressiveTransform(features=6, hidden_features=64, num_blocks=2)
+    else:
+        t = transforms.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+            features=6, hidden_features=64, num_blocks=2, num_bins=8, tails="linear", tail_bound=3.0)
+    t.eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    x = torch.randn(1000, 6) * 1.2
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(t, x.clone(), inverse=inverse)
+    t = t.to(device)
+    fn = t.inverse if inverse else t.forward
+    with torch.no_grad():
+        assert t.autoregressive_net.hip_hidden_supported()
+        with ops.KernelTimer("fc_resnet_hidden") as timer:
+            y, lad = fn(x.to(device))
+        assert len(timer.pairs) == (6 if inverse else 1), "the hidden-layer kernel did not run"
+        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        y2, lad2 = fn(x.to(device))
+    scale = max(1.0, float(ref_y.abs().max()))
+    tol = 3e-4 if inverse else 2e-5      # the inverse chains D conditioner passes
+    assert maxdiff(y, ref_y) <= tol * scale
+    assert maxdiff(lad, ref_lad) <= 10 * tol * max(1.0, float(ref_lad.abs().max()) / 10)
+    assert maxdiff(y, y2) <= tol * scale
