@@ -1,0 +1,220 @@
+// Shared-weight Sylvester flow on the matrix cores, gfx950.
+//
+//   z -> y = z + Q R2 tanh(R1 Q^T z + b),   logabsdet = sum_i log(1 + (1 - tanh^2(.)_i) diag(R1)_i diag(R2)_i)
+//
+// (flowcon/transforms/no_analytic_inv/planar.py:144-166; Q = product of M Householder reflections,
+// orthogonal.py:63-85.)  With parameters shared across the batch the two chains Q^T -> R1 and R2 -> Q are
+// fixed D x D matrices: W1 = R1 Q^T, W2 = Q R2 (formed once per call by the host, in float64), and the batch
+// sees two dense [N, D] x [D, D] products -- the one place of the path that is a true dense contraction
+// (BASELINE.json north_star).  They run as three-term scaled two-piece f16 splits (fc_split.h) with the
+// structure of fc_resnet_hidden.hip: a wave carries 16 samples through both products in registers, weight
+// rows ordered so that the C layout of the first product is the B operand layout of the second
+// (tile t, row 4g + r <-> feature 32 (t >> 1) + 8 g + 4 (t & 1) + r), weights of both products as ready-made
+// A fragments in LDS (128 KB at D = 128).  The row-per-wave VALU kernel (fc_rowwave.hip) stays for
+// per-sample parameters and other widths: 3.4 ms per 2^18 x 128 rows there, ~0.1 ms here.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fc_split.h"
+#include "fc_lane.h"
+#include "../../include/flowcon_hip.h"
+
+namespace fc {
+
+constexpr int kSylThreads = 512;
+
+struct SylArgs {
+  const float* x;      // [N, F]
+  float* y;            // [N, F]
+  float* lad;          // [N]
+  const float* w1;     // [F, F] row-major: pre = W1 z + b
+  const float* w2;     // [F, F]: y = z + W2 tanh(pre)
+  const float* bias;   // [F]
+  const float* rdiag;  // [F] diag(R1) * diag(R2)
+  int64_t blocks16;
+};
+
+__host__ __device__ constexpr int syl_feat(int t, int g, int r) { return 32 * (t >> 1) + 8 * g + 4 * (t & 1) + r; }
+
+// F = 32 KS features: NT = 2 KS accumulator tiles per lane group, KS k-steps
+template <int KS>
+__global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
+  constexpr int F = 32 * KS, NT = 2 * KS;
+  constexpr int kFragL = KS * NT * 2;   // fragments of one product: [ks][t][piece]
+  extern __shared__ __attribute__((aligned(16))) unsigned char ssmem[];
+  f16x8* wfrag = reinterpret_cast<f16x8*>(ssmem);                       // [2][KS][NT][2][64]
+  float* bias = reinterpret_cast<float*>(ssmem + (size_t)2 * kFragL * 64 * 16);   // [g][NT * 4]
+  float* rdg = bias + 4 * NT * 4;                                        // [g][NT * 4]
+  float* wun = rdg + 4 * NT * 4;                                         // [2]
+  float* red = wun + 8;                                                  // [8]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s16 = lane & 15, g = lane >> 4;
+
+  // ---- once per workgroup: scale, split and lay out both matrices ------------------------------------
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const float* w = l == 0 ? a.w1 : a.w2;
+    float m = 0.f;
+    for (int i = tid; i < F * F; i += kSylThreads) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __syncthreads();
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = red[0];
+#pragma unroll
+    for (int i = 1; i < kSylThreads / 64; ++i) m = fmaxf(m, red[i]);
+    float sc, un;
+    pow2_scale(m, sc, un);
+    if (tid == 0) wun[l] = un;
+    // fragment entry e = (ks * NT + t) * 64 + lane': W[feat(t, lane' & 15)][32 ks + 8 (lane' >> 4) + j]
+    for (int e = tid; e < KS * NT * 64; e += kSylThreads) {
+      const int ln = e & 63, t = (e >> 6) % NT, ks = (e >> 6) / NT;
+      const int rho = ln & 15, f = syl_feat(t, rho >> 2, rho & 3);
+      f16x8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 32 * ks + 8 * (ln >> 4) + j;
+        _Float16 ph, pl;
+        split2(w[(size_t)f * F + k] * sc, ph, pl);
+        hi[j] = ph;
+        lo[j] = pl;
+      }
+      wfrag[(l * kFragL + (ks * NT + t) * 2 + 0) * 64 + ln] = hi;
+      wfrag[(l * kFragL + (ks * NT + t) * 2 + 1) * 64 + ln] = lo;
+    }
+  }
+  for (int i = tid; i < 4 * NT * 4; i += kSylThreads) {   // accumulator order: [g][t * 4 + r]
+    const int gg = i / (NT * 4), t = (i / 4) % NT, r = i & 3;
+    bias[i] = a.bias[syl_feat(t, gg, r)];
+    rdg[i] = a.rdiag[syl_feat(t, gg, r)];
+  }
+  __syncthreads();
+
+  // B operand from this lane's NT * 4 values: scale by the row maximum, split
+  auto make_operand = [&](const f32x4 (&v)[NT], f16x8 (&bh)[KS], f16x8 (&bl)[KS]) {
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(v[t][r]));
+    m = rows4_allmax(m, lane);
+    float sc, un;
+    pow2_scale(m, sc, un);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        _Float16 ph, pl;
+        split2(v[t][r] * sc, ph, pl);
+        bh[t >> 1][4 * (t & 1) + r] = ph;
+        bl[t >> 1][4 * (t & 1) + r] = pl;
+      }
+    return un;
+  };
+  // acc = (scaled W_l) (scaled v)^T: three split terms, small ones first; consecutive MFMAs on different tiles
+  auto product = [&](int l, const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], f32x4 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f16x8* wf = wfrag + (size_t)l * kFragL * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f16x8 wl = wf[((ks * NT + t) * 2 + 1) * 64];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[ks], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f16x8 wh[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wh[t] = wf[((ks * NT + t) * 2 + 0) * 64];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl[ks], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh[ks], acc[t], 0, 0, 0);
+    }
+  };
+
+  const int64_t nwaves = (int64_t)gridDim.x * (kSylThreads / 64);
+  for (int64_t blk = (int64_t)blockIdx.x * (kSylThreads / 64) + wave; blk < a.blocks16; blk += nwaves) {
+    asm volatile("" ::: "memory");   // keeps the loop-invariant LDS fragment loads inside the loop
+    // lane (s, g) holds features 32 ks + 8 g + j of sample s: tile 2 ks + (j >> 2), register j & 3
+    const float4* xrow = reinterpret_cast<const float4*>(a.x + (blk * 16 + s16) * F);
+    f32x4 z[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 v = xrow[8 * (t >> 1) + 2 * g + (t & 1)];
+      z[t] = f32x4{v.x, v.y, v.z, v.w};
+    }
+    f16x8 bh[KS], bl[KS];
+    f32x4 acc[NT];
+    float un = make_operand(z, bh, bl);
+    product(0, bh, bl, acc);
+    const f32x4* bsrc = reinterpret_cast<const f32x4*>(bias + g * NT * 4);
+    const f32x4* rsrc = reinterpret_cast<const f32x4*>(rdg + g * NT * 4);
+    float c = un * wun[0];
+    float lsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 b = bsrc[t], rd = rsrc[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float act = tanhf(__builtin_fmaf(acc[t][r], c, b[r]));     // tanh(R1 Q^T z + b)
+        acc[t][r] = act;
+        lsum += logf(1.f + (1.f - act * act) * rd[r]);                    // planar.py:160-163
+      }
+    }
+    un = make_operand(acc, bh, bl);
+    product(1, bh, bl, acc);
+    c = un * wun[1];
+    float4* yrow = reinterpret_cast<float4*>(a.y + (blk * 16 + s16) * F);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      yrow[8 * (t >> 1) + 2 * g + (t & 1)] = float4{z[t][0] + acc[t][0] * c, z[t][1] + acc[t][1] * c,
+                                                    z[t][2] + acc[t][2] * c, z[t][3] + acc[t][3] * c};
+    lsum = rows4_allsum(lsum, lane);
+    if (g == 0) a.lad[blk * 16 + s16] = lsum;
+  }
+}
+
+template <int KS>
+static hipError_t launch_syl(const SylArgs& a, int cus, hipStream_t s) {
+  constexpr int NT = 2 * KS;
+  const size_t lds = (size_t)2 * KS * NT * 2 * 64 * 16 + (2 * 4 * NT * 4 + 16) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sylvester_mm_kernel<KS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  int64_t grid = cus;
+  const int64_t need = (a.blocks16 + 7) / 8;
+  if (grid > need) grid = need;
+  hipLaunchKernelGGL(sylvester_mm_kernel<KS>, dim3((unsigned)grid), dim3(kSylThreads), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace fc
+
+extern "C" int fc_sylvester_mm(const float* x, float* y, float* logabsdet, const float* w1, const float* w2,
+                               const float* bias, const float* r_diag_prod, int64_t n, int32_t d, void* stream) {
+  if (n < 0 || d <= 0 || d % 32 != 0 || d > 128 || n % 16 != 0) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!x || !y || !logabsdet || !w1 || !w2 || !bias || !r_diag_prod) return hipErrorInvalidValue;
+  if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return hipErrorInvalidValue;
+  fc::SylArgs a{x, y, logabsdet, w1, w2, bias, r_diag_prod, n / 16};
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    cus = prop.multiProcessorCount;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (d / 32) {
+    case 1: return fc::launch_syl<1>(a, cus * 2, s);
+    case 2: return fc::launch_syl<2>(a, cus * 2, s);
+    case 3: return fc::launch_syl<3>(a, cus, s);
+    default: return fc::launch_syl<4>(a, cus, s);
+  }
+}

@@ -732,6 +732,55 @@ def sylvester(inputs, q_vectors, r1, r2, bias):
     return y, lad
 
 
+SYLVESTER_MM_ROWS = 16
+
+
+def sylvester_mm_supported(n, d):
+    """Shapes of the matrix-core Sylvester kernel (shared parameters only)."""
+    return d % 32 == 0 and d <= 128 and n >= SYLVESTER_MM_ROWS
+
+
+def householder_matrix(q_vectors, reverse=False):
+    """[D, D] float64 matrix M with ``householder(v, q, reverse) == v @ M`` (rows as vectors): the K reflections
+    of orthogonal.py:144-171 applied to the identity.  Host-side helper for batch-independent parameters."""
+    q = q_vectors.detach().double()
+    if reverse:
+        q = q.flip(0)
+    m = torch.eye(q.shape[1], dtype=torch.float64, device=q.device)
+    for i in range(q.shape[0]):
+        qi = q[i]
+        m = m - torch.outer(m @ qi, (2.0 / (qi @ qi)) * qi)
+    return m
+
+
+def pack_sylvester(q_vectors, r1, r2):
+    """(W1, W2, r_diag_prod) of ``fc_sylvester_mm`` from the reference's parameters: with rows as vectors
+    Q^T z = z @ Mr (reflections in reverse order) and Q v = v @ Mf, so W1 = R1 Mr^T and W2 = Mf^T R2; formed in
+    float64, rounded once."""
+    mr = householder_matrix(q_vectors, reverse=True)
+    mf = householder_matrix(q_vectors, reverse=False)
+    w1 = (r1.detach().double() @ mr.T).float().contiguous()
+    w2 = (mf.T @ r2.detach().double()).float().contiguous()
+    rdiag = (torch.diagonal(r1.detach()) * torch.diagonal(r2.detach())).float().contiguous()
+    return w1, w2, rdiag
+
+
+def sylvester_mm(inputs, w1, w2, bias, rdiag):
+    """Sylvester flow forward + logabsdet with shared parameters as two matrix-core products (rows a multiple of 16)."""
+    lib = _hip.load()
+    x = _rows(inputs)
+    _hip.require_no_grad(inputs)
+    n, d = x.shape
+    if n % SYLVESTER_MM_ROWS != 0 or not sylvester_mm_supported(n, d):
+        raise ValueError("fc_sylvester_mm: unsupported shape %s" % (tuple(x.shape),))
+    bv = _param(bias, x.device, "bias")
+    y = torch.empty_like(x)
+    lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    _call("fc_sylvester_mm", lib.fc_sylvester_mm, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(lad), _hip.ptr(w1),
+          _hip.ptr(w2), _hip.ptr(bv), _hip.ptr(rdiag), n, d, _hip.stream_ptr(x.device))
+    return y, lad
+
+
 # ---- element-wise non-linearities -----------------------------------------------------------------
 
 EW_EXP, EW_TANH, EW_LOGTANH, EW_LEAKY_RELU, EW_SIGMOID, EW_SOFTPLUS, EW_CAUCHY_CDF = range(7)

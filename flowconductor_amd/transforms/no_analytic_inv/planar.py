@@ -2,6 +2,8 @@
 
 Forward direction only, like the reference.  Each is one fused row-per-wavefront HIP kernel.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -88,8 +90,30 @@ class SylvesterTransform(Transform):
     def h(self, x):
         return torch.tanh(x)
 
+    def _mm_weights(self):
+        """(W1, W2, r_diag_prod) for the matrix-core kernel, recomputed only when a parameter changed."""
+        params = (self.Q_orth.q_vectors, self.upper_entries1, self.log_upper_diag1, self.upper_entries2,
+                  self.log_upper_diag2)
+        key = tuple((p._version, p.data_ptr()) for p in params)
+        if getattr(self, "_mm_cache", None) is None or self._mm_cache[0] != key:
+            self._mm_cache = (key, ops.pack_sylvester(self.Q_orth.q_vectors, self._create_R1(), self._create_R2()))
+        return self._mm_cache[1]
+
     def forward(self, inputs, context=None):
         with torch.no_grad():
+            n = inputs.shape[0]
+            if (inputs.dim() == 2 and inputs.is_cuda and ops.sylvester_mm_supported(n, self.features)
+                    and os.environ.get("FC_SYLVESTER_MM", "1") != "0"):
+                # batch-independent parameters: the Householder / triangular chains fold into two dense
+                # [D, D] matrices and the batch goes through the matrix cores
+                w1, w2, rdiag = self._mm_weights()
+                body = n - n % ops.SYLVESTER_MM_ROWS
+                y, lad = ops.sylvester_mm(inputs[:body], w1, w2, self.bias, rdiag)
+                if body < n:
+                    y2, lad2 = ops.sylvester(inputs[body:], self.Q_orth.q_vectors, self._create_R1(),
+                                             self._create_R2(), self.bias)
+                    y, lad = torch.cat((y, y2)), torch.cat((lad, lad2))
+                return y, lad
             return ops.sylvester(inputs, self.Q_orth.q_vectors, self._create_R1(), self._create_R2(), self.bias)
 
     def inverse(self, inputs, context=None):

@@ -257,6 +257,13 @@ int fc_sylvester(const float* x, float* y, float* logabsdet, const float* q, con
                  const float* r2_t, const float* bias, const float* r_diag_prod, int64_t n, int32_t d,
                  int32_t num_householder, int32_t per_sample, void* stream);
 
+/* Shared-weight Sylvester flow as two dense products on the matrix cores (planar.py:144-166 with the batch-
+ * independent chains folded into W1 = R1 Q^T and W2 = Q R2, both [d, d] row-major):
+ *   y = x + W2 tanh(W1 x + bias),  logabsdet[n] = sum_i log(1 + (1 - tanh^2(.)_i) r_diag_prod_i).
+ * d % 32 == 0, d <= 128, n % 16 == 0, x / y 16-byte aligned.  Products: three-term scaled f16 splits. */
+int fc_sylvester_mm(const float* x, float* y, float* logabsdet, const float* w1, const float* w2,
+                    const float* bias, const float* r_diag_prod, int64_t n, int32_t d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,7 @@
 """Row-per-wavefront kernels with PER-SAMPLE parameters (the conditional forms of SURVEY.md 8f #1)
 and misc. element-wise ops that the golden cases do not reach: HIP vs CPU oracle."""
+import copy
+
 import pytest
 import torch
 
@@ -169,3 +171,36 @@ def test_per_sample_lu_round_trip(d, device):
     assert maxdiff(xb, x) <= 5e-4 * scale and maxdiff(lad + ladb, torch.zeros(n)) <= 1e-4
     assert maxdiff(mt, (m @ x.unsqueeze(-1)).squeeze(-1)) <= 2e-5 * scale
     assert maxdiff(mtt, (m.transpose(-2, -1) @ x.unsqueeze(-1)).squeeze(-1)) <= 2e-5 * scale
+
+
+@pytest.mark.parametrize("d,m,n", [(32, 8, 64), (64, 16, 1000), (96, 32, 48), (128, 32, 4096)])
+def test_sylvester_matrix_core_path(d, m, n, device, monkeypatch):
+    """Shared-weight Sylvester flow as two matrix-core products (fc_sylvester_mm) against the oracle's reflection-
+    by-reflection evaluation in float64 and against the row-per-wave kernel."""
+    from flowconductor_amd import ops
+    from flowconductor_amd.transforms import SylvesterTransform
+    from oracle import torch_oracle as O
+
+    torch.manual_seed(d)
+    t = SylvesterTransform(features=d, num_householder=m, device=None).eval()
+    with torch.no_grad():
+        t.Q_orth.q_vectors.copy_(torch.randn(m, d))
+        t.bias.copy_(torch.randn(d) * 0.3)
+        t.upper_entries1.mul_(2.0)
+        t.upper_entries2.mul_(2.0)
+    x = torch.randn(n, d)
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(copy.deepcopy(t).double(), x.double())
+        f32_y, f32_lad = O.transform_apply(t, x)
+    t = t.to(device)
+    with torch.no_grad():
+        with ops.KernelTimer("fc_sylvester_mm") as timer:
+            y, lad = t(x.to(device))
+        assert len(timer.pairs) == 1, "the matrix-core kernel did not run"
+        monkeypatch.setenv("FC_SYLVESTER_MM", "0")
+        y2, lad2 = t(x.to(device))
+    sy, sl = max(1.0, float(ref_y.abs().max())), max(1.0, float(ref_lad.abs().max()))
+    fy, fl = maxdiff(f32_y.double(), ref_y), maxdiff(f32_lad.double(), ref_lad)
+    assert maxdiff(y.cpu().double(), ref_y) <= 1e-5 * sy + 4 * fy
+    assert maxdiff(lad.cpu().double(), ref_lad) <= 1e-5 * sl + 4 * fl
+    assert maxdiff(y, y2) <= 2e-5 * sy and maxdiff(lad, lad2) <= 2e-5 * sl + 8 * fl
