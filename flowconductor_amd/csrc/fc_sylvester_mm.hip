@@ -36,7 +36,9 @@ struct SylArgs {
 __host__ __device__ constexpr int syl_feat(int t, int g, int r) { return 32 * (t >> 1) + 8 * g + 4 * (t & 1) + r; }
 
 // F = 32 KS features: NT = 2 KS accumulator tiles per lane group, KS k-steps
-template <int KS>
+// kDense: only the first product, y = W1 z + b (a dense linear layer with batch-independent weights: LU / Linear
+// forward, a Householder sequence folded into its orthogonal matrix)
+template <int KS, bool kDense>
 __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
   constexpr int F = 32 * KS, NT = 2 * KS;
   constexpr int kFragL = KS * NT * 2;   // fragments of one product: [ks][t][piece]
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
 
   // ---- once per workgroup: scale, split and lay out both matrices ------------------------------------
 #pragma unroll
-  for (int l = 0; l < 2; ++l) {
+  for (int l = 0; l < (kDense ? 1 : 2); ++l) {
     const float* w = l == 0 ? a.w1 : a.w2;
     float m = 0.f;
     for (int i = tid; i < F * F; i += kSylThreads) m = fmaxf(m, fabsf(w[i]));
@@ -86,8 +88,8 @@ __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
   }
   for (int i = tid; i < 4 * NT * 4; i += kSylThreads) {   // accumulator order: [g][t * 4 + r]
     const int gg = i / (NT * 4), t = (i / 4) % NT, r = i & 3;
-    bias[i] = a.bias[syl_feat(t, gg, r)];
-    rdg[i] = a.rdiag[syl_feat(t, gg, r)];
+    bias[i] = a.bias ? a.bias[syl_feat(t, gg, r)] : 0.f;
+    rdg[i] = kDense ? 0.f : a.rdiag[syl_feat(t, gg, r)];
   }
   __syncthreads();
 
@@ -155,6 +157,17 @@ __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
     const f32x4* bsrc = reinterpret_cast<const f32x4*>(bias + g * NT * 4);
     const f32x4* rsrc = reinterpret_cast<const f32x4*>(rdg + g * NT * 4);
     float c = un * wun[0];
+    if constexpr (kDense) {
+      float4* yrow = reinterpret_cast<float4*>(a.y + (blk * 16 + s16) * F);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 b = bsrc[t];
+        yrow[8 * (t >> 1) + 2 * g + (t & 1)] =
+            float4{__builtin_fmaf(acc[t][0], c, b[0]), __builtin_fmaf(acc[t][1], c, b[1]),
+                   __builtin_fmaf(acc[t][2], c, b[2]), __builtin_fmaf(acc[t][3], c, b[3])};
+      }
+      continue;
+    }
     float lsum = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -179,13 +192,13 @@ __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
   }
 }
 
-template <int KS>
+template <int KS, bool kDense>
 static hipError_t launch_syl(const SylArgs& a, int cus, hipStream_t s) {
   constexpr int NT = 2 * KS;
   const size_t lds = (size_t)2 * KS * NT * 2 * 64 * 16 + (2 * 4 * NT * 4 + 16) * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sylvester_mm_kernel<KS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sylvester_mm_kernel<KS, kDense>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
@@ -193,7 +206,7 @@ static hipError_t launch_syl(const SylArgs& a, int cus, hipStream_t s) {
   int64_t grid = cus;
   const int64_t need = (a.blocks16 + 7) / 8;
   if (grid > need) grid = need;
-  hipLaunchKernelGGL(sylvester_mm_kernel<KS>, dim3((unsigned)grid), dim3(kSylThreads), lds, s, a);
+  hipLaunchKernelGGL((sylvester_mm_kernel<KS, kDense>), dim3((unsigned)grid), dim3(kSylThreads), lds, s, a);
   return hipGetLastError();
 }
 
@@ -212,9 +225,29 @@ extern "C" int fc_sylvester_mm(const float* x, float* y, float* logabsdet, const
     cus = prop.multiProcessorCount;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (d / 32) {
-    case 1: return fc::launch_syl<1>(a, cus * 2, s);
-    case 2: return fc::launch_syl<2>(a, cus * 2, s);
-    case 3: return fc::launch_syl<3>(a, cus, s);
-    default: return fc::launch_syl<4>(a, cus, s);
+    case 1: return fc::launch_syl<1, false>(a, cus * 2, s);
+    case 2: return fc::launch_syl<2, false>(a, cus * 2, s);
+    case 3: return fc::launch_syl<3, false>(a, cus, s);
+    default: return fc::launch_syl<4, false>(a, cus, s);
+  }
+}
+
+extern "C" int fc_dense_mm(const float* x, float* y, const float* w, const float* bias, int64_t n, int32_t d,
+                           void* stream) {
+  if (n < 0 || d <= 0 || d % 32 != 0 || d > 128 || n % 16 != 0) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!x || !y || !w) return hipErrorInvalidValue;
+  if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return hipErrorInvalidValue;
+  fc::SylArgs a{x, y, nullptr, w, nullptr, bias, nullptr, n / 16};
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    cus = prop.multiProcessorCount;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (d / 32) {
+    case 1: return fc::launch_syl<1, true>(a, cus * 2, s);
+    case 2: return fc::launch_syl<2, true>(a, cus * 2, s);
+    case 3: return fc::launch_syl<3, true>(a, cus, s);
+    default: return fc::launch_syl<4, true>(a, cus, s);
   }
 }

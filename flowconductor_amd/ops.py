@@ -765,6 +765,25 @@ def pack_sylvester(q_vectors, r1, r2):
     return w1, w2, rdiag
 
 
+def dense_mm(inputs, weight, bias=None):
+    """``inputs @ weight.T + bias`` for a batch-independent [D, D] ``weight`` on the matrix cores (rows a multiple
+    of 16, D % 32 == 0, D <= 128): f32-GEMM accuracy by split-f16 products."""
+    lib = _hip.load()
+    x = _rows(inputs)
+    _hip.require_no_grad(inputs)
+    n, d = x.shape
+    if n % SYLVESTER_MM_ROWS != 0 or not sylvester_mm_supported(n, d):
+        raise ValueError("fc_dense_mm: unsupported shape %s" % (tuple(x.shape),))
+    w = _param(weight, x.device, "weight")
+    if w.shape != (d, d):
+        raise ValueError("weight must be [%d, %d]" % (d, d))
+    bv = _param(bias, x.device, "bias").reshape(-1) if bias is not None else None
+    y = torch.empty_like(x)
+    _call("fc_dense_mm", lib.fc_dense_mm, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(w), _hip.ptr(bv), n, d,
+          _hip.stream_ptr(x.device))
+    return y
+
+
 def sylvester_mm(inputs, w1, w2, bias, rdiag):
     """Sylvester flow forward + logabsdet with shared parameters as two matrix-core products (rows a multiple of 16)."""
     lib = _hip.load()

@@ -52,7 +52,14 @@ class LULinear(Linear):
         """outputs = L (U x) + bias in one kernel; logabsdet = sum log diag(U)."""
         with torch.no_grad():
             lower, upper = self._create_lower_upper()
-            outputs = ops.linear(inputs, upper, lower, self.bias, mode=ops.LINEAR_LU_FORWARD)
+            n = inputs.shape[0]
+            if (inputs.dim() == 2 and inputs.is_cuda and ops.sylvester_mm_supported(n, self.features)
+                    and n % ops.SYLVESTER_MM_ROWS == 0 and n >= 1024):
+                # W = L U formed once in float64; the batch goes through the matrix cores
+                weight = (lower.double() @ upper.double()).float()
+                outputs = ops.dense_mm(inputs, weight, self.bias)
+            else:
+                outputs = ops.linear(inputs, upper, lower, self.bias, mode=ops.LINEAR_LU_FORWARD)
             logabsdet = self.logabsdet() * inputs.new_ones(outputs.shape[0])
         return outputs, logabsdet
 

@@ -1,4 +1,6 @@
 """Orthogonal transforms built from Householder reflections (API of flowcon/transforms/orthogonal.py)."""
+import os
+
 import torch
 from torch import nn
 
@@ -37,12 +39,36 @@ class HouseholderSequence(Transform):
         self.num_transforms = num_transforms
         self.q_vectors = nn.Parameter(_paired_unit_vectors(num_transforms, features))
 
+    def _dense(self, inputs, reverse):
+        """Batch-independent reflections fold into one orthogonal [D, D] matrix (formed in float64, cached per
+        parameter version); wide batches then go through the matrix cores (``fc_dense_mm``)."""
+        n = inputs.shape[0]
+        if not (inputs.dim() == 2 and inputs.is_cuda and ops.sylvester_mm_supported(n, self.features)
+                and n >= 1024   # enough rows to pay for the fold
+                and os.environ.get("FC_SYLVESTER_MM", "1") != "0"
+                and not (torch.is_grad_enabled() and (inputs.requires_grad or self.q_vectors.requires_grad))):
+            return None
+        key = (self.q_vectors._version, self.q_vectors.data_ptr())
+        if getattr(self, "_dense_cache", None) is None or self._dense_cache[0] != key:
+            self._dense_cache = (key, {})
+        mats = self._dense_cache[1]
+        if reverse not in mats:
+            # householder(v, q, reverse) == v @ M  ->  as a column map the weight is M^T
+            mats[reverse] = ops.householder_matrix(self.q_vectors, reverse=reverse).T.float().contiguous()
+        body = n - n % ops.SYLVESTER_MM_ROWS
+        out = ops.dense_mm(inputs[:body], mats[reverse])
+        if body < n:
+            out = torch.cat((out, ops.householder(inputs[body:], self.q_vectors, reverse=reverse)))
+        return out, inputs.new_zeros(n)
+
     def forward(self, inputs, context=None):
-        return _apply(inputs, self.q_vectors, reverse=False)
+        dense = self._dense(inputs, False)
+        return dense if dense is not None else _apply(inputs, self.q_vectors, reverse=False)
 
     def inverse(self, inputs, context=None):
         # each reflection is its own inverse: apply them in reverse order
-        return _apply(inputs, self.q_vectors, reverse=True)
+        dense = self._dense(inputs, True)
+        return dense if dense is not None else _apply(inputs, self.q_vectors, reverse=True)
 
     def matrix(self):
         """The [D, D] orthogonal matrix of the whole sequence (inverse applied to the identity)."""

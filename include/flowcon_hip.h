@@ -264,6 +264,11 @@ int fc_sylvester(const float* x, float* y, float* logabsdet, const float* q, con
 int fc_sylvester_mm(const float* x, float* y, float* logabsdet, const float* w1, const float* w2,
                     const float* bias, const float* r_diag_prod, int64_t n, int32_t d, void* stream);
 
+/* y = W x + bias for a batch-independent dense [d, d] matrix on the matrix cores (same split-f16 products):
+ * LULinear / Linear forward with W = L U (lu.py:56-68, linear.py:45-60), a HouseholderSequence folded into its
+ * orthogonal matrix (orthogonal.py:63-85).  bias may be NULL.  d % 32 == 0, d <= 128, n % 16 == 0. */
+int fc_dense_mm(const float* x, float* y, const float* w, const float* bias, int64_t n, int32_t d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

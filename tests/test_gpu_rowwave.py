@@ -204,3 +204,26 @@ def test_sylvester_matrix_core_path(d, m, n, device, monkeypatch):
     assert maxdiff(y.cpu().double(), ref_y) <= 1e-5 * sy + 4 * fy
     assert maxdiff(lad.cpu().double(), ref_lad) <= 1e-5 * sl + 4 * fl
     assert maxdiff(y, y2) <= 2e-5 * sy and maxdiff(lad, lad2) <= 2e-5 * sl + 8 * fl
+
+
+@pytest.mark.parametrize("d,k,n", [(64, 8, 4096), (128, 32, 8192)])
+def test_householder_and_lu_dense_matrix_core_path(d, k, n, device):
+    """Wide batches with batch-independent parameters: a Householder sequence folded into its orthogonal matrix and
+    LULinear's W = L U run as one matrix-core product (fc_dense_mm); against the oracle in float64."""
+    torch.manual_seed(k)
+    h = T.HouseholderSequence(features=d, num_transforms=k).eval()
+    with torch.no_grad():
+        h.q_vectors.copy_(torch.randn(k, d))
+    lu = T.LULinear(d).eval()
+    x = torch.randn(n, d)
+    for t, inverse in ((h, False), (h, True), (lu, False)):
+        with torch.no_grad():
+            ref_y, ref_lad = O.transform_apply(copy.deepcopy(t).double(), x.double(), inverse=inverse)
+            f32_y, _ = O.transform_apply(t, x, inverse=inverse)
+        td = copy.deepcopy(t).to(device)
+        with torch.no_grad(), ops.KernelTimer("fc_dense_mm") as timer:
+            y, lad = (td.inverse if inverse else td)(x.to(device))
+        assert len(timer.pairs) == 1, "the matrix-core kernel did not run"
+        scale = max(1.0, float(ref_y.abs().max()))
+        assert maxdiff(y.cpu().double(), ref_y) <= 1e-5 * scale + 4 * maxdiff(f32_y.double(), ref_y)
+        assert maxdiff(lad.cpu().double(), ref_lad) <= 1e-5 * max(1.0, float(ref_lad.abs().max()))
