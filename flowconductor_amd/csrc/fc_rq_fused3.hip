@@ -4,7 +4,7 @@
 //   params[n, :] = W h[n, :] + b        (flowcon/nn/nets/resnet.py:91,99, the conditioner's final Linear)
 //   y, logabsdet = rq_spline(x, params) (flowcon/transforms/coupling.py:279-293,549-582)
 //
-// Why not the f32-input MFMA (fc_rq_fused.hip, fc_rq_fused2.hip): v_mfma_f32_*_f32 runs at the f32 VALU
+// Why not the f32-input MFMA (the first two versions of this kernel, see fc_rq_fused.hip): v_mfma_f32_*_f32 runs at the f32 VALU
 // rate and, measured here, does not overlap with VALU work at all -- MFMA-only 0.85 ms, spline-only
 // 0.72 ms, both 1.29 ms per 2^20-row launch, whichever way the two streams were interleaved.  The 16-bit
 // matrix pipe is 16x faster.  So the f32 product is computed to f32 accuracy on it: after an exact

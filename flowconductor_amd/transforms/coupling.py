@@ -271,8 +271,9 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
     # ---- fused final conditioner layer -------------------------------------------
     # When the conditioner is this package's ResidualNet with the north-star shape (hidden 64, 32
     # transformed dims, K = 8, linear tails) its last nn.Linear is evaluated INSIDE the spline kernel on
-    # the exact-f32 matrix cores, so the [N, 736] parameter tensor never touches HBM.  The hidden layers
-    # stay PyTorch-ROCm.  Any other conditioner / shape takes the generic path; FC_FUSED=0 disables it.
+    # the matrix cores (split-f16 products, f32-GEMM accuracy), so the [N, 736] parameter tensor never
+    # touches HBM; the hidden layers run in fc_resnet_hidden.  Inference only.  Any other conditioner /
+    # shape takes the generic path; FC_FUSED=0 disables it.
 
     def _fused_ok(self, inputs):
         from flowconductor_amd.nn.nets.resnet import ResidualNet

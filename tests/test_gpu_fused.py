@@ -33,7 +33,7 @@ def test_fused_matches_unfused_and_oracle(n, inverse, device, monkeypatch):
         assert not t._fused_ok(xd)
         y_u, lad_u = fn(xd)
     scale = max(1.0, float(ref_y.abs().max()))
-    # fused vs unfused: same spline arithmetic, GEMM by exact-f32 MFMA vs hipBLASLt
+    # fused vs unfused: same spline arithmetic, GEMM by split-f16 MFMA vs hipBLASLt
     assert maxdiff(y_f, y_u) <= 5e-5 * scale
     # (the spline inverse is ill-conditioned on a few elements: tools/noise_floor.py, max 1.9e-3 at 2^14 rows)
     assert maxdiff(lad_f, lad_u) <= (1e-3 if not inverse else 1e-2)
