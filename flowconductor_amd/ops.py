@@ -252,7 +252,7 @@ def rq_spline_backward(inputs, params, cols, grad_outputs, grad_logabsdet, **kw)
                      kw.get("min_derivative", DEFAULT_MIN_DERIVATIVE), kw.get("enable_identity_init", False),
                      kw.get("wh_divisor", 1.0), False)
     gl = None if grad_logabsdet is None else _hip.dev_f32(grad_logabsdet, "grad_logabsdet")
-    gx = gy.clone()                       # identity columns: d out / d in = 1
+    gx = torch.empty_like(gy)             # every column is written (identity columns: grad_outputs)
     gp = torch.empty_like(p)
     _call("fc_rq_spline_backward", lib.fc_rq_spline_backward, x.device, _hip.ptr(x), _hip.ptr(p), _hip.ptr(cols),
           _hip.ptr(gy), _hip.ptr(gl), _hip.ptr(gx), _hip.ptr(gp), n, d, d_t, cfg, _hip.stream_ptr(x.device))

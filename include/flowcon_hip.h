@@ -88,8 +88,8 @@ int fc_affine_backward(const float* x, const float* params, const int32_t* cols,
 
 /* Backward of fc_rq_spline in the forward direction (what torch.autograd yields for the reference's op
  * sequence, rational_quadratic.py:13-181; the reference trains through it, examples/toy_2d.py:57-68):
- *   grad_x[n, cols[j]]            = gy dy/dx + gl dlogabsdet/dx      (other columns of grad_x are NOT written:
- *                                                                      the caller passes grad_y's identity part on)
+ *   grad_x[n, cols[j]]            = gy dy/dx + gl dlogabsdet/dx      (the other columns: grad_x = grad_y, the
+ *                                                                      bijector copies them)
  *   grad_params[n, j*P .. j*P+P)  = gy dy/dp + gl dlogabsdet/dp      for the P = 3K-1 (3K+1) raw values of dim j
  * x [n, d], params [n, d_t*P] (per-sample rows only), grad_y [n, d], grad_logabsdet [n] or NULL (zeros).
  * cfg->inverse must be 0; num_bins <= 32. */
