@@ -67,10 +67,10 @@ template <int R>
 struct Fused3Lds {
   static constexpr int kHPiece = R * kHB;                  // f16 per piece per buffer
   static constexpr int kHbufBytes = 2 * 2 * kHPiece * 2;   // [buf][piece][row][kHB] f16
-  static constexpr int kLpartBytes = 2 * 8 * R * 4;        // [buf][wave][row]
-  static constexpr int kHscaleBytes = 2 * R * 4;           // [buf][row] 2^-T of the h row
+  static constexpr int kLpartBytes = 3 * 8 * R * 4;        // [ring of 3][wave][row]
+  static constexpr int kHscaleBytes = 3 * R * 4;           // [ring of 3][row] 2^-T of the h row
   static constexpr size_t bytes(int d) {
-    return (size_t)kHbufBytes + kLpartBytes + kHscaleBytes + kTabBytes + 2 * R * (d + 4) * 4 + kDt * 4;
+    return (size_t)kHbufBytes + kLpartBytes + kHscaleBytes + kTabBytes + 3 * R * (d + 4) * 4 + kDt * 4;
   }
 };
 
@@ -86,11 +86,11 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   _Float16* hbuf = reinterpret_cast<_Float16*>(smem3);                               // [2][2][R][kHB]
   float* lpart = reinterpret_cast<float*>(smem3 + L::kHbufBytes);                    // [2][8][R]
-  float* hscale = lpart + 2 * 8 * R;                                                  // [2][R]
-  float* tabs = hscale + 2 * R;                                                       // [8 waves][knots | derivs]
+  float* hscale = lpart + 3 * 8 * R;                                                  // [3][R]
+  float* tabs = hscale + 3 * R;                                                       // [8 waves][knots | derivs]
   float* xbuf = tabs + kTabBytes / 4;                                                 // [2][R][D + 4]
   const int D = a.D, XS = D + 4;
-  int* cs = reinterpret_cast<int*>(xbuf + 2 * R * XS);                                // [kDt]
+  int* cs = reinterpret_cast<int*>(xbuf + 3 * R * XS);                                // [kDt]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s16 = lane & 15, g = lane >> 4;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     return reinterpret_cast<float4*>(xbuf + (buf * R + r) * XS + c);
   };
   // thread tid holds h[row (tid >> 4) + 32 k][4 (tid & 15) ..]: the 16 threads of a row are 16 adjacent lanes
-  auto park_h = [&](int buf, int k, const float4& hvk) __attribute__((always_inline)) {
+  auto park_h = [&](int buf, int xbuf3, int k, const float4& hvk) __attribute__((always_inline)) {
     const int c = (tid & 15) * 4, r = (tid >> 4) + 32 * k;
     const float v[4] = {hvk.x, hvk.y, hvk.z, hvk.w};
     const float m = row16_allmax(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -200,15 +200,16 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     _Float16* dst = hbuf + (buf * 2 * R + r) * kHB + c;
     *reinterpret_cast<f16x4*>(dst) = p0;
     *reinterpret_cast<f16x4*>(dst + kHPiece) = p1;
-    if ((tid & 15) == 0) hscale[buf * R + r] = un;
+    if ((tid & 15) == 0) hscale[xbuf3 * R + r] = un;
   };
-  auto park = [&](int buf) __attribute__((always_inline)) {
-    park_h(buf, 0, hv0);
-    if constexpr (HV > 1) park_h(buf, 1, hv1);
-    if (tid < xvec) *xslot(buf, tid) = xv0;
-    if constexpr (XV > 1) if (tid + 512 < xvec) *xslot(buf, tid + 512) = xv1;
-    if constexpr (XV > 2) if (tid + 1024 < xvec) *xslot(buf, tid + 1024) = xv2;
-    if constexpr (XV > 3) if (tid + 1536 < xvec) *xslot(buf, tid + 1536) = xv3;
+  // h tile -> hbuf[hb2] (ring of 2), its row scales and the x tile -> ring slot x3 (ring of 3)
+  auto park = [&](int hb2, int x3) __attribute__((always_inline)) {
+    park_h(hb2, x3, 0, hv0);
+    if constexpr (HV > 1) park_h(hb2, x3, 1, hv1);
+    if (tid < xvec) *xslot(x3, tid) = xv0;
+    if constexpr (XV > 1) if (tid + 512 < xvec) *xslot(x3, tid + 512) = xv1;
+    if constexpr (XV > 2) if (tid + 1024 < xvec) *xslot(x3, tid + 1024) = xv2;
+    if constexpr (XV > 3) if (tid + 1536 < xvec) *xslot(x3, tid + 1536) = xv3;
   };
   // B operand (h^T piece `hp`, k-step ks) of block `blk` in buffer `hb`:
   // lane holds h[sample 16 blk + (lane & 15)][k = 32 ks + 8 (lane >> 4) + j]
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #endif
 #if FC_ABL & 16   // cycles each wave spends in the phases of the loop / waiting at its two barriers
   uint64_t barrier_wait = 0, phase_cyc[6] = {0, 0, 0, 0, 0, 0}, phase_t = __builtin_amdgcn_s_memtime();
-  // phase k ends at FC_PHASE(k): 0 write-out + loop overhead, 1 step A, 2 park, 3 barrier 1, 4 step B, 5 barrier 2
+  // phase k ends at FC_PHASE(k): 0 loop overhead + fetch, 1 steps 0..NB-2, 2 park, 3 barrier, 5 write-out, 4 last step
 #define FC_PHASE(k)                                              \
   do {                                                           \
     const uint64_t now = __builtin_amdgcn_s_memtime();           \
@@ -322,51 +323,59 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   f32x4 acc0[kCt3], acc1[kCt3];
 #pragma unroll
   for (int t = 0; t < kCt3; ++t) acc0[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Rings: the h tile is double-buffered; the x tile, its row scales and the logabsdet partials live in a ring
+  // of three, because the results of a tile leave only after the NEXT tile's barrier (one barrier per tile):
+  //   iteration i:  steps 0..NB-2 of tile i | park tile i+1 | BARRIER | write out tile i-1 | last step of tile i
+  // Every thread writes out exactly the float4 slots it parks, so the ring needs no further synchronisation.
+  auto write_out = [&](int64_t t, int x3) __attribute__((always_inline)) {
+    float4* yg = reinterpret_cast<float4*>(a.y + t * R * D);
+#pragma unroll
+    for (int k = 0; k < XV; ++k)
+      if (tid + 512 * k < xvec) yg[tid + 512 * k] = *xslot(x3, tid + 512 * k);
+    if (tid < R) {
+      const float* lp = lpart + x3 * 8 * R + tid;
+      float l = lp[0];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) l += lp[w * R];
+      // running total of the composite (base.py:51 `total_logabsdet += logabsdet`) or a fresh value
+      a.logabsdet[t * R + tid] = a.accumulate ? a.logabsdet[t * R + tid] + l : l;
+    }
+  };
   fetch(tile0);
-  park(0);
+  park(0, 0);
   __syncthreads();
   produce_only(acc0, 0, 0);   // block 0 of the first tile
-  int tb = 0;
+  int hb = 0, x3 = 0;          // ring slots of the current tile
+  int64_t prev_tile = -1;
   for (int64_t tile = tile0; tile < a.tiles; tile += stride) {
     const bool has_next = tile + stride < a.tiles;
+    const int x3n = x3 == 2 ? 0 : x3 + 1, x3p = x3 == 0 ? 2 : x3 - 1;
     FC_PHASE(0);
     if (has_next) fetch(tile + stride);
     // Steps 0 .. NB-2: evaluate block j of `tile`, produce its block j + 1.  (acc0 / acc1 alternate; NB is
     // even, so every tile starts with its block 0 in acc0.)
-    step(acc0, tb, 0, acc1, tb, 1);
+    step(acc0, x3, 0, acc1, hb, 1);
     if constexpr (NB == 4) {
-      step(acc1, tb, 1, acc0, tb, 2);
-      step(acc0, tb, 2, acc1, tb, 3);
+      step(acc1, x3, 1, acc0, hb, 2);
+      step(acc0, x3, 2, acc1, hb, 3);
     }
     FC_PHASE(1);
-    if (has_next) park(tb ^ 1);
+    if (has_next) park(hb ^ 1, x3n);
     FC_PHASE(2);
     FC_TIMED_BARRIER();
     FC_PHASE(3);
+    if (prev_tile >= 0) write_out(prev_tile, x3p);   // complete since every wave passed this barrier
+    FC_PHASE(5);
     // Last step: evaluate block NB-1, produce block 0 of the next tile (unconditional: on the last tile the
     // MFMAs work on stale h rows into accumulators nobody reads -- a branch would split the interleaved block).
-    step(acc1, tb, NB - 1, acc0, tb ^ 1, 0);
+    step(acc1, x3, NB - 1, acc0, hb ^ 1, 0);
     FC_PHASE(4);
-    FC_TIMED_BARRIER();
-    FC_PHASE(5);
-    // Every thread writes out exactly the float4 slots it parks, and lpart is double-buffered, so no third
-    // barrier is needed before the next iteration.
-    {
-      float4* yg = reinterpret_cast<float4*>(a.y + tile * R * D);
-#pragma unroll
-      for (int k = 0; k < XV; ++k)
-        if (tid + 512 * k < xvec) yg[tid + 512 * k] = *xslot(tb, tid + 512 * k);
-      if (tid < R) {
-        const float* lp = lpart + tb * 8 * R + tid;
-        float l = lp[0];
-#pragma unroll
-        for (int w = 1; w < 8; ++w) l += lp[w * R];
-        // running total of the composite (base.py:51 `total_logabsdet += logabsdet`) or a fresh value
-        a.logabsdet[tile * R + tid] = a.accumulate ? a.logabsdet[tile * R + tid] + l : l;
-      }
-    }
-    tb ^= 1;
+    prev_tile = tile;
+    hb ^= 1;
+    x3 = x3n;
   }
+  __syncthreads();
+  if (prev_tile >= 0) write_out(prev_tile, x3 == 0 ? 2 : x3 - 1);
 #if FC_ABL & 16   // the stamps overwrite two outputs of the workgroup's first tile: probe builds only
   if (tid == 0) {
     a.y[tile0 * R * D] = (float)(__builtin_amdgcn_s_memtime() - stamp_c0);

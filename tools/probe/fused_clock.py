@@ -28,7 +28,7 @@ with torch.no_grad():
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 yy = y.view(-1, 64 * d)[:cus, :60].double().cpu()
 ph = (yy[:, 12:60].median(dim=0).values / (n // 64 / cus)).view(8, 6)
-print('phase cycles per 64-row tile [write-out, steps 0-2, park, barrier 1, step 3, barrier 2] per wave:')
+print('phase cycles per 64-row tile [loop overhead + fetch, steps 0-2, park, barrier, last step, write-out of the previous tile] per wave:')
 for w in range(8):
     print('  wave', w, [int(v) for v in ph[w]])
 print('barrier wait per wave (cycles per tile, median over workgroups):', [round(float(v), 0) for v in (yy[:, 4:12].median(dim=0).values / (n // 64 / cus))])
