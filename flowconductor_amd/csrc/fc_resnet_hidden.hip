@@ -7,7 +7,7 @@
 //  kernels + a gather per layer, each a full pass over [N, 64] in HBM; here the only HBM traffic is
 //  the x rows in and the h rows out.  The conditioner stays a PyTorch nn.Module (parameters,
 //  state_dict, CPU execution); this kernel is the device fast path for its inference forward when
-//  the shapes match: hidden = 64, <= 2 blocks, ReLU, <= 64 input features.
+//  the shapes match: hidden = 64, <= 4 blocks, ReLU, <= 64 input features.
 //
 // Every product runs as three v_mfma_f32_16x16x32_f16 terms on scaled two-piece f16 splits of both
 // operands (fc_split.h): f32-GEMM accuracy at 3/16 of the f32-MFMA cycles.
@@ -56,7 +56,8 @@ struct HiddenLds {
   static constexpr int kFrag0 = K0S * 4 * 2;              // fragments of the initial layer
   static constexpr int kFragL = 2 * 4 * 2;                // fragments of a 64 x 64 layer
   static constexpr int kFrags = kFrag0 + 2 * NB * kFragL;
-  static constexpr size_t kBytes = (size_t)kFrags * 64 * 16 + kLayers * 64 * 4 + 8 * 4 + 32 * K0S * 4 + 64;
+  static constexpr size_t kBytes = (size_t)kFrags * 64 * 16 + kLayers * 64 * 4 + 16 * 4 + 32 * K0S * 4 + 64;
+  static_assert(kLayers <= 16, "wun holds 16 entries");
 };
 
 template <int NB, int K0S>
@@ -65,8 +66,8 @@ __global__ __launch_bounds__(kHidThreads, 4) void resnet_hidden_kernel(HiddenArg
   extern __shared__ __attribute__((aligned(16))) unsigned char hsmem[];
   f16x8* wfrag = reinterpret_cast<f16x8*>(hsmem);
   float* bias = reinterpret_cast<float*>(hsmem + (size_t)L::kFrags * 64 * 16);   // [layer][g][16]
-  float* wun = bias + L::kLayers * 64;                                             // [layer] (padded to 8)
-  int* ids = reinterpret_cast<int*>(wun + 8);                                      // [32 K0S]
+  float* wun = bias + L::kLayers * 64;                                             // [layer] (padded to 16)
+  int* ids = reinterpret_cast<int*>(wun + 16);                                      // [32 K0S]
   float* red = reinterpret_cast<float*>(ids + 32 * K0S);                           // [8] + pad
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -263,7 +264,7 @@ hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
 extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const float* w0,
                                 const float* b0, const float* wb, const float* bb, int64_t n, int32_t d,
                                 int32_t in_features, int32_t hidden, int32_t num_blocks, void* stream) {
-  if (n < 0 || d <= 0 || hidden != fc::kHid || num_blocks < 0 || num_blocks > 2) return hipErrorInvalidValue;
+  if (n < 0 || d <= 0 || hidden != fc::kHid || num_blocks < 0 || num_blocks > 4) return hipErrorInvalidValue;
   if (in_features <= 0 || in_features > 64 || in_features > d) return hipErrorInvalidValue;
   if (n % 16 != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
@@ -274,9 +275,10 @@ extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
     cus = prop.multiProcessorCount;
-  // two 512-thread workgroups per CU when their weight images fit (<= 32 inputs), else one
+  // two 512-thread workgroups per CU when two weight images fit in LDS (<= 2 blocks at <= 32 inputs), else one
   const bool wide = in_features > 32;
-  int64_t grid = (int64_t)cus * (wide ? 1 : 2);
+  const size_t frags = (size_t)(wide ? 16 : 8) + (size_t)num_blocks * 2 * 16;   // 1 KB each
+  int64_t grid = (int64_t)cus * (frags * 1024 + 2048 <= 80 * 1024 ? 2 : 1);
   const int64_t need = (a.blocks16 + 7) / 8;
   if (grid > need) grid = need;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -286,6 +288,10 @@ extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols
     case 2: return fc::launch_hidden<1, 1>(a, grid, s);
     case 3: return fc::launch_hidden<1, 2>(a, grid, s);
     case 4: return fc::launch_hidden<2, 1>(a, grid, s);
-    default: return fc::launch_hidden<2, 2>(a, grid, s);
+    case 5: return fc::launch_hidden<2, 2>(a, grid, s);
+    case 6: return fc::launch_hidden<3, 1>(a, grid, s);
+    case 7: return fc::launch_hidden<3, 2>(a, grid, s);
+    case 8: return fc::launch_hidden<4, 1>(a, grid, s);
+    default: return fc::launch_hidden<4, 2>(a, grid, s);
   }
 }

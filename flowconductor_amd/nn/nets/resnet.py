@@ -78,12 +78,12 @@ class ResidualNet(nn.Module):
 
     # ---- device fast path for the hidden layers (inference) ------------------------------------------
     def hip_hidden_supported(self, features_total):
-        """True when ``fc_resnet_hidden`` covers this net: hidden 64, <= 2 blocks, ReLU, no context, no
+        """True when ``fc_resnet_hidden`` covers this net: hidden 64, <= 4 blocks, ReLU, no context, no
         batch norm, dropout inactive, input width <= 64."""
         def is_relu(f):
             return isinstance(f, torch.nn.ReLU) or f is F.relu or f is torch.relu
 
-        if self.context_features is not None or self.hidden_features != 64 or len(self.blocks) > 2:
+        if self.context_features is not None or self.hidden_features != 64 or len(self.blocks) > 4:
             return False
         in_f = self.initial_layer.in_features
         if in_f > 64 or in_f > features_total:

@@ -171,7 +171,7 @@ class MADE(nn.Module):
         def is_relu(f):
             return isinstance(f, torch.nn.ReLU) or f is F.relu or f is torch.relu
 
-        if (not self.use_residual_blocks or hasattr(self, "context_layer") or len(self.blocks) > 2
+        if (not self.use_residual_blocks or hasattr(self, "context_layer") or len(self.blocks) > 4
                 or self.initial_layer.out_features != 64 or self.initial_layer.in_features > 64
                 or not is_relu(self.activation)):
             return False

@@ -46,7 +46,8 @@ def test_fused_matches_unfused_and_oracle(n, inverse, device, monkeypatch):
 
 
 @pytest.mark.parametrize("in_f,blocks,d,n", [(32, 2, 64, 64), (32, 2, 64, 6400), (16, 1, 32, 128), (6, 0, 12, 64),
-                                            (64, 2, 128, 192), (7, 1, 15, 48), (33, 2, 70, 16), (32, 2, 64, 100000)])
+                                            (64, 2, 128, 192), (7, 1, 15, 48), (33, 2, 70, 16), (32, 2, 64, 100000), (32, 3, 64, 512),
+                                            (24, 4, 48, 1024), (64, 4, 128, 256)])
 def test_resnet_hidden_kernel_matches_torch(in_f, blocks, d, n, device):
     """fc_resnet_hidden vs the same nn.Module evaluated by PyTorch on the CPU."""
     from flowconductor_amd.nn import nets
