@@ -1,0 +1,89 @@
+"""Randomised shapes for the matrix-core kernels against torch (float64 on the device): fc_resnet_hidden,
+fc_rq_spline_fused_linear (vs the unfused HIP path), fc_sylvester_mm / fc_dense_mm.  Not part of the test suite;
+run on the GPU box:  python tools/probe/fuzz_kernels.py [seed] [cases]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from flowconductor_amd import ops  # noqa: E402
+from flowconductor_amd.nn import nets  # noqa: E402
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+g = torch.Generator().manual_seed(seed)
+dev = "cuda"
+
+
+def ri(lo, hi):
+    return int(torch.randint(lo, hi + 1, (1,), generator=g))
+
+
+worst = {}
+for c in range(cases):
+    # ---- hidden kernel
+    in_f, blocks = ri(1, 64), ri(0, 4)
+    d = ri(in_f, 128)
+    n = 16 * ri(1, 300)
+    torch.manual_seed(seed * 1000 + c)
+    net = nets.ResidualNet(in_f, 8, hidden_features=64, num_blocks=blocks).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(float(torch.rand(1, generator=g)) * 3 + 0.3)
+    ids = torch.randperm(d, generator=g)[:in_f].sort().values
+    x = torch.randn(n, d, generator=g) * float(10 ** (torch.rand(1, generator=g) * 6 - 3))
+    with torch.no_grad():
+        ref = net.double().hidden(x.double()[:, ids]).float()
+        net = net.float().to(dev)
+        got = net.hidden_hip(x.to(dev), ids.to(dev)).cpu()
+    err = float((got - ref).abs().max() / max(1e-30, float(ref.abs().max())))
+    worst["hidden"] = max(worst.get("hidden", 0.0), err)
+    assert err < 5e-5, ("hidden", in_f, blocks, d, n, err)
+
+    # ---- fused final layer + spline against the unfused HIP path
+    d = 4 * ri(8, 32)
+    n = 32 * ri(1, 200)
+    k, d_t = 8, 32
+    x = torch.randn(n, d, generator=g) * 1.7
+    h = torch.randn(n, 64, generator=g) * float(10 ** (torch.rand(1, generator=g) * 4 - 2))
+    w = torch.randn(d_t * 23, 64, generator=g) * 0.2 / float(h.abs().mean())
+    b = torch.randn(d_t * 23, generator=g) * 0.2
+    cols = torch.randperm(d, generator=g)[:d_t].sort().values.to(torch.int32)
+    inverse = bool(ri(0, 1))
+    kw = dict(num_bins=k, tail_bound=3.0, wh_divisor=8.0, inverse=inverse)
+    wp, bp = ops.pack_final_layer(w.to(dev), b.to(dev))
+    with torch.no_grad():
+        y, lad = ops.rq_spline_fused_linear(x.to(dev), h.to(dev), wp, bp, cols.to(dev), **kw)
+        params = (h.double() @ w.double().T + b.double()).float().to(dev)
+        y2, lad2 = ops.rq_spline(x.to(dev), params, cols.to(dev), tails="linear", **kw)
+    ey = float((y - y2).abs().max())
+    el = float((lad - lad2).abs().max() / max(1.0, float(lad2.abs().max())))
+    worst["fused_y"] = max(worst.get("fused_y", 0.0), ey)
+    worst["fused_lad"] = max(worst.get("fused_lad", 0.0), el)
+    assert ey < (5e-3 if inverse else 2e-4) and el < (5e-3 if inverse else 2e-4), ("fused", d, n, inverse, ey, el)
+
+    # ---- dense / Sylvester matrix-core kernels
+    d = 32 * ri(1, 4)
+    n = 16 * ri(1, 400)
+    x = torch.randn(n, d, generator=g) * float(10 ** (torch.rand(1, generator=g) * 4 - 2))
+    w1 = torch.randn(d, d, generator=g) / d ** 0.5
+    w2 = torch.randn(d, d, generator=g) / d ** 0.5
+    bias = torch.randn(d, generator=g) * 0.3
+    rd = torch.rand(d, generator=g) * 0.8
+    with torch.no_grad():
+        y = ops.dense_mm(x.to(dev), w1.to(dev), bias.to(dev)).cpu()
+        ref = (x.double() @ w1.double().T + bias.double()).float()
+        err = float((y - ref).abs().max() / float(ref.abs().max()))
+        worst["dense"] = max(worst.get("dense", 0.0), err)
+        assert err < 2e-5, ("dense", d, n, err)
+        ys, ls = ops.sylvester_mm(x.to(dev), w1.to(dev), w2.to(dev), bias.to(dev), rd.to(dev))
+        act = torch.tanh(x.double() @ w1.double().T + bias.double())
+        refy = x.double() + act @ w2.double().T
+        refl = torch.log(1 + (1 - act ** 2) * rd.double()).sum(1)
+        ey = float((ys.cpu().double() - refy).abs().max() / float(refy.abs().max()))
+        el = float((ls.cpu().double() - refl).abs().max() / max(1.0, float(refl.abs().max())))
+        worst["syl_y"] = max(worst.get("syl_y", 0.0), ey)
+        worst["syl_lad"] = max(worst.get("syl_lad", 0.0), el)
+        assert ey < 2e-5 and el < 2e-5, ("sylvester", d, n, ey, el)
+print("fuzz ok: seed %d, %d cases each; worst relative errors %s" % (seed, cases, {k: "%.2e" % v for k, v in worst.items()}))
