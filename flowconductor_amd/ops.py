@@ -91,6 +91,27 @@ def deferred_errors():
             _check_now()
 
 
+@contextlib.contextmanager
+def capture_mode():
+    """Inside a HIP-graph capture the error word cannot be read (no host sync): kernels still OR their bits into
+    it, ``check_errors`` reads it after a replay."""
+    _flags()
+    _state.depth += 1
+    try:
+        yield
+    finally:
+        _state.depth -= 1
+        _state.dirty = set()
+
+
+def check_errors(device):
+    """Read (and clear) the device error word of ``device`` now; raises the reference's exceptions."""
+    _flags()
+    _state.dirty.add((device.type, device.index))
+    _flag_for(device)
+    _check_now()
+
+
 def _err_word(device, may_raise):
     """Device pointer for the kernel's error word (None when the op cannot raise)."""
     if not may_raise:

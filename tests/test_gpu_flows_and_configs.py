@@ -214,3 +214,35 @@ def test_config5_sylvester_d128_m32_large_batch(device):
     with torch.no_grad():
         y_tail, lad_tail = t(x[-128:].to(device))
     assert torch.equal(y_tail, y[-128:]) and torch.equal(lad_tail, lad[-128:])
+
+
+def test_hip_graph_replay_of_log_prob(device):
+    """A captured HIP graph of Flow.log_prob (utils/graphs.GraphedCall) replays bit-identically to eager calls on
+    new inputs of the same shape, and still raises the reference's domain exception after a replay."""
+    from flowconductor_amd import distributions, flows, transforms
+    from flowconductor_amd.utils.graphs import GraphedCall
+
+    torch.manual_seed(0)
+    layers = []
+    for _ in range(4):
+        layers.append(transforms.MaskedAffineAutoregressiveTransform(features=2, hidden_features=4))
+        layers.append(transforms.RandomPermutation(features=2))
+    flow = flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([2])).to(device).eval()
+    x0 = torch.randn(4096, 2, device=device)
+    graphed = GraphedCall(flow.log_prob, x0)
+    for seed in (1, 2):
+        x = torch.randn(4096, 2, device=device, generator=torch.Generator(device=device).manual_seed(seed))
+        with torch.no_grad():
+            eager = flow.log_prob(x)
+        assert torch.equal(graphed(x), eager)
+    with pytest.raises(ValueError):
+        graphed(torch.randn(100, 2, device=device))
+
+    # error word after a replay: a box-domain spline fed values outside its interval
+    t = transforms.PiecewiseRationalQuadraticCDF(shape=[3], num_bins=4, tails=None).to(device).eval()
+    inside = torch.rand(64, 3, device=device)
+    g2 = GraphedCall(t.forward, inside)
+    y, lad = g2(inside)
+    assert torch.isfinite(y).all()
+    with pytest.raises(transforms.InputOutsideDomain):
+        g2(inside + 5.0)
