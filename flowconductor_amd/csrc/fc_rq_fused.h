@@ -9,7 +9,7 @@ namespace fc {
 
 constexpr int kRowsMin = 32;      // the entry takes multiples of 32 rows (tiles of 64 rows + one of 32)
 constexpr int kH = 64;            // hidden width (GEMM K)
-constexpr int kDt = 32;           // transformed dims
+constexpr int kDt = 32;           // transformed dims, at most (4 per wave; fewer dims leave waves without spline work)
 constexpr int kK = 8;             // spline bins
 constexpr int kPP = 24;           // parameters per dim, padded from 3K - 1 = 23
 
@@ -19,12 +19,13 @@ struct FusedArgs {
   const float* h;        // [N, 64] last hidden activation of the conditioner
   const float* wpad;     // [768, 64] final-layer weight, zero-padded from 23 to 24 rows per dim
   const float* bias;     // [768] padded bias
-  const int32_t* cols;   // [32]
+  const int32_t* cols;   // [dt]
   float* logabsdet;      // [N]
   uint32_t* err;
   int64_t tiles;         // full tiles (64 or 32 rows, see launch_fused3)
   int D;
   int accumulate;        // logabsdet[n] += instead of = (FC_RQ_ACCUMULATE_LOGABSDET)
+  int dt;                // transformed dims: a multiple of 4, <= 32
 };
 
 size_t fused3_lds_bytes(int d, int rows);

@@ -7,7 +7,8 @@
 // Unfused, the [N, 736] f32 parameter tensor is written by the GEMM and read back by the spline
 // kernel: 5.9 KB of HBM traffic per sample and layer for cfg 3, 85 % of everything the layer moves.
 // Fused, it only ever exists in registers.  Specialised for the north-star layer shape: H = 64, d_t = 32,
-// K = 8, linear tails (P = 23).
+// K = 8, linear tails (P = 23); d_t a multiple of 4 up to 32 (wave w owns dims 4w..4w+3; with fewer than 32
+// dims the remaining waves only move tiles).
 //
 // History of the structure (measurements per 2^20-row launch):
 //   1. f32-input MFMA, 4 producer + 4 consumer waves, parameters through LDS        1.43 ms
@@ -27,7 +28,8 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
                                          uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t, int32_t hidden,
                                          const fc_rq_config* cfg, void* stream) {
   if (!cfg || n < 0 || d < d_t) return hipErrorInvalidValue;
-  if (hidden != fc::kH || d_t != fc::kDt || cfg->num_bins != fc::kK || cfg->tails != 1 || d % 4 != 0 || d > 128)
+  if (hidden != fc::kH || d_t < 4 || d_t > fc::kDt || d_t % 4 != 0 || cfg->num_bins != fc::kK || cfg->tails != 1 ||
+      d % 4 != 0 || d > 128)
     return hipErrorInvalidValue;  // only the north-star layer shape is fused; callers fall back otherwise
   if (n % fc::kRowsMin != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
@@ -55,13 +57,13 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
   const bool wide_ok = fc::fused3_lds_bytes(d, 64) <= 160 * 1024;
   const int64_t n64 = wide_ok ? n - n % 64 : 0;
   if (n64 > 0) {
-    fc::FusedArgs a{x, y, h, w_pad, bias_pad, cols, logabsdet, err_flag, n64 / 64, d, acc};
+    fc::FusedArgs a{x, y, h, w_pad, bias_pad, cols, logabsdet, err_flag, n64 / 64, d, acc, d_t};
     const hipError_t e = fc::launch_fused3(op, a, 64, (unsigned)(cus < a.tiles ? cus : a.tiles), s);
     if (e != hipSuccess) return e;
   }
   if (n64 < n) {
     fc::FusedArgs a{x + n64 * d, y + n64 * d, h + n64 * fc::kH, w_pad, bias_pad, cols, logabsdet + n64, err_flag,
-                    (n - n64) / 32, d, acc};
+                    (n - n64) / 32, d, acc, d_t};
     return fc::launch_fused3(op, a, 32, (unsigned)(cus < a.tiles ? cus : a.tiles), s);
   }
   return hipSuccess;

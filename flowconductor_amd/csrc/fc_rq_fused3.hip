@@ -77,7 +77,8 @@ struct Fused3Lds {
 size_t fused3_lds_bytes(int d, int rows) { return rows == 64 ? Fused3Lds<64>::bytes(d) : Fused3Lds<32>::bytes(d); }
 
 // R: rows per tile (64, or 32), NB = R / 16 sample blocks per tile; XV: float4 of the x tile per thread
-template <bool kInv, int R, int XV>
+// kFull: all 32 dims (every wave has spline work; no per-wave guards in the loop)
+template <bool kInv, int R, int XV, bool kFull>
 __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, FusedArgs a) {
   using L = Fused3Lds<R>;
   constexpr int kHPiece = L::kHPiece;
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   const int64_t stride = gridDim.x;
   const int64_t tile0 = blockIdx.x;
   if (tile0 >= a.tiles) return;
-  if (tid < kDt) cs[tid] = a.cols[tid];
+  if (tid < kDt) cs[tid] = tid < a.dt ? a.cols[tid] : 0;
+  const int WD = kFull ? 8 : a.dt >> 2;          // dim groups = waves with spline work
+  const bool active = kFull || wave < WD;
   const float inv_div = op.inv_div;
 #if FC_ABL & 16
   const uint64_t stamp_r_entry = __builtin_amdgcn_s_memrealtime();
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     float wmax = 0.f;
 #pragma unroll
     for (int t = 0; t < kCt3; ++t) {
-      const int row = (4 * wave + (s16 >> 2)) * kPP + 4 * t + (s16 & 3);
+      const int row = (4 * (active ? wave : 0) + (s16 >> 2)) * kPP + 4 * t + (s16 & 3);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const float4* src = reinterpret_cast<const float4*>(a.wpad + (int64_t)row * kH + 32 * ks + 8 * g);
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   f32x4 bw[kCt3];
 #pragma unroll
   for (int t = 0; t < kCt3; ++t) {
-    const float* bsrc = a.bias + (4 * wave + g) * kPP + 4 * t;
+    const float* bsrc = a.bias + (4 * (active ? wave : 0) + g) * kPP + 4 * t;
     const float m = t < 4 ? inv_div : 1.f;   // params 0..15 are widths and heights
     bw[t] = f32x4{bsrc[0] * m, bsrc[1] * m, bsrc[2] * m, bsrc[3] * m};
   }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   // One step: evaluate this lane's element of block `cblk` of the tile in buffer `xb` from the accumulators
   // `pa`, and produce into `acc` the accumulators of block `pblk` of the tile in buffer `hb`.
   auto step = [&](const f32x4 (&pa)[kCt3], int xb, int cblk, f32x4 (&acc)[kCt3], int hb, int pblk) {
-    float* xr = xbuf + (xb * R + 16 * cblk + s16) * XS + cs[4 * wave + g];
+    float* xr = xbuf + (xb * R + 16 * cblk + s16) * XS + cs[(4 * wave + g) & (kDt - 1)];
     const float x = *xr;
     const float c_d = hscale[xb * R + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
     const float c_wh = c_d * inv_div;
@@ -336,7 +339,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
       const float* lp = lpart + x3 * 8 * R + tid;
       float l = lp[0];
 #pragma unroll
-      for (int w = 1; w < 8; ++w) l += lp[w * R];
+      for (int w = 1; w < 8; ++w)
+        if (w < WD) l += lp[w * R];
       // running total of the composite (base.py:51 `total_logabsdet += logabsdet`) or a fresh value
       a.logabsdet[t * R + tid] = a.accumulate ? a.logabsdet[t * R + tid] + l : l;
     }
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   fetch(tile0);
   park(0, 0);
   __syncthreads();
-  produce_only(acc0, 0, 0);   // block 0 of the first tile
+  if (active) produce_only(acc0, 0, 0);   // block 0 of the first tile
   int hb = 0, x3 = 0;          // ring slots of the current tile
   int64_t prev_tile = -1;
   for (int64_t tile = tile0; tile < a.tiles; tile += stride) {
@@ -354,10 +358,12 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     if (has_next) fetch(tile + stride);
     // Steps 0 .. NB-2: evaluate block j of `tile`, produce its block j + 1.  (acc0 / acc1 alternate; NB is
     // even, so every tile starts with its block 0 in acc0.)
-    step(acc0, x3, 0, acc1, hb, 1);
-    if constexpr (NB == 4) {
-      step(acc1, x3, 1, acc0, hb, 2);
-      step(acc0, x3, 2, acc1, hb, 3);
+    if (active) {
+      step(acc0, x3, 0, acc1, hb, 1);
+      if constexpr (NB == 4) {
+        step(acc1, x3, 1, acc0, hb, 2);
+        step(acc0, x3, 2, acc1, hb, 3);
+      }
     }
     FC_PHASE(1);
     if (has_next) park(hb ^ 1, x3n);
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     FC_PHASE(5);
     // Last step: evaluate block NB-1, produce block 0 of the next tile (unconditional: on the last tile the
     // MFMAs work on stale h rows into accumulators nobody reads -- a branch would split the interleaved block).
-    step(acc1, x3, NB - 1, acc0, hb ^ 1, 0);
+    if (active) step(acc1, x3, NB - 1, acc0, hb ^ 1, 0);
     FC_PHASE(4);
     prev_tile = tile;
     hb ^= 1;
@@ -395,19 +401,24 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #undef FC_TIMED_BARRIER
 #undef FC_PHASE
 
-template <bool kInv, int R, int XV>
-static hipError_t launch_one(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
+template <bool kInv, int R, int XV, bool kFull>
+static hipError_t launch_cfg(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
   const size_t lds = Fused3Lds<R>::bytes(a.D);
   if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rq_fused_linear_kernel3<kInv, R, XV>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rq_fused_linear_kernel3<kInv, R, XV, kFull>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((rq_fused_linear_kernel3<kInv, R, XV>), dim3(grid), dim3(512), lds, stream, op, a);
+  hipLaunchKernelGGL((rq_fused_linear_kernel3<kInv, R, XV, kFull>), dim3(grid), dim3(512), lds, stream, op, a);
   return hipGetLastError();
+}
+
+template <bool kInv, int R, int XV>
+static hipError_t launch_one(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
+  return a.dt == kDt ? launch_cfg<kInv, R, XV, true>(op, a, grid, stream) : launch_cfg<kInv, R, XV, false>(op, a, grid, stream);
 }
 
 // `a.tiles` counts tiles of `rows` rows (64 or 32)

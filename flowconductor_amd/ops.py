@@ -318,7 +318,8 @@ FUSED_ROWS, FUSED_HIDDEN, FUSED_DT, FUSED_BINS = 32, 64, 32, 8
 
 def fused_linear_supported(n, d, d_t, hidden, num_bins, tails):
     """Shapes the fused final-layer + RQ-spline kernel is specialised for (the north-star layer)."""
-    return (hidden == FUSED_HIDDEN and d_t == FUSED_DT and num_bins == FUSED_BINS and tails == "linear"
+    return (hidden == FUSED_HIDDEN and 4 <= d_t <= FUSED_DT and d_t % 4 == 0 and num_bins == FUSED_BINS
+            and tails == "linear"
             and d % 4 == 0 and d <= 128 and n >= FUSED_ROWS)
 
 
@@ -386,7 +387,9 @@ def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, t
     _hip.require_no_grad(inputs, hidden)
     n, d = x.shape
     cols = _as_cols(cols, x.device)
-    if n % FUSED_ROWS != 0 or h.shape != (n, FUSED_HIDDEN) or cols.numel() != FUSED_DT:
+    d_t = cols.numel()
+    if (n % FUSED_ROWS != 0 or h.shape != (n, FUSED_HIDDEN) or d_t % 4 != 0 or not 4 <= d_t <= FUSED_DT
+            or w_pad.shape[0] != d_t * 24):
         raise ValueError("fused RQ layer: unsupported shapes %s / %s" % (tuple(x.shape), tuple(h.shape)))
     cfg = _hip.RQConfig()
     cfg.num_bins, cfg.tails, cfg.inverse = num_bins, 1, 1 if inverse else 0
@@ -406,7 +409,7 @@ def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, t
     err = _err_word(x.device, True)
     _call("fc_rq_spline_fused_linear", lib.fc_rq_spline_fused_linear, x.device, _hip.ptr(x), _hip.ptr(y),
           _hip.ptr(h), _hip.ptr(w_pad), _hip.ptr(bias_pad), _hip.ptr(cols), _hip.ptr(lad), _hip.ptr(err), n, d,
-          FUSED_DT, FUSED_HIDDEN, cfg, _hip.stream_ptr(x.device))
+          d_t, FUSED_HIDDEN, cfg, _hip.stream_ptr(x.device))
     _finish(True)
     return y, lad
 

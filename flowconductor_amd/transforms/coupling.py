@@ -269,8 +269,8 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             wh_divisor=_softmax_divisor(self.transform_net, warn=True), inverse=inverse)
 
     # ---- fused final conditioner layer -------------------------------------------
-    # When the conditioner is this package's ResidualNet with the north-star shape (hidden 64, 32
-    # transformed dims, K = 8, linear tails) its last nn.Linear is evaluated INSIDE the spline kernel on
+    # When the conditioner is this package's ResidualNet with the north-star shape (hidden 64, K = 8, linear
+    # tails, a multiple of 4 transformed dims up to 32) its last nn.Linear is evaluated INSIDE the spline kernel on
     # the matrix cores (split-f16 products, f32-GEMM accuracy), so the [N, 736] parameter tensor never
     # touches HBM; the hidden layers run in fc_resnet_hidden.  Inference only.  Any other conditioner /
     # shape takes the generic path; FC_FUSED=0 disables it.
