@@ -17,15 +17,15 @@ struct FusedArgs {
   const float* x;        // [N, D]
   float* y;              // [N, D]
   const float* h;        // [N, 64] last hidden activation of the conditioner
-  const float* wpad;     // [768, 64] final-layer weight, zero-padded from 23 to 24 rows per dim
-  const float* bias;     // [768] padded bias
+  const float* wpad;     // [ceil(dt/4)*4*24, 64] final-layer weight, zero-padded from 23 to 24 rows per dim
+  const float* bias;     // padded bias, same rows
   const int32_t* cols;   // [dt]
   float* logabsdet;      // [N]
   uint32_t* err;
   int64_t tiles;         // full tiles (64 or 32 rows, see launch_fused3)
   int D;
   int accumulate;        // logabsdet[n] += instead of = (FC_RQ_ACCUMULATE_LOGABSDET)
-  int dt;                // transformed dims: a multiple of 4, <= 32
+  int dt;                // transformed dims, <= 32 (wpad / bias hold ceil(dt / 4) * 4 dims)
 };
 
 size_t fused3_lds_bytes(int d, int rows);

@@ -7,8 +7,9 @@
 // Unfused, the [N, 736] f32 parameter tensor is written by the GEMM and read back by the spline
 // kernel: 5.9 KB of HBM traffic per sample and layer for cfg 3, 85 % of everything the layer moves.
 // Fused, it only ever exists in registers.  Specialised for the north-star layer shape: H = 64, d_t = 32,
-// K = 8, linear tails (P = 23); d_t a multiple of 4 up to 32 (wave w owns dims 4w..4w+3; with fewer than 32
-// dims the remaining waves only move tiles).
+// K = 8, linear tails (P = 23); up to 32 transformed dims (wave w owns dims 4w..4w+3; the weight image is padded
+// to a multiple of 4 dims, padding lanes evaluate but do not write; with fewer than 29 dims the remaining waves
+// only move tiles).
 //
 // History of the structure (measurements per 2^20-row launch):
 //   1. f32-input MFMA, 4 producer + 4 consumer waves, parameters through LDS        1.43 ms
@@ -28,7 +29,7 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
                                          uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t, int32_t hidden,
                                          const fc_rq_config* cfg, void* stream) {
   if (!cfg || n < 0 || d < d_t) return hipErrorInvalidValue;
-  if (hidden != fc::kH || d_t < 4 || d_t > fc::kDt || d_t % 4 != 0 || cfg->num_bins != fc::kK || cfg->tails != 1 ||
+  if (hidden != fc::kH || d_t < 1 || d_t > fc::kDt || cfg->num_bins != fc::kK || cfg->tails != 1 ||
       d % 4 != 0 || d > 128)
     return hipErrorInvalidValue;  // only the north-star layer shape is fused; callers fall back otherwise
   if (n % fc::kRowsMin != 0) return hipErrorInvalidValue;

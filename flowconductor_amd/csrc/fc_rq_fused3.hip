@@ -99,7 +99,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   const int64_t tile0 = blockIdx.x;
   if (tile0 >= a.tiles) return;
   if (tid < kDt) cs[tid] = tid < a.dt ? a.cols[tid] : 0;
-  const int WD = kFull ? 8 : a.dt >> 2;          // dim groups = waves with spline work
+  const int WD = kFull ? 8 : (a.dt + 3) >> 2;    // dim groups = waves with spline work
+  const bool dim_ok = kFull || 4 * wave + g < a.dt;   // (the last group may be partly padding)
   const bool active = kFull || wave < WD;
   const float inv_div = op.inv_div;
 #if FC_ABL & 16
@@ -295,9 +296,9 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #undef FC_UD
 #undef FC_WH
 #undef FC_HOOK
-    *xr = y;
+    if (dim_ok) *xr = y;
     // logabsdet partial of this wave's 4 dims: lanes s, s+16, s+32, s+48 hold the same sample
-    const float l = rows4_allsum(lad, lane);
+    const float l = rows4_allsum(dim_ok ? lad : 0.f, lane);
     if (g == 0) lpart[(xb * 8 + wave) * R + 16 * cblk + s16] = l;
   };
 

@@ -318,8 +318,7 @@ FUSED_ROWS, FUSED_HIDDEN, FUSED_DT, FUSED_BINS = 32, 64, 32, 8
 
 def fused_linear_supported(n, d, d_t, hidden, num_bins, tails):
     """Shapes the fused final-layer + RQ-spline kernel is specialised for (the north-star layer)."""
-    return (hidden == FUSED_HIDDEN and 4 <= d_t <= FUSED_DT and d_t % 4 == 0 and num_bins == FUSED_BINS
-            and tails == "linear"
+    return (hidden == FUSED_HIDDEN and 1 <= d_t <= FUSED_DT and num_bins == FUSED_BINS and tails == "linear"
             and d % 4 == 0 and d <= 128 and n >= FUSED_ROWS)
 
 
@@ -362,15 +361,18 @@ def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks):
 
 
 def pack_final_layer(weight, bias, num_bins=FUSED_BINS):
-    """[d_t*23, 64] weight / [d_t*23] bias of the conditioner's final Linear -> (w_pad [d_t*24, 64],
-    bias_pad [d_t*24]): one zero row / entry appended per dim so that the 768 columns form whole MFMA tiles."""
+    """[d_t*23, 64] weight / [d_t*23] bias of the conditioner's final Linear -> (w_pad [dp*24, 64], bias_pad
+    [dp*24]): one zero row / entry appended per dim so that a dim is 24 = 6 x 4 accumulator registers, and zero
+    dims appended up to dp = ceil(d_t / 4) * 4 (a wave owns 4 dims)."""
     p = 3 * num_bins - 1
     d_t = weight.shape[0] // p
+    dp = -(-d_t // 4) * 4
     w = weight.detach().reshape(d_t, p, weight.shape[1])
-    wpad = torch.cat((w, w.new_zeros(d_t, 1, weight.shape[1])), dim=1).reshape(d_t * (p + 1), weight.shape[1])
-    b = bias.detach().reshape(d_t, p)
-    bpad = torch.cat((b, b.new_zeros(d_t, 1)), dim=1).reshape(-1)
-    return wpad.contiguous(), bpad.contiguous()
+    wpad = w.new_zeros(dp, p + 1, weight.shape[1])
+    wpad[:d_t, :p] = w
+    bpad = bias.new_zeros(dp, p + 1)
+    bpad[:d_t, :p] = bias.detach().reshape(d_t, p)
+    return wpad.reshape(dp * (p + 1), weight.shape[1]).contiguous(), bpad.reshape(-1).contiguous()
 
 
 def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, tail_bound,
@@ -388,8 +390,8 @@ def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, t
     n, d = x.shape
     cols = _as_cols(cols, x.device)
     d_t = cols.numel()
-    if (n % FUSED_ROWS != 0 or h.shape != (n, FUSED_HIDDEN) or d_t % 4 != 0 or not 4 <= d_t <= FUSED_DT
-            or w_pad.shape[0] != d_t * 24):
+    if (n % FUSED_ROWS != 0 or h.shape != (n, FUSED_HIDDEN) or not 1 <= d_t <= FUSED_DT
+            or w_pad.shape[0] != -(-d_t // 4) * 4 * 24):
         raise ValueError("fused RQ layer: unsupported shapes %s / %s" % (tuple(x.shape), tuple(h.shape)))
     cfg = _hip.RQConfig()
     cfg.num_bins, cfg.tails, cfg.inverse = num_bins, 1, 1 if inverse else 0

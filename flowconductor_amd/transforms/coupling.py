@@ -270,7 +270,7 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
 
     # ---- fused final conditioner layer -------------------------------------------
     # When the conditioner is this package's ResidualNet with the north-star shape (hidden 64, K = 8, linear
-    # tails, a multiple of 4 transformed dims up to 32) its last nn.Linear is evaluated INSIDE the spline kernel on
+    # tails, up to 32 transformed dims) its last nn.Linear is evaluated INSIDE the spline kernel on
     # the matrix cores (split-f16 products, f32-GEMM accuracy), so the [N, 736] parameter tensor never
     # touches HBM; the hidden layers run in fc_resnet_hidden.  Inference only.  Any other conditioner /
     # shape takes the generic path; FC_FUSED=0 disables it.

@@ -183,12 +183,13 @@ def test_composite_accumulates_logabsdet_in_kernel(n, inverse, device):
 
 
 @pytest.mark.parametrize("d,n,d_t", [(36, 96, 32), (48, 4096, 32), (64, 32, 32), (96, 2080, 32), (112, 640, 32),
-                                     (128, 1056, 32), (32, 4096, 16), (8, 160, 4), (40, 992, 20), (64, 2048, 28)])
+                                     (128, 1056, 32), (32, 4096, 16), (8, 160, 4), (40, 992, 20), (64, 2048, 28), (44, 2048, 21),
+                                     (12, 96, 1), (64, 320, 31)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fused_linear_input_widths(d, n, d_t, inverse, device):
     """The fused kernel's tile variants: 64-row tiles with 1 / 2 / 4 float4 of x per thread (D <= 32 / 64 /
-    112), 32-row tiles for wider inputs and for the last 32 rows of an odd multiple of 32; any multiple of 4
-    transformed dims up to 32 (wave w owns dims 4w..4w+3)."""
+    112), 32-row tiles for wider inputs and for the last 32 rows of an odd multiple of 32; any number of
+    transformed dims up to 32 (wave w owns dims 4w..4w+3; the last group may be partly padding)."""
     torch.manual_seed(d)
     k, hidden = 8, 64
     x = torch.randn(n, d) * 1.5
