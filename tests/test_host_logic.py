@@ -163,3 +163,14 @@ def test_pack_resnet_hidden_stacks_linear_weights():
     assert torch.equal(wb[1], net.blocks[0].linear_layers[1].weight) and torch.equal(bb[2], net.blocks[1].linear_layers[0].bias)
     w0, b0, wb, bb = ops.pack_resnet_hidden(nets.ResidualNet(6, 8, hidden_features=64, num_blocks=0))
     assert wb is None and bb is None and w0.shape == (64, 6)
+
+
+def test_generated_fused_eval_is_current():
+    """flowconductor_amd/csrc/fc_rq_fused3_eval.inc is generated; the committed copy must be the generator's output."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rc = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_fused_eval.py"), "--check"]).returncode
+    assert rc == 0, "run python tools/gen_fused_eval.py and commit the result"

@@ -6,12 +6,14 @@ over its instruction stream.  hipcc's sched_group_barrier pipeline clusters abou
 so the interleave is explicit in the source: FC_HOOK(n) issues MFMA number n of the NEXT block and pins its
 position with a sched_barrier.
 
-    python tools/gen_fused_eval.py        # rewrites the .inc (committed; the build does not run this)
+    python tools/gen_fused_eval.py          # rewrites the .inc (committed; the build does not run this)
+    python tools/gen_fused_eval.py --check  # exit status 1 if the committed .inc differs
 
 The arithmetic and its order are those of RQOp::eval_tails_straight (fc_rq_op.h), which restates
 flowcon/transforms/splines/rational_quadratic.py:26-38 (tails) and :78-188 (spline).
 """
 import os
+import sys
 
 K = 8
 HOOKS = 36
@@ -116,5 +118,8 @@ while hook < HOOKS:
     hook += 1
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flowconductor_amd", "csrc",
                     "fc_rq_fused3_eval.inc")
-open(path, "w").write("\n".join(out) + "\n")
+text = "\n".join(out) + "\n"
+if "--check" in sys.argv:      # tests/test_host_logic.py: the committed file is what this script generates
+    sys.exit(0 if open(path).read() == text else 1)
+open(path, "w").write(text)
 print("wrote", path, "chunks", len(chunks), "weight", total)
