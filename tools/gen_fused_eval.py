@@ -33,10 +33,17 @@ for i in range(K):
 for j in range(K - 1):
     add("FC_DER_ST(%d, FC_UD(%d));" % (j + 1, j), 1)
 add("const FC_F2 m = {mx, my};\nFC_F2 sum = {0.f, 0.f};", 0)
+# Software scheduling (the hooks pin the order, so independent work is laid out by hand): all subtractions /
+# multiplications first, then the 16 exponentials, then the running sum -- a dependent instruction is never the
+# next one issued (packed f32 results need a wait state, transcendentals several).
 for i in range(K):
     # exp_softmax(d) = exp2(d * log2e): the multiply as one packed op for both axes
-    add("t%d = (t%d - m) * FC_F2{1.4426950408889634f, 1.4426950408889634f};" % (i, i), 2)
+    add("t%d = t%d - m;" % (i, i), 1)
+for i in range(K):
+    add("t%d = t%d * FC_F2{1.4426950408889634f, 1.4426950408889634f};" % (i, i), 1)
+for i in range(K):
     add("t%d = FC_F2{__builtin_amdgcn_exp2f(t%d.x), __builtin_amdgcn_exp2f(t%d.y)};" % (i, i, i), 4)
+for i in range(K):
     add("sum += t%d;" % i, 1)
 add("const float rsx = div_lean(1.f, sum.x);", 5)
 add("const float rsy = div_lean(1.f, sum.y);\nconst FC_F2 rs = {rsx, rsy};", 5)
@@ -44,12 +51,27 @@ add("const float rsy = div_lean(1.f, sum.y);\nconst FC_F2 rs = {rsx, rsy};", 5)
 # (slots 0 and K hold the interval ends, written once per kernel), the bin index is a count of compares, and
 # the two knots / two derivative logits of the bin come back with four LDS reads.
 add("FC_CUM_T cx = 0, cy = 0;\nint idx = 0;", 1)
-for i in range(K - 1):   # the last knot is pinned to the interval end: bin K - 1's width is never summed
-    add("const FC_F2 w%d = minb + c1 * (t%d * rs);" % (i, i), 3)
-    if True:
-        add("cx += (FC_CUM_T)w%d.x;\ncy += (FC_CUM_T)w%d.y;" % (i, i), 4)
-        add("const FC_F2 next%d = span * FC_F2{(float)cx, (float)cy} + lo;\nFC_KNOT_ST(%d, next%d);" % (i, i + 1, i), 4)
-        add("idx += (xc >= (kInv ? next%d.y : next%d.x)) ? 1 : 0;" % (i, i), 2)
+# bin widths / heights of bins 0..K-2 (the last knot is pinned to the interval end: bin K-1 is never summed),
+# then their conversions, then the two running sums with the knot of step i-1 finished while step i adds
+for i in range(K - 1):
+    add("const FC_F2 pr%d = t%d * rs;" % (i, i), 1)
+for i in range(K - 1):
+    add("const FC_F2 w%d = minb + c1 * pr%d;" % (i, i), 2)
+for i in range(K - 1):
+    add("const FC_CUM_T wx%d = (FC_CUM_T)w%d.x, wy%d = (FC_CUM_T)w%d.y;" % (i, i, i, i), 2)
+
+
+def finish_knot(i):
+    add("const FC_F2 next%d = span * FC_F2{cfx%d, cfy%d} + lo;\nFC_KNOT_ST(%d, next%d);" % (i, i, i, i + 1, i), 2)
+    add("idx += (xc >= (kInv ? next%d.y : next%d.x)) ? 1 : 0;" % (i, i), 2)
+
+
+for i in range(K - 1):
+    add("cx += wx%d;\ncy += wy%d;" % (i, i), 2)
+    add("const float cfx%d = (float)cx, cfy%d = (float)cy;" % (i, i), 2)
+    if i > 0:
+        finish_knot(i - 1)
+finish_knot(K - 2)
 add("const FC_F2 sel_lo = FC_KNOT_LD(idx, 0), sel_hi = FC_KNOT_LD(idx, 1);\n"
     "const float u0 = FC_DER_LD(idx, 0), u1 = FC_DER_LD(idx, 1);", 3)
 add("const float xk = sel_lo.x, yk = sel_lo.y;\nconst float wk = sel_hi.x - sel_lo.x, hk = sel_hi.y - sel_lo.y;", 2)
