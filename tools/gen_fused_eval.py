@@ -127,12 +127,15 @@ out = ["// GENERATED by tools/gen_fused_eval.py -- do not edit by hand.",
        "// Expects in scope: FC_WH(i) / FC_UD(j) (logits of the element), FC_KNOT_ST / FC_KNOT_LD / FC_DER_ST / FC_DER_LD",
        "// (lane-private LDS tables of K + 1 knots and K + 1 derivative logits), FC_F2, FC_CUM_T, x, q, inv_beta, err,",
        "// kInv (constexpr bool), outputs y / lad, and FC_HOOK(n)."]
+# hook placement: hook k sits where the accumulated weight passes (k + 1 - SHIFT) / HOOKS of the total
+# (FC_GEN_SHIFT: probe knob for tools/probe/search_hooks.sh; the committed file uses 0)
+SHIFT = float(os.environ.get("FC_GEN_SHIFT", "0"))
 acc = 0.0
 hook = 0
 for code, w in chunks:
     out.append(code)
     acc += w
-    while hook < HOOKS and acc >= (hook + 1) * total / HOOKS:
+    while hook < HOOKS and acc >= (hook + 1 - SHIFT) * total / HOOKS:
         out.append("FC_HOOK(%d)" % hook)
         hook += 1
 while hook < HOOKS:
