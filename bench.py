@@ -47,7 +47,7 @@ def build_flow():
     return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([FEATURES])).eval()
 
 
-TRAFFIC_PROFILE = "profiles/r01f_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r01g_hbm_traffic.json"
 
 
 def measured_traffic_per_launch(entry, rows_per_launch):
@@ -279,7 +279,7 @@ def main():
                                "launches_timed": len(fused_ms), "avg_launch_ms": f_avg,
                                "algorithmic_bytes_per_launch": f_bytes,
                                "share_of_step": sum(fused_ms) / (1e3 * elapsed),
-                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01f_fused_sq_counters.txt",
+                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01g_fused_sq_counters.txt",
                                "matrix_pipe": {"algorithmic_tflops": flops / (f_avg * 1e-3) / 1e12,
                                                "executed_tflops": 3.0 * (24.0 / 23.0) * flops / (f_avg * 1e-3) / 1e12,
                                                "peak_f16_dense_tflops": MFMA_F16_PEAK_TFLOPS,
