@@ -174,3 +174,53 @@ def test_generated_fused_eval_is_current():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rc = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_fused_eval.py"), "--check"]).returncode
     assert rc == 0, "run python tools/gen_fused_eval.py and commit the result"
+
+
+def test_pack_final_layer_pads_dims_to_groups_of_four():
+    from flowconductor_amd import ops
+
+    for d_t in (1, 5, 16, 21, 32):
+        w = torch.randn(d_t * 23, 64)
+        b = torch.randn(d_t * 23)
+        wpad, bpad = ops.pack_final_layer(w, b)
+        dp = -(-d_t // 4) * 4
+        assert wpad.shape == (dp * 24, 64) and bpad.shape == (dp * 24,)
+        wv, bv = wpad.view(dp, 24, 64), bpad.view(dp, 24)
+        assert torch.equal(wv[:d_t, :23], w.view(d_t, 23, 64)) and torch.equal(bv[:d_t, :23], b.view(d_t, 23))
+        assert float(wv[:, 23].abs().sum()) == 0.0 and float(wv[d_t:].abs().sum()) == 0.0
+        assert float(bv[:, 23].abs().sum()) == 0.0 and float(bv[d_t:].abs().sum()) == 0.0
+
+
+def test_fused_path_shape_predicates():
+    from flowconductor_amd import ops
+
+    ok = dict(n=4096, d=64, d_t=32, hidden=64, num_bins=8, tails="linear")
+    assert ops.fused_linear_supported(**ok)
+    for key, bad in (("hidden", 128), ("num_bins", 10), ("tails", None), ("d", 66), ("d", 132), ("d_t", 33), ("n", 16)):
+        assert not ops.fused_linear_supported(**{**ok, key: bad}), (key, bad)
+    assert ops.fused_linear_supported(**{**ok, "d_t": 7, "d": 12})
+    assert ops.sylvester_mm_supported(1024, 128) and ops.sylvester_mm_supported(16, 32)
+    assert not ops.sylvester_mm_supported(1024, 100) and not ops.sylvester_mm_supported(8, 64)
+    assert not ops.sylvester_mm_supported(1024, 160)
+
+
+def test_householder_matrix_matches_sequential_reflections():
+    from flowconductor_amd import ops
+    from oracle import torch_oracle as O
+
+    torch.manual_seed(2)
+    q = torch.randn(5, 12)
+    v = torch.randn(7, 12)
+    for reverse in (False, True):
+        m = ops.householder_matrix(q, reverse=reverse)
+        ref = O.householder_apply(v.double(), (q.flip(0) if reverse else q).double())
+        assert torch.allclose(v.double() @ m, ref, atol=1e-12)
+    w1, w2, rd = ops.pack_sylvester(q, torch.triu(torch.randn(12, 12)), torch.triu(torch.randn(12, 12)))
+    assert w1.shape == (12, 12) and w2.shape == (12, 12) and rd.shape == (12,) and w1.dtype == torch.float32
+
+
+def test_graphed_call_rejects_cpu_tensors():
+    from flowconductor_amd.utils.graphs import GraphedCall
+
+    with pytest.raises(ValueError):
+        GraphedCall(lambda t: t, torch.zeros(4, 2))
