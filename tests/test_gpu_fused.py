@@ -246,3 +246,32 @@ def test_made_hidden_stack_on_hip_kernel(kind, inverse, device, monkeypatch):
     assert maxdiff(y, ref_y) <= tol * scale
     assert maxdiff(lad, ref_lad) <= 10 * tol * max(1.0, float(ref_lad.abs().max()) / 10)
     assert maxdiff(y, y2) <= tol * scale
+
+
+@pytest.mark.parametrize("features,n", [(32, 1000), (20, 333), (63, 200)])
+def test_fused_flow_other_widths(features, n, device, monkeypatch):
+    """Flows whose coupling layers transform fewer than 32 dims (D = 32 -> 16, D = 20 -> 10) take the fused kernels
+    too; an odd feature count (63: rows not a multiple of 4 floats) must fall back cleanly.  Against the oracle."""
+    from flowconductor_amd import distributions, flows, transforms, utils
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(features)
+    layers = [transforms.PiecewiseRationalQuadraticCouplingTransform(
+        utils.create_alternating_binary_mask(features, even=(i % 2 == 0)),
+        lambda a, b: nets.ResidualNet(a, b, hidden_features=64, num_blocks=2), num_bins=8, tails="linear",
+        tail_bound=3.0) for i in range(4)]
+    flow = flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([features])).eval()
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.mul_(1.5)
+    x = torch.randn(n, features) * 1.3
+    with torch.no_grad():
+        ref = O.flow_log_prob(flow, x)
+    flow = flow.to(device)
+    with torch.no_grad(), ops.KernelTimer("fc_rq_spline_fused_linear") as timer:
+        lp = flow.log_prob(x.to(device))
+    expected = 0 if features % 4 else 4 * (2 if n % 32 and n >= 32 else 1)
+    assert len(timer.pairs) in (expected, 4), (len(timer.pairs), expected)
+    if features % 4:
+        assert len(timer.pairs) == 0
+    assert maxdiff(lp, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
