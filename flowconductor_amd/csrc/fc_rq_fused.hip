@@ -30,7 +30,7 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
                                          const fc_rq_config* cfg, void* stream) {
   if (!cfg || n < 0 || d < d_t) return hipErrorInvalidValue;
   if (hidden != fc::kH || d_t < 1 || d_t > fc::kDt || cfg->num_bins != fc::kK || cfg->tails != 1 ||
-      d % 4 != 0 || d > 128)
+      d > 128)
     return hipErrorInvalidValue;  // only the north-star layer shape is fused; callers fall back otherwise
   if (n % fc::kRowsMin != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;

@@ -77,8 +77,8 @@ struct Fused3Lds {
 size_t fused3_lds_bytes(int d, int rows) { return rows == 64 ? Fused3Lds<64>::bytes(d) : Fused3Lds<32>::bytes(d); }
 
 // R: rows per tile (64, or 32), NB = R / 16 sample blocks per tile; XV: float4 of the x tile per thread
-// kFull: all 32 dims (every wave has spline work; no per-wave guards in the loop)
-template <bool kInv, int R, int XV, bool kFull>
+// kFull: all 32 dims (every wave has spline work; no per-wave guards in the loop); kPadX: D % 4 == 0
+template <bool kInv, int R, int XV, bool kFull, bool kPadX>
 __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, FusedArgs a) {
   using L = Fused3Lds<R>;
   constexpr int kHPiece = L::kHPiece;
@@ -90,8 +90,11 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   float* hscale = lpart + 3 * 8 * R;                                                  // [3][R]
   float* tabs = hscale + 3 * R;                                                       // [8 waves][knots | derivs]
   float* xbuf = tabs + kTabBytes / 4;                                                 // [2][R][D + 4]
-  const int D = a.D, XS = D + 4;
-  int* cs = reinterpret_cast<int*>(xbuf + 3 * R * XS);                                // [kDt]
+  // x rows in LDS: padded by 4 floats when D is a multiple of 4 (bank spread, float4 pieces stay inside a row);
+  // for other D the tile is kept as the contiguous [R * D] block it is in memory (an odd stride spreads the banks
+  // by itself) -- R * D is always a whole number of float4
+  const int D = a.D, XS = kPadX ? D + 4 : D;
+  int* cs = reinterpret_cast<int*>(xbuf + 3 * R * (D + 4));                           // [kDt]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s16 = lane & 15, g = lane >> 4;
@@ -183,7 +186,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     if constexpr (XV > 2) xv2 = xg[tid + 1024 < xvec ? tid + 1024 : 0];
     if constexpr (XV > 3) xv3 = xg[tid + 1536 < xvec ? tid + 1536 : 0];
   };
-  auto xslot = [&](int buf, int i) __attribute__((always_inline)) {   // float4 index i of a [R, D] tile -> its padded LDS position
+  auto xslot = [&](int buf, int i) __attribute__((always_inline)) {   // float4 index i of a [R, D] tile -> its LDS position
+    if constexpr (!kPadX) return reinterpret_cast<float4*>(xbuf + buf * R * XS + 4 * i);
     const int e = i * 4, r = e / D, c = e - r * D;
     return reinterpret_cast<float4*>(xbuf + (buf * R + r) * XS + c);
   };
@@ -402,24 +406,26 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #undef FC_TIMED_BARRIER
 #undef FC_PHASE
 
-template <bool kInv, int R, int XV, bool kFull>
+template <bool kInv, int R, int XV, bool kFull, bool kPadX>
 static hipError_t launch_cfg(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
   const size_t lds = Fused3Lds<R>::bytes(a.D);
   if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rq_fused_linear_kernel3<kInv, R, XV, kFull>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rq_fused_linear_kernel3<kInv, R, XV, kFull, kPadX>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((rq_fused_linear_kernel3<kInv, R, XV, kFull>), dim3(grid), dim3(512), lds, stream, op, a);
+  hipLaunchKernelGGL((rq_fused_linear_kernel3<kInv, R, XV, kFull, kPadX>), dim3(grid), dim3(512), lds, stream, op, a);
   return hipGetLastError();
 }
 
 template <bool kInv, int R, int XV>
 static hipError_t launch_one(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
-  return a.dt == kDt ? launch_cfg<kInv, R, XV, true>(op, a, grid, stream) : launch_cfg<kInv, R, XV, false>(op, a, grid, stream);
+  if (a.D & 3) return launch_cfg<kInv, R, XV, false, false>(op, a, grid, stream);   // unpadded rows: generic variant
+  return a.dt == kDt ? launch_cfg<kInv, R, XV, true, true>(op, a, grid, stream)
+                     : launch_cfg<kInv, R, XV, false, true>(op, a, grid, stream);
 }
 
 // `a.tiles` counts tiles of `rows` rows (64 or 32)

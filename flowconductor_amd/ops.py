@@ -319,7 +319,7 @@ FUSED_ROWS, FUSED_HIDDEN, FUSED_DT, FUSED_BINS = 32, 64, 32, 8
 def fused_linear_supported(n, d, d_t, hidden, num_bins, tails):
     """Shapes the fused final-layer + RQ-spline kernel is specialised for (the north-star layer)."""
     return (hidden == FUSED_HIDDEN and 1 <= d_t <= FUSED_DT and num_bins == FUSED_BINS and tails == "linear"
-            and d % 4 == 0 and d <= 128 and n >= FUSED_ROWS)
+            and d <= 128 and n >= FUSED_ROWS)
 
 
 HIDDEN_ROWS = 16

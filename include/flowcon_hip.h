@@ -69,7 +69,7 @@ int fc_rq_spline(const float* x, float* y, const float* params, const int32_t* c
 /* Final conditioner layer fused with the RQ-spline coupling bijector: the [n, d_t*(3K-1)] parameter
  * tensor  h @ W^T + b  (flowcon/nn/nets/resnet.py:91,99 final_layer) is produced on the matrix cores (three-term
  * scaled f16 splits, f32-GEMM accuracy) straight into the registers of the lanes that evaluate the spline
- * (coupling.py:279-293, 549-582); it never reaches HBM.  cfg->flags: FC_RQ_ACCUMULATE_LOGABSDET.  Specialised: hidden == 64, 1 <= d_t <= 32, K == 8, linear tails, d % 4 == 0, d <= 128,
+ * (coupling.py:279-293, 549-582); it never reaches HBM.  cfg->flags: FC_RQ_ACCUMULATE_LOGABSDET.  Specialised: hidden == 64, 1 <= d_t <= 32, K == 8, linear tails, d <= 128,
  * n % 32 == 0 (callers route other shapes / the leftover rows through fc_rq_spline).
  *   h        [n, 64]  last hidden activation of the conditioner (input of its final Linear)
  *   w_pad    [dp*24, 64]  the weight, zero-padded from 23 to 24 rows per dim (row j*24+i = W row j*23+i, i < 23)

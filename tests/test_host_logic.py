@@ -196,7 +196,7 @@ def test_fused_path_shape_predicates():
 
     ok = dict(n=4096, d=64, d_t=32, hidden=64, num_bins=8, tails="linear")
     assert ops.fused_linear_supported(**ok)
-    for key, bad in (("hidden", 128), ("num_bins", 10), ("tails", None), ("d", 66), ("d", 132), ("d_t", 33), ("n", 16)):
+    for key, bad in (("hidden", 128), ("num_bins", 10), ("tails", None), ("d", 132), ("d_t", 33), ("n", 16)):
         assert not ops.fused_linear_supported(**{**ok, key: bad}), (key, bad)
     assert ops.fused_linear_supported(**{**ok, "d_t": 7, "d": 12})
     assert ops.sylvester_mm_supported(1024, 128) and ops.sylvester_mm_supported(16, 32)
