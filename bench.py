@@ -280,6 +280,16 @@ def main():
                                "algorithmic_bytes_per_launch": f_bytes,
                                "share_of_step": sum(fused_ms) / (1e3 * elapsed),
                                "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01g_fused_sq_counters.txt",
+                               # BASELINE.md section 4 prices a coupling bijector at B = 4 d_t (P + 2) + 8 bytes per
+                               # sample and layer (parameters read from HBM).  The fused kernel never moves them; in
+                               # that accounting it delivers:
+                               "baseline_md_accounting": {
+                                   "bytes_per_sample_layer": algorithmic_bytes_per_sample_layer(),
+                                   "kernel_GBs": alg_bytes / (f_avg * 1e-3) / 1e9,
+                                   "kernel_frac_of_hbm_peak": alg_bytes / (f_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "whole_step_GBs": alg_bytes * LAYERS / (elapsed / args.steps) / 1e9,
+                                   "whole_step_frac_of_hbm_peak": alg_bytes * LAYERS / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+                                   "note": "whole step = conditioner + bijector + base distribution, per GPU"},
                                "matrix_pipe": {"algorithmic_tflops": flops / (f_avg * 1e-3) / 1e12,
                                                "executed_tflops": 3.0 * (24.0 / 23.0) * flops / (f_avg * 1e-3) / 1e12,
                                                "peak_f16_dense_tflops": MFMA_F16_PEAK_TFLOPS,
