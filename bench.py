@@ -137,6 +137,28 @@ def parity(flow, flow_cpu, device, rows=2048):
             "rows": rows}
 
 
+def trained_like(flow_cpu, rows=2048):
+    """BASELINE.md section 3's second variant: conditioner outputs ~ N(0, 1) so that every spline bin is exercised
+    (default-initialised conditioners give near-identity splines).  Re-draws each layer's final Linear, layer by
+    layer on the data the previous layers produce, so that its outputs have unit scale."""
+    import copy
+
+    from oracle import torch_oracle as O
+
+    flow2 = copy.deepcopy(flow_cpu)
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(rows, FEATURES, generator=gen)
+    with torch.no_grad():
+        for t in flow2._transform._transforms:
+            net = t.transform_net
+            h = net.hidden(x[:, t.identity_features])
+            lin = net.final_layer
+            lin.weight.copy_(torch.randn(lin.weight.shape, generator=gen) / (HIDDEN ** 0.5 * float(h.std())))
+            lin.bias.copy_(torch.randn(lin.bias.shape, generator=gen) * 0.1)
+            x, _ = O.transform_apply(t, x)
+    return flow2
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,6 +338,13 @@ def main():
             flow_cpu = build_flow()
             out["parity"] = parity(flow, flow_cpu, device)
             log("parity done: %s" % out["parity"])
+            # the same check with trained-like conditioners (parameters ~ N(0, 1): every bin, steep derivatives)
+            import copy
+            flow_tl_cpu = trained_like(flow_cpu)
+            flow_tl = copy.deepcopy(flow_tl_cpu).to(device).eval()
+            out["parity_trained_like"] = parity(flow_tl, flow_tl_cpu, device)
+            del flow_tl
+            log("parity (trained-like weights) done: %s" % out["parity_trained_like"])
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(flow_cpu, 1 << args.cpu_sample_log2, 1 << 14)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
