@@ -1,8 +1,8 @@
 """Masked autoregressive transforms (API of flowcon/transforms/autoregressive/autoregressive.py).
 
-``forward`` = one MADE pass (PyTorch-ROCm) + one HIP element-wise kernel; ``inverse`` = D
-sequential MADE passes, each followed by the element-wise inverse kernel on all dims
-(reference autoregressive.py:39-53 -- same fixed-point iteration, same cost model).
+``forward`` = one MADE pass + one HIP element-wise kernel; ``inverse`` = D sequential passes
+(reference autoregressive.py:39-53), each of which here only computes what it fixes: the
+hidden stack, the final-layer rows of dim d and the element-wise inverse of column d.
 """
 import os
 
@@ -25,29 +25,43 @@ class AutoregressiveTransform(Transform):
         super().__init__()
         self.autoregressive_net = autoregressive_net
 
-    def _conditioner(self, inputs, context):
-        """``autoregressive_net(inputs, context)``; a MADE whose hidden stack ``fc_resnet_hidden`` covers (hidden
-        64, residual blocks, ReLU, no context) runs it there on pre-masked weights -- inference only."""
+    def _hidden(self, inputs, context):
+        """Everything before the conditioner's final layer, or None when the net is not a MADE-like module with
+        ``hidden`` / ``final_layer``.  A MADE whose hidden stack ``fc_resnet_hidden`` covers (hidden 64, residual
+        blocks, ReLU, no context) runs it there on pre-masked weights -- inference only."""
         net = self.autoregressive_net
+        if not (hasattr(net, "hidden") and hasattr(net, "final_layer")):
+            return None
         n = inputs.shape[0]
         if (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
                 and n >= ops.HIDDEN_ROWS and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
                 and getattr(net, "hip_hidden_supported", None) is not None and net.hip_hidden_supported()
-                and hasattr(net, "final_layer")
-                and not (torch.is_grad_enabled()
-                         and (inputs.requires_grad or any(p.requires_grad for p in net.parameters())))):
+                and not self._needs_grad(inputs)):
             body = n - n % ops.HIDDEN_ROWS
             hidden = net.hidden_hip(inputs[:body].contiguous())
             if body < n:
                 hidden = torch.cat((hidden, net.hidden(inputs[body:])))
-            return net.final_layer(hidden)
-        return net(inputs, context)
+            return hidden
+        return net.hidden(inputs, context)
+
+    def _needs_grad(self, inputs):
+        return torch.is_grad_enabled() and (inputs.requires_grad
+                                            or any(p.requires_grad for p in self.autoregressive_net.parameters()))
+
+    def _conditioner(self, inputs, context):
+        """``autoregressive_net(inputs, context)``."""
+        hidden = self._hidden(inputs, context) if inputs.dim() == 2 else None
+        if hidden is None:
+            return self.autoregressive_net(inputs, context)
+        return self.autoregressive_net.final_layer(hidden)
 
     def forward(self, inputs, context=None):
         autoregressive_params = self._conditioner(inputs, context)
         return self._elementwise_forward(inputs, autoregressive_params)
 
     def inverse(self, inputs, context=None):
+        if self._incremental_ok(inputs):
+            return self._inverse_incremental(inputs, context)
         num_inputs = int(np.prod(inputs.shape[1:]))
         outputs = torch.zeros_like(inputs)
         logabsdet = None
@@ -55,6 +69,45 @@ class AutoregressiveTransform(Transform):
             for _ in range(num_inputs):
                 autoregressive_params = self._conditioner(outputs, context)
                 outputs, logabsdet = self._elementwise_inverse(inputs, autoregressive_params)
+        return outputs, logabsdet
+
+    def _incremental_ok(self, inputs):
+        """Column-at-a-time inverse applies to a MADE: its input degrees are 1..D and its output
+        degrees tile(1..D) whatever the hidden masks are (made.py:14-49), so the parameters of dim d depend on
+        outputs[:, :d] alone.  Inference only (the column writes are in place).  It pays when the final layer and
+        the bijector dominate a pass, i.e. for the spline / sum-of-sigmoids forms; with 1-2 parameters per dim
+        (shift, affine) a pass is the hidden stack either way and the GEMM library handles a 1-2 column product
+        no better than a full-width one, so those keep the full passes; so do batches small enough to be bound by
+        launches (a column pass has two more).  ``FC_AR_INCREMENTAL=force`` lifts both size rules, ``0`` disables."""
+        net = self.autoregressive_net
+        return (isinstance(net, made_module.MADE) and inputs.dim() == 2 and inputs.shape[1] > 1
+                and ((net.final_layer.out_features >= 8 * inputs.shape[1] and inputs.shape[0] >= 8192)
+                     or os.environ.get("FC_AR_INCREMENTAL") == "force")
+                and os.environ.get("FC_AR_INCREMENTAL", "1") != "0" and not self._needs_grad(inputs)
+                and not net._forward_hooks and not net._forward_pre_hooks)
+
+    def _inverse_incremental(self, inputs, context):
+        """The reference's D passes (autoregressive.py:44-53) each recompute all D x P parameters and invert all D
+        dims although pass d only fixes column d.  Here pass d runs the hidden stack on the columns found so far
+        (the others still zero: they only meet zeroed weights), the P rows of the final layer that belong to dim d,
+        and the element-wise inverse of that one column: final-layer and bijector work drop by a factor of D; the
+        per-column log-determinants add up to the last pass's row sum."""
+        net = self.autoregressive_net
+        final = net.final_layer
+        features = inputs.shape[1]
+        per_dim = final.out_features // features
+        weight = (final.weight * final.mask).detach().view(features, per_dim, final.in_features)
+        bias = final.bias.detach().view(features, per_dim) if final.bias is not None else None
+        columns = inputs.t().contiguous()           # row d = the d-th column, contiguous
+        outputs = torch.zeros_like(inputs)
+        logabsdet = None
+        with ops.deferred_errors():
+            for d in range(features):
+                hidden = self._hidden(outputs, context)
+                params = F.linear(hidden, weight[d], None if bias is None else bias[d])
+                column, lad = self._elementwise_inverse(columns[d].unsqueeze(1), params)
+                outputs[:, d] = column[:, 0]
+                logabsdet = lad if logabsdet is None else logabsdet + lad
         return outputs, logabsdet
 
     def _output_dim_multiplier(self):

@@ -1,0 +1,110 @@
+"""Column-at-a-time inverse of the masked autoregressive transforms against the reference's
+D-full-passes scheme (autoregressive.py:44-53), restated by the oracle and by this package with
+FC_AR_INCREMENTAL=0."""
+import copy
+
+import pytest
+import torch
+
+from _util import maxdiff
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(kind, features, hidden, random_mask=False):
+    from flowconductor_amd import transforms as T
+
+    blocks = dict(num_blocks=2, use_residual_blocks=not random_mask, random_mask=random_mask)
+    if kind == "maf":
+        return T.MaskedAffineAutoregressiveTransform(features, hidden, **blocks)
+    if kind == "shift":
+        return T.MaskedShiftAutoregressiveTransform(features, hidden, **blocks)
+    if kind == "rq_linear_tails":
+        return T.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+            features, hidden, num_bins=8, tails="linear", tail_bound=3.0, **blocks)
+    if kind == "rq_box":
+        return T.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(features, hidden, num_bins=5, **blocks)
+    if kind == "sos":
+        return T.MaskedSumOfSigmoidsTransform(features, hidden, n_sigmoids=6, **blocks)
+    if kind == "linear":
+        return T.MaskedPiecewiseLinearAutoregressiveTransform(8, features, hidden, **blocks)
+    if kind == "quadratic":
+        return T.MaskedPiecewiseQuadraticAutoregressiveTransform(6, features, hidden, tails="linear",
+                                                                 tail_bound=3.0, **blocks)
+    if kind == "cubic":
+        return T.MaskedPiecewiseCubicAutoregressiveTransform(6, features, hidden, **blocks)
+    raise KeyError(kind)
+
+
+def _inputs(kind, n, features):
+    g = torch.Generator().manual_seed(5)
+    if kind in ("linear", "cubic"):
+        return torch.rand(n, features, generator=g) * 0.98 + 0.01
+    if kind == "rq_box":
+        return torch.rand(n, features, generator=g) * 2.2 - 1.1
+    if kind == "sos":
+        return torch.randn(n, features, generator=g) * 0.6
+    return torch.randn(n, features, generator=g) * 1.2
+
+
+@pytest.mark.parametrize("kind", ["maf", "shift", "rq_linear_tails", "rq_box", "sos", "linear", "quadratic", "cubic"])
+@pytest.mark.parametrize("features,hidden,n", [(6, 64, 1000), (5, 24, 77)])
+def test_incremental_inverse_matches_full_passes(kind, features, hidden, n, device, monkeypatch):
+    torch.manual_seed(31)
+    t = _build(kind, features, hidden).eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    x = _inputs(kind, n, features)
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(t, x.clone(), inverse=True)
+        ref_y64, ref_lad64 = O.transform_apply(copy.deepcopy(t).double(), x.double(), inverse=True)
+    t = t.to(device)
+    with torch.no_grad():
+        # by default only where it pays: >= 8 parameters per dim (not shift / affine) and >= 8192 rows
+        assert not t._incremental_ok(x.to(device))
+        big = torch.zeros(8192, features, device=device)
+        assert t._incremental_ok(big) == (kind not in ("maf", "shift"))
+        monkeypatch.setenv("FC_AR_INCREMENTAL", "force")
+        assert t._incremental_ok(x.to(device))
+        y, lad = t.inverse(x.to(device))
+        monkeypatch.setenv("FC_AR_INCREMENTAL", "0")
+        assert not t._incremental_ok(x.to(device))
+        y_full, lad_full = t.inverse(x.to(device))
+    # D chained conditioner passes amplify rounding (the quadratic spline's inverse is ill-conditioned near its
+    # knots: the f32 oracle itself is 3e-3 from float64 there), so the bound carries the f32 noise floor
+    tol_y = 1e-4 * max(1.0, float(ref_y.abs().max())) + 4 * maxdiff(ref_y, ref_y64)
+    tol_l = 1e-3 * max(1.0, float(ref_lad.abs().max()) / 10) + 4 * maxdiff(ref_lad, ref_lad64)
+    assert maxdiff(y, y_full) <= tol_y
+    assert maxdiff(lad, lad_full) <= tol_l
+    assert maxdiff(y, ref_y64) <= tol_y
+    assert maxdiff(lad, ref_lad64) <= tol_l
+
+
+def test_incremental_inverse_random_masks_round_trip(device, monkeypatch):
+    """Random hidden degrees (feed-forward blocks): inputs/outputs keep degrees 1..D, so the column order is still
+    the natural one.  forward(inverse(z)) = z and the log-determinants cancel."""
+    torch.manual_seed(3)
+    t = _build("rq_linear_tails", 7, 32, random_mask=True).eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    t = t.to(device)
+    z = torch.randn(500, 7, device=device)
+    monkeypatch.setenv("FC_AR_INCREMENTAL", "force")
+    with torch.no_grad():
+        assert t._incremental_ok(z)
+        x, lad_inv = t.inverse(z)
+        z2, lad_fwd = t.forward(x)
+    assert maxdiff(z2, z) <= 2e-4 * max(1.0, float(z.abs().max()))
+    assert maxdiff(lad_inv + lad_fwd, torch.zeros_like(lad_inv)) <= 2e-3
+
+
+def test_incremental_inverse_not_used_when_gradients_are_needed(device):
+    """The column writes are in place: with autograd recording, the reference's out-of-place D-pass scheme stays."""
+    t = _build("rq_linear_tails", 4, 16).to(device)
+    x = torch.randn(8192, 4, device=device)
+    assert not t._incremental_ok(x)
+    with torch.no_grad():
+        assert t._incremental_ok(x)
