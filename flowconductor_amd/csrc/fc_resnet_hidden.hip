@@ -9,6 +9,11 @@
 //  state_dict, CPU execution); this kernel is the device fast path for its inference forward when
 //  the shapes match: hidden = 64, <= 4 blocks, ReLU, <= 64 input features.
 //
+// With a context (resnet.py:48-49, 94-97; kCtx): the initial layer sees [x_id | context] and every block gates
+// its output,  h += (W2 relu(W1 relu(h) + b1) + b2) * sigmoid(Wc context + bc)   (F.glu of the concatenation).
+// The context row is one more B operand (<= 32 features: one k-step), split once per 16-sample block and used by
+// the gate product of every residual block (12 MFMAs each).
+//
 // Every product runs as three v_mfma_f32_16x16x32_f16 terms on scaled two-piece f16 splits of both
 // operands (fc_split.h): f32-GEMM accuracy at 3/16 of the f32-MFMA cycles.
 //
@@ -26,6 +31,7 @@
 #include <stdint.h>
 #include "fc_split.h"
 #include "fc_lane.h"
+#include "fc_math.h"
 #include "../../include/flowcon_hip.h"
 
 namespace fc {
@@ -43,26 +49,34 @@ struct HiddenArgs {
   const float* bb;        // [blocks][2][64]
   int64_t blocks16;       // number of 16-row blocks
   int D;
-  int k0;                 // conditioner input features (<= 64)
+  int k0;                 // identity features read from x (k0 + C <= 64)
+  const float* ctx;       // [N, C] context rows, or null
+  const float* wc;        // [blocks][64][C]  context_layer.weight of each block
+  const float* bc;        // [blocks][64]
+  int C;                  // context features (<= 32), 0 without context
 };
 
 // feature held by accumulator tile t, register r of a lane in group g
 __host__ __device__ constexpr int hid_feat(int t, int g, int r) { return 32 * (t >> 1) + 8 * g + 4 * (t & 1) + r; }
 
 // LDS: [layer][k-step][tile][piece][lane] f16x8 fragments, then bias [layer][g][16], unscale [layer], ids
-template <int NB, int K0S>
+template <int NB, int K0S, bool kCtx>
 struct HiddenLds {
-  static constexpr int kLayers = 1 + 2 * NB;
+  static constexpr int kMain = 1 + 2 * NB;                // initial layer + two per block
+  static constexpr int kLayers = kMain + (kCtx ? NB : 0); // + one gate layer per block
   static constexpr int kFrag0 = K0S * 4 * 2;              // fragments of the initial layer
   static constexpr int kFragL = 2 * 4 * 2;                // fragments of a 64 x 64 layer
-  static constexpr int kFrags = kFrag0 + 2 * NB * kFragL;
-  static constexpr size_t kBytes = (size_t)kFrags * 64 * 16 + kLayers * 64 * 4 + 16 * 4 + 32 * K0S * 4 + 64;
+  static constexpr int kFragG = 1 * 4 * 2;                // fragments of a 64 x C gate layer (C <= 32)
+  static constexpr int kFragsMain = kFrag0 + 2 * NB * kFragL;
+  static constexpr int kFrags = kFragsMain + (kCtx ? NB * kFragG : 0);
+  static constexpr size_t kBytes = (size_t)kFrags * 64 * 16 + kLayers * 64 * 4 + 16 * 4 + 32 * K0S * 4 + 128;
   static_assert(kLayers <= 16, "wun holds 16 entries");
+  static_assert(kBytes <= 160 * 1024, "weight fragments exceed the CU's LDS");
 };
 
-template <int NB, int K0S>
-__global__ __launch_bounds__(kHidThreads, 4) void resnet_hidden_kernel(HiddenArgs a) {
-  using L = HiddenLds<NB, K0S>;
+template <int NB, int K0S, bool kCtx>
+__global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(HiddenArgs a) {
+  using L = HiddenLds<NB, K0S, kCtx>;
   extern __shared__ __attribute__((aligned(16))) unsigned char hsmem[];
   f16x8* wfrag = reinterpret_cast<f16x8*>(hsmem);
   float* bias = reinterpret_cast<float*>(hsmem + (size_t)L::kFrags * 64 * 16);   // [layer][g][16]
@@ -72,15 +86,17 @@ __global__ __launch_bounds__(kHidThreads, 4) void resnet_hidden_kernel(HiddenArg
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s16 = lane & 15, g = lane >> 4;
-  const int k0 = a.k0, D = a.D;
+  const int k0 = a.k0, D = a.D, C = kCtx ? a.C : 0;
 
   // ---- once per workgroup: scale, split and lay out the weights -----------------------------------
-  for (int i = tid; i < 32 * K0S; i += kHidThreads) ids[i] = i < k0 ? a.id_cols[i] : -1;
+  // operand column i of the initial layer: identity column of x (>= 0), context feature -2 - j, or padding (-1)
+  for (int i = tid; i < 32 * K0S; i += kHidThreads) ids[i] = i < k0 ? a.id_cols[i] : (i < k0 + C ? -2 - (i - k0) : -1);
 #pragma unroll
   for (int l = 0; l < L::kLayers; ++l) {
-    const float* w = l == 0 ? a.w0 : a.wb + (size_t)(l - 1) * kHid * kHid;
-    const float* b = l == 0 ? a.b0 : a.bb + (size_t)(l - 1) * kHid;
-    const int kin = l == 0 ? k0 : kHid;
+    const bool gate = l >= L::kMain;
+    const float* w = l == 0 ? a.w0 : gate ? a.wc + (size_t)(l - L::kMain) * kHid * C : a.wb + (size_t)(l - 1) * kHid * kHid;
+    const float* b = l == 0 ? a.b0 : gate ? a.bc + (size_t)(l - L::kMain) * kHid : a.bb + (size_t)(l - 1) * kHid;
+    const int kin = l == 0 ? k0 + C : gate ? C : kHid;
     float m = 0.f;
     for (int i = tid; i < kHid * kin; i += kHidThreads) m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
@@ -95,8 +111,8 @@ __global__ __launch_bounds__(kHidThreads, 4) void resnet_hidden_kernel(HiddenArg
     pow2_scale(m, sc, un);
     if (tid == 0) wun[l] = un;
     // fragment entry e = (ks * 4 + t) * 64 + lane': W[feat(t, lane' & 15)][32 ks + 8 (lane' >> 4) + j]
-    const int nks = l == 0 ? K0S : 2;
-    const int base = l == 0 ? 0 : L::kFrag0 + (l - 1) * L::kFragL;
+    const int nks = l == 0 ? K0S : gate ? 1 : 2;
+    const int base = l == 0 ? 0 : gate ? L::kFragsMain + (l - L::kMain) * L::kFragG : L::kFrag0 + (l - 1) * L::kFragL;
     for (int e = tid; e < nks * 4 * 64; e += kHidThreads) {
       const int ln = e & 63, t = (e >> 6) & 3, ks = e >> 8;
       const int rho = ln & 15, f = hid_feat(t, rho >> 2, rho & 3);
@@ -195,6 +211,7 @@ __global__ __launch_bounds__(kHidThreads, 4) void resnet_hidden_kernel(HiddenArg
     // out of the loop and spills
     asm volatile("" ::: "memory");
     const float* xrow = a.x + (blk * 16 + s16) * D;
+    const float* crow = kCtx ? a.ctx + (blk * 16 + s16) * C : nullptr;
     // x operand: 8 (16) identity features of sample s per lane, laid out like an activation tile
     f32x4 xin[4];
 #pragma unroll
@@ -205,12 +222,41 @@ __global__ __launch_bounds__(kHidThreads, 4) void resnet_hidden_kernel(HiddenArg
         float v = 0.f;
         if (ks < K0S) {
           const int c = mycol[ks < K0S ? ks : 0][j];
-          v = c >= 0 ? xrow[c] : 0.f;
+          if constexpr (kCtx)
+            v = c >= 0 ? xrow[c] : (c <= -2 ? crow[-2 - c] : 0.f);
+          else
+            v = c >= 0 ? xrow[c] : 0.f;
         }
         xin[t][r] = v;
       }
     f16x8 bh[2], bl[2];
     f32x4 acc[4], h[4], tmid[4];
+    // context row as the B operand of the gate products: lane (s, g) supplies features 8g..8g+7 of sample s; split
+    // once per 16-sample block, used by every residual block.  (With a context the weight image, 96 KB at 2 blocks,
+    // allows one 8-wave workgroup per CU: 256 registers per wave, these 9 stay live for free.  12- and 16-wave
+    // workgroups sharing the image were tried: the compiler spills at 168 / 128 registers and they run 15 % slower.)
+    f16x8 ch[2] = {}, cl[2] = {};
+    float unc = 1.f;
+    if constexpr (kCtx) {
+      float cv[8], m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * g + j;
+        cv[j] = crow[k < C ? k : 0];
+        cv[j] = k < C ? cv[j] : 0.f;
+        m = fmaxf(m, fabsf(cv[j]));
+      }
+      m = rows4_allmax(m, lane);
+      float sc;
+      pow2_scale(m, sc, unc);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        _Float16 ph, pl;
+        split2(cv[j] * sc, ph, pl);
+        ch[0][j] = ph;
+        cl[0][j] = pl;
+      }
+    }
     float un = make_operand(xin, bh, bl);
     layer(0, K0S, bh, bl, acc);
     finish(0, un, acc, h);
@@ -231,6 +277,17 @@ __global__ __launch_bounds__(kHidThreads, 4) void resnet_hidden_kernel(HiddenArg
       un = make_operand(act, bh, bl);
       layer(L::kFrag0 + (2 * b + 1) * L::kFragL, 2, bh, bl, acc);
       finish(2 + 2 * b, un, acc, tmid);
+      if constexpr (kCtx) {
+        // resnet.py:48-49: temps = glu(cat(temps, context_layer(context))) = temps * sigmoid(Wc c + bc)
+        f32x4 gpre[4];
+        layer(L::kFragsMain + b * L::kFragG, 1, ch, cl, acc);
+        finish(L::kMain + b, unc, acc, gpre);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            tmid[t][r] *= __builtin_amdgcn_rcpf(1.f + exp_lean(fminf(-gpre[t][r], 87.f)));   // sigmoid, ~1 ulp
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -245,18 +302,50 @@ __global__ __launch_bounds__(kHidThreads, 4) void resnet_hidden_kernel(HiddenArg
   }
 }
 
-template <int NB, int K0S>
+template <int NB, int K0S, bool kCtx>
 hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
-  using L = HiddenLds<NB, K0S>;
+  using L = HiddenLds<NB, K0S, kCtx>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S>), dim3((unsigned)grid), dim3(kHidThreads), L::kBytes, s, a);
+  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S, kCtx>), dim3((unsigned)grid), dim3(kHidThreads), L::kBytes,
+                     s, a);
   return hipGetLastError();
+}
+
+template <bool kCtx>
+hipError_t dispatch_hidden(const HiddenArgs& a, int num_blocks, hipStream_t s) {
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+    cus = prop.multiProcessorCount;
+  // two 512-thread workgroups per CU when two weight images fit in LDS (<= 2 blocks at <= 32 inputs, no
+  // context), else one
+  const bool wide = a.k0 + a.C > 32;
+  const size_t frags = (size_t)(wide ? 16 : 8) + (size_t)num_blocks * (2 * 16 + (kCtx ? 8 : 0));   // 1 KB each
+  int64_t grid = (int64_t)cus * (!kCtx && frags * 1024 + 2048 <= 80 * 1024 ? 2 : 1);
+  const int64_t need = (a.blocks16 + 7) / 8;
+  if (grid > need) grid = need;
+  switch (num_blocks * 2 + (wide ? 1 : 0)) {
+    case 0: return launch_hidden<0, 1, kCtx>(a, grid, s);
+    case 1: return launch_hidden<0, 2, kCtx>(a, grid, s);
+    case 2: return launch_hidden<1, 1, kCtx>(a, grid, s);
+    case 3: return launch_hidden<1, 2, kCtx>(a, grid, s);
+    case 4: return launch_hidden<2, 1, kCtx>(a, grid, s);
+    case 5: return launch_hidden<2, 2, kCtx>(a, grid, s);
+    case 6: return launch_hidden<3, 1, kCtx>(a, grid, s);
+    case 7: return launch_hidden<3, 2, kCtx>(a, grid, s);
+    default: break;
+  }
+  if constexpr (!kCtx) {
+    if (wide) return launch_hidden<4, 2, false>(a, grid, s);
+    return launch_hidden<4, 1, false>(a, grid, s);
+  }
+  return hipErrorInvalidValue;
 }
 
 }  // namespace fc
@@ -270,28 +359,25 @@ extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols
   if (n == 0) return hipSuccess;
   if (!x || !h || !id_cols || !w0 || !b0 || (num_blocks > 0 && (!wb || !bb))) return hipErrorInvalidValue;
   if (((uintptr_t)h & 15u) != 0) return hipErrorInvalidValue;
-  fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features};
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-    cus = prop.multiProcessorCount;
-  // two 512-thread workgroups per CU when two weight images fit in LDS (<= 2 blocks at <= 32 inputs), else one
-  const bool wide = in_features > 32;
-  const size_t frags = (size_t)(wide ? 16 : 8) + (size_t)num_blocks * 2 * 16;   // 1 KB each
-  int64_t grid = (int64_t)cus * (frags * 1024 + 2048 <= 80 * 1024 ? 2 : 1);
-  const int64_t need = (a.blocks16 + 7) / 8;
-  if (grid > need) grid = need;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  switch (num_blocks * 2 + (wide ? 1 : 0)) {
-    case 0: return fc::launch_hidden<0, 1>(a, grid, s);
-    case 1: return fc::launch_hidden<0, 2>(a, grid, s);
-    case 2: return fc::launch_hidden<1, 1>(a, grid, s);
-    case 3: return fc::launch_hidden<1, 2>(a, grid, s);
-    case 4: return fc::launch_hidden<2, 1>(a, grid, s);
-    case 5: return fc::launch_hidden<2, 2>(a, grid, s);
-    case 6: return fc::launch_hidden<3, 1>(a, grid, s);
-    case 7: return fc::launch_hidden<3, 2>(a, grid, s);
-    case 8: return fc::launch_hidden<4, 1>(a, grid, s);
-    default: return fc::launch_hidden<4, 2>(a, grid, s);
-  }
+  fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, nullptr, nullptr, nullptr, 0};
+  return fc::dispatch_hidden<false>(a, num_blocks, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fc_resnet_hidden_context(const float* x, const float* context, float* h, const int32_t* id_cols,
+                                        const float* w0, const float* b0, const float* wb, const float* bb,
+                                        const float* wc, const float* bc, int64_t n, int32_t d,
+                                        int32_t in_features, int32_t context_features, int32_t hidden,
+                                        int32_t num_blocks, void* stream) {
+  // 3 blocks: weight fragments of 4 blocks + 4 gate layers would need 168 KB of LDS
+  if (n < 0 || d <= 0 || hidden != fc::kHid || num_blocks < 0 || num_blocks > 3) return hipErrorInvalidValue;
+  if (in_features <= 0 || in_features > d || context_features <= 0 || context_features > 32 ||
+      in_features + context_features > 64)
+    return hipErrorInvalidValue;
+  if (n % 16 != 0) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!x || !context || !h || !id_cols || !w0 || !b0 || (num_blocks > 0 && (!wb || !bb || !wc || !bc)))
+    return hipErrorInvalidValue;
+  if (((uintptr_t)h & 15u) != 0) return hipErrorInvalidValue;
+  fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, context, wc, bc, context_features};
+  return fc::dispatch_hidden<true>(a, num_blocks, static_cast<hipStream_t>(stream));
 }

@@ -77,16 +77,28 @@ class ResidualNet(nn.Module):
         return self.final_layer(self.hidden(inputs, context))
 
     # ---- device fast path for the hidden layers (inference) ------------------------------------------
-    def hip_hidden_supported(self, features_total):
-        """True when ``fc_resnet_hidden`` covers this net: hidden 64, <= 4 blocks, ReLU, no context, no
-        batch norm, dropout inactive, input width <= 64."""
+    def hip_hidden_supported(self, features_total, context=None):
+        """True when ``fc_resnet_hidden`` covers this net: hidden 64, <= 4 blocks, ReLU, no batch norm, dropout
+        inactive, input width (identity features + context features) <= 64; a context must be a [N, C <= 32] f32
+        tensor matching ``context_features`` and allows <= 3 blocks (the gate layers' fragments share the LDS)."""
         def is_relu(f):
             return isinstance(f, torch.nn.ReLU) or f is F.relu or f is torch.relu
 
-        if self.context_features is not None or self.hidden_features != 64 or len(self.blocks) > 4:
+        if self.hidden_features != 64 or len(self.blocks) > 4:
             return False
         in_f = self.initial_layer.in_features
-        if in_f > 64 or in_f > features_total:
+        if (self.context_features is None) != (context is None):
+            return False        # the module itself raises / ignores: leave that to PyTorch
+        if context is not None:
+            c = self.context_features
+            if len(self.blocks) > 3:
+                return False
+            if (context.dim() != 2 or context.shape[1] != c or c > 32 or context.dtype != torch.float32
+                    or not context.is_cuda or context.requires_grad and torch.is_grad_enabled()):
+                return False
+            if in_f - c <= 0 or in_f - c > features_total:
+                return False
+        if in_f > 64 or (context is None and in_f > features_total):
             return False
         for block in self.blocks:
             if block.use_batch_norm or not is_relu(block.activation):
@@ -95,12 +107,12 @@ class ResidualNet(nn.Module):
                 return False
         return True
 
-    def hidden_hip(self, rows, id_cols):
-        """h [N, 64] from FULL input rows + the identity column indices (N a multiple of 16)."""
+    def hidden_hip(self, rows, id_cols, context=None):
+        """h [N, 64] from FULL input rows + the identity column indices (N a multiple of 16) [+ context rows]."""
         from flowconductor_amd import ops
 
         key = tuple((p._version, p.data_ptr()) for p in self.parameters())
         if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
             self._hip_packed = (key, ops.pack_resnet_hidden(self))
-        return ops.resnet_hidden(rows, id_cols, self._hip_packed[1], self.initial_layer.in_features,
-                                 len(self.blocks))
+        in_features = self.initial_layer.in_features - (self.context_features or 0)
+        return ops.resnet_hidden(rows, id_cols, self._hip_packed[1], in_features, len(self.blocks), context)

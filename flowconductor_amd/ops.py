@@ -326,37 +326,53 @@ HIDDEN_ROWS = 16
 
 
 def pack_resnet_hidden(net):
-    """Weights of the hidden layers of a ResidualNet (hidden 64, <= 2 blocks) as ``fc_resnet_hidden`` takes
-    them: the nn.Linear tensors row-major, the block layers stacked [blocks, 2, 64, 64] / [blocks, 2, 64]."""
+    """Weights of the hidden layers of a ResidualNet (hidden 64, <= 4 blocks) as ``fc_resnet_hidden`` takes
+    them: the nn.Linear tensors row-major, the block layers stacked [blocks, 2, 64, 64] / [blocks, 2, 64]; with a
+    context also the blocks' ``context_layer`` stacked [blocks, 64, C] / [blocks, 64]."""
     w0 = net.initial_layer.weight.detach().contiguous()
     b0 = net.initial_layer.bias.detach().contiguous()
-    ws, bs = [], []
+    ws, bs, wcs, bcs = [], [], [], []
     for block in net.blocks:
         for lin in block.linear_layers:
             ws.append(lin.weight.detach())
             bs.append(lin.bias.detach())
-    if ws:
-        wb = torch.stack(ws).contiguous()
-        bb = torch.stack(bs).contiguous()
-    else:
-        wb = bb = None
-    return w0, b0, wb, bb
+        if getattr(block, "context_layer", None) is not None:
+            wcs.append(block.context_layer.weight.detach())
+            bcs.append(block.context_layer.bias.detach())
+    wb = torch.stack(ws).contiguous() if ws else None
+    bb = torch.stack(bs).contiguous() if bs else None
+    wc = torch.stack(wcs).contiguous() if wcs else None
+    bc = torch.stack(bcs).contiguous() if bcs else None
+    return w0, b0, wb, bb, wc, bc
 
 
-def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks):
-    """Hidden layers of the conditioner on the rows of ``inputs`` (multiple of 16 rows) -> h [N, 64]."""
+def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks, context=None):
+    """Hidden layers of the conditioner on the rows of ``inputs`` (multiple of 16 rows) -> h [N, 64].
+    ``in_features`` = number of identity columns read from ``inputs``; ``context`` [N, C] (C <= 32,
+    in_features + C <= 64) enters the initial layer after them and gates every block (``packed`` then carries
+    the context layers)."""
     lib = _hip.load()
     x = _prep_2d(inputs)
     _hip.require_no_grad(inputs)
     n, d = x.shape
     if n % HIDDEN_ROWS != 0:
         raise ValueError("fc_resnet_hidden needs a multiple of %d rows" % HIDDEN_ROWS)
-    w0, b0, wb, bb = packed
+    w0, b0, wb, bb = packed[:4]
     ids = _as_cols(id_cols, x.device)
     h = torch.empty(n, 64, dtype=torch.float32, device=x.device)
-    _call("fc_resnet_hidden", lib.fc_resnet_hidden, x.device, _hip.ptr(x), _hip.ptr(h), _hip.ptr(ids),
-          _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(wb), _hip.ptr(bb), n, d, in_features, 64, num_blocks,
-          _hip.stream_ptr(x.device))
+    if context is None:
+        _call("fc_resnet_hidden", lib.fc_resnet_hidden, x.device, _hip.ptr(x), _hip.ptr(h), _hip.ptr(ids),
+              _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(wb), _hip.ptr(bb), n, d, in_features, 64, num_blocks,
+              _hip.stream_ptr(x.device))
+        return h
+    wc, bc = packed[4:6]
+    c = _prep_2d(context)
+    _hip.require_no_grad(context)
+    if c.shape[0] != n or w0.shape[1] != in_features + c.shape[1]:
+        raise ValueError("context rows / width do not match the inputs / the initial layer")
+    _call("fc_resnet_hidden_context", lib.fc_resnet_hidden_context, x.device, _hip.ptr(x), _hip.ptr(c), _hip.ptr(h),
+          _hip.ptr(ids), _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(wb), _hip.ptr(bb), _hip.ptr(wc), _hip.ptr(bc), n, d,
+          in_features, c.shape[1], 64, num_blocks, _hip.stream_ptr(x.device))
     return h
 
 

@@ -123,15 +123,18 @@ class CouplingTransform(Transform):
 
         net = self.transform_net
         n = inputs.shape[0]
-        if (type(net) is ResidualNet and context is None and self.unconditional_transform is None
+        if (type(net) is ResidualNet and self.unconditional_transform is None
                 and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32 and n >= ops.HIDDEN_ROWS
-                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0" and net.hip_hidden_supported(inputs.shape[1])
+                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
+                and net.hip_hidden_supported(inputs.shape[1], context)
                 and not (torch.is_grad_enabled()
                          and (inputs.requires_grad or any(p.requires_grad for p in net.parameters())))):
             body = n - n % ops.HIDDEN_ROWS
-            hidden = net.hidden_hip(inputs[:body], self._id_cols(inputs.device))
+            hidden = net.hidden_hip(inputs[:body], self._id_cols(inputs.device),
+                                    None if context is None else context[:body])
             if body < n:
-                hidden = torch.cat((hidden, net.hidden(identity_split[body:], context)))
+                hidden = torch.cat((hidden, net.hidden(identity_split[body:],
+                                                       None if context is None else context[body:])))
             return net.final_layer(hidden)
         return net(identity_split, context)
 
@@ -310,13 +313,16 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         n = inputs.shape[0]
         body16 = n - n % ops.HIDDEN_ROWS
         identity_split = logabsdet_identity = None
-        if (self.unconditional_transform is None and context is None and body16 > 0
-                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0" and net.hip_hidden_supported(inputs.shape[1])):
+        if (self.unconditional_transform is None and body16 > 0
+                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
+                and net.hip_hidden_supported(inputs.shape[1], context)):
             # hidden layers of the conditioner in one matrix-core kernel straight from the full input rows: the
             # identity half is never gathered into a separate tensor
-            hidden = net.hidden_hip(inputs[:body16], self._id_cols(inputs.device))
+            hidden = net.hidden_hip(inputs[:body16], self._id_cols(inputs.device),
+                                    None if context is None else context[:body16])
             if body16 < n:
-                hidden = torch.cat((hidden, net.hidden(inputs[body16:, self.identity_features], context)))
+                hidden = torch.cat((hidden, net.hidden(inputs[body16:, self.identity_features],
+                                                       None if context is None else context[body16:])))
         else:
             identity_split = inputs[:, self.identity_features]
             if inverse and self.unconditional_transform is not None:

@@ -110,6 +110,16 @@ int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const flo
                      const float* b0, const float* wb, const float* bb, int64_t n, int32_t d,
                      int32_t in_features, int32_t hidden, int32_t num_blocks, void* stream);
 
+/* The same with a context (resnet.py:48-49, 94-97): the initial layer sees [x[:, id_cols] | context]
+ * (w0 [64, in_features + context_features]) and every block gates its output,
+ *   h += (W2 relu(W1 relu(h) + b1) + b2) * sigmoid(Wc context + bc)      (F.glu of the concatenation),
+ * wc [blocks][64][context_features] / bc [blocks][64] = blocks[i].context_layer.  context [n, context_features]
+ * row-major; context_features <= 32, in_features + context_features <= 64, num_blocks <= 3. */
+int fc_resnet_hidden_context(const float* x, const float* context, float* h, const int32_t* id_cols,
+                             const float* w0, const float* b0, const float* wb, const float* bb,
+                             const float* wc, const float* bc, int64_t n, int32_t d, int32_t in_features,
+                             int32_t context_features, int32_t hidden, int32_t num_blocks, void* stream);
+
 /* ---- linear / quadratic / cubic splines ------------------------------------------------------ */
 #define FC_SPLINE_LINEAR 0    /* row per dim: [K pdf]                          (splines/linear.py:38-105) */
 #define FC_SPLINE_QUADRATIC 1 /* row per dim: [K widths | K-1 or K+1 heights]  (splines/quadratic.py:55-159) */

@@ -1,0 +1,101 @@
+"""Conditional coupling flows: a ResidualNet conditioner with a context (concatenated into the initial layer, GLU gate
+in every block -- nn/nets/resnet.py:48-49, 94-97) on fc_resnet_hidden_context; against the same module in float64 on
+the CPU and against the PyTorch-ROCm path."""
+import copy
+
+import pytest
+import torch
+
+from _util import maxdiff
+from flowconductor_amd import ops
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("in_f,ctx_f,blocks,d,n", [(32, 8, 2, 64, 6400), (16, 32, 1, 32, 128), (3, 5, 3, 7, 48),
+                                                  (40, 24, 2, 80, 192), (5, 1, 0, 10, 64), (32, 32, 3, 64, 1024),
+                                                  (1, 31, 2, 2, 16), (32, 16, 2, 64, 100000)])
+def test_hidden_kernel_with_context_matches_float64(in_f, ctx_f, blocks, d, n, device):
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(in_f + 7 * ctx_f + blocks)
+    net = nets.ResidualNet(in_f, 8, hidden_features=64, context_features=ctx_f, num_blocks=blocks).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)     # residual blocks / gates far from their near-zero initialisation
+    ids = torch.randperm(d)[:in_f].sort().values
+    x = torch.randn(n, d)
+    c = torch.randn(n, ctx_f) * 1.5
+    with torch.no_grad():
+        ref = copy.deepcopy(net).double().hidden(x.double()[:, ids], c.double())
+        ref32 = net.hidden(x[:, ids], c)
+        net = net.to(device)
+        assert net.hip_hidden_supported(d, c.to(device))
+        with ops.KernelTimer("fc_resnet_hidden_context") as timer:
+            got = net.hidden_hip(x.to(device), ids.to(device), c.to(device))
+        assert len(timer.pairs) == 1
+    assert got.shape == (n, 64)
+    floor = maxdiff(ref32, ref)
+    assert maxdiff(got, ref) <= 1e-5 * max(1.0, float(ref.abs().max())) + 4 * floor
+
+
+def test_context_predicate(device):
+    from flowconductor_amd.nn import nets
+
+    net = nets.ResidualNet(8, 4, hidden_features=64, context_features=6).to(device).eval()
+    c = torch.randn(32, 6, device=device)
+    assert net.hip_hidden_supported(16, c)
+    assert not net.hip_hidden_supported(16, None)              # a context net without its context: PyTorch decides
+    assert not net.hip_hidden_supported(16, c[:, :5])          # wrong width
+    assert not net.hip_hidden_supported(16, c.double())
+    assert not net.hip_hidden_supported(16, torch.randn(32, 2, 3, device=device))
+    wide = nets.ResidualNet(8, 4, hidden_features=64, context_features=33).to(device).eval()
+    assert not wide.hip_hidden_supported(16, torch.randn(32, 33, device=device))
+    plain = nets.ResidualNet(8, 4, hidden_features=64).to(device).eval()
+    assert not plain.hip_hidden_supported(16, c)
+
+
+@pytest.mark.parametrize("kind", ["rq", "affine"])
+@pytest.mark.parametrize("n", [1000, 77])
+def test_conditional_coupling_flow(kind, n, device, monkeypatch):
+    """A 4-layer conditional coupling flow (D = 16, context 5): log_prob(x | c) through the context variant of the
+    hidden kernel (+ the fused final-layer kernel for the RQ layers) vs the oracle and vs the PyTorch conditioner."""
+    from flowconductor_amd import distributions, flows, transforms, utils
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(11)
+    features, ctx_f = 16, 5
+
+    def net(i, o):
+        return nets.ResidualNet(i, o, hidden_features=64, context_features=ctx_f, num_blocks=2)
+
+    layers = []
+    for i in range(4):
+        mask = utils.create_alternating_binary_mask(features, even=(i % 2 == 0))
+        if kind == "rq":
+            layers.append(transforms.PiecewiseRationalQuadraticCouplingTransform(
+                mask, net, num_bins=8, tails="linear", tail_bound=3.0))
+        else:
+            layers.append(transforms.AffineCouplingTransform(mask, net))
+    flow = flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([features])).eval()
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.mul_(1.5)
+    x = torch.randn(n, features) * 1.2
+    c = torch.randn(n, ctx_f)
+    with torch.no_grad():
+        ref = O.flow_log_prob(flow, x, c)
+    flow = flow.to(device)
+    with torch.no_grad():
+        with ops.KernelTimer("fc_resnet_hidden_context") as timer:
+            got = flow.log_prob(x.to(device), c.to(device))
+        assert len(timer.pairs) == 4, "the context variant of the hidden-layer kernel did not run"
+        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        got_torch = flow.log_prob(x.to(device), c.to(device))
+        z, _ = flow._transform(x.to(device), c.to(device))
+        back, _ = flow._transform.inverse(z, c.to(device))
+    tol = 3e-4 * max(1.0, float(ref.abs().max()) / 10)
+    assert maxdiff(got, ref) <= tol
+    assert maxdiff(got, got_torch) <= tol
+    assert maxdiff(back, x) <= 2e-4 * max(1.0, float(x.abs().max()))

@@ -158,11 +158,21 @@ def test_pack_resnet_hidden_stacks_linear_weights():
     from flowconductor_amd.nn import nets
 
     net = nets.ResidualNet(32, 8, hidden_features=64, num_blocks=2)
-    w0, b0, wb, bb = ops.pack_resnet_hidden(net)
+    w0, b0, wb, bb, wc, bc = ops.pack_resnet_hidden(net)
+    assert wc is None and bc is None
     assert w0.shape == (64, 32) and b0.shape == (64,) and wb.shape == (4, 64, 64) and bb.shape == (4, 64)
     assert torch.equal(wb[1], net.blocks[0].linear_layers[1].weight) and torch.equal(bb[2], net.blocks[1].linear_layers[0].bias)
-    w0, b0, wb, bb = ops.pack_resnet_hidden(nets.ResidualNet(6, 8, hidden_features=64, num_blocks=0))
+    w0, b0, wb, bb, wc, bc = ops.pack_resnet_hidden(nets.ResidualNet(6, 8, hidden_features=64, num_blocks=0))
     assert wb is None and bb is None and w0.shape == (64, 6)
+    # with a context: the initial layer is [identity | context] wide, the blocks' gate layers are stacked
+    net = nets.ResidualNet(10, 8, hidden_features=64, context_features=5, num_blocks=3)
+    w0, b0, wb, bb, wc, bc = ops.pack_resnet_hidden(net)
+    assert w0.shape == (64, 15) and wb.shape == (6, 64, 64) and wc.shape == (3, 64, 5) and bc.shape == (3, 64)
+    assert torch.equal(wc[2], net.blocks[2].context_layer.weight)
+    # the predicate is device-independent up to the tensor checks: CPU context -> PyTorch path
+    assert not net.hip_hidden_supported(20, torch.zeros(4, 5))
+    assert not nets.ResidualNet(10, 8, hidden_features=64, context_features=5, num_blocks=4).hip_hidden_supported(
+        20, torch.zeros(4, 5))
 
 
 def test_generated_fused_eval_is_current():
