@@ -394,11 +394,12 @@ def pack_final_layer(weight, bias, num_bins=FUSED_BINS):
 def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, tail_bound,
                            min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
                            min_derivative=DEFAULT_MIN_DERIVATIVE, wh_divisor=1.0, inverse=False,
-                           logabsdet_accum=None):
+                           logabsdet_accum=None, enable_identity_init=False):
     """RQ-spline coupling bijector with the conditioner's final Linear fused in (rows must be a multiple
     of 32).  ``hidden``: [N, 64] input of that Linear.  Returns ``(outputs [N, D], logabsdet [N])``; with
     ``logabsdet_accum`` (f32 [N], contiguous) the kernel adds the layer's logabsdet onto it in place and that
-    tensor is returned."""
+    tensor is returned.  ``enable_identity_init``: the autoregressive form's softplus beta
+    (autoregressive.py:612)."""
     lib = _hip.load()
     x = _prep_2d(inputs)
     h = _hip.dev_f32(hidden, "hidden")
@@ -414,7 +415,7 @@ def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, t
     cfg.left, cfg.right, cfg.bottom, cfg.top = -tail_bound, tail_bound, -tail_bound, tail_bound
     cfg.min_bin_width, cfg.min_bin_height, cfg.min_derivative = min_bin_width, min_bin_height, min_derivative
     cfg.wh_divisor = wh_divisor
-    cfg.softplus_beta = 1.0
+    cfg.softplus_beta = (math.log(2) / (1 - min_derivative)) if enable_identity_init else 1.0
     cfg.tail_constant = float(np.log(np.exp(1 - min_derivative) - 1))
     y = torch.empty_like(x)
     if logabsdet_accum is not None:

@@ -231,6 +231,49 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
     def _elementwise_inverse(self, inputs, autoregressive_params):
         return self._elementwise(inputs, autoregressive_params, inverse=True)
 
+    # ---- density direction on the fused kernels ------------------------------------------------------------------
+    # One MADE pass yields the parameters of all D dims, so the forward is a coupling layer that transforms every
+    # column: hidden stack in fc_resnet_hidden (pre-masked weights), masked final Linear + spline in
+    # fc_rq_spline_fused_linear -- the [N, D (3K-1)] parameter tensor never reaches HBM.  Shapes: D <= 32, hidden 64,
+    # K = 8, linear tails (the fused kernel's), inference only.
+    def _fused_forward_ok(self, inputs, context):
+        net = self.autoregressive_net
+        return (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and os.environ.get("FC_FUSED", "1") != "0" and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
+                and isinstance(net, made_module.MADE) and not hasattr(net, "hidden_features")
+                and net.final_layer.in_features == 64 and net.hip_hidden_supported()
+                and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], inputs.shape[1], 64,
+                                               self.num_bins, self.tails)
+                and not net._forward_hooks and not net._forward_pre_hooks and not self._needs_grad(inputs))
+
+    def _packed_final_layer(self, device):
+        lin = self.autoregressive_net.final_layer
+        key = (lin.weight._version, lin.bias._version, lin.weight.device, lin.weight.data_ptr())
+        if getattr(self, "_packed", None) is None or self._packed[0] != key:
+            masked = (lin.weight * lin.mask).detach()
+            w_pad, b_pad = ops.pack_final_layer(masked, lin.bias, self.num_bins)
+            cols = torch.arange(lin.out_features // (3 * self.num_bins - 1), dtype=torch.int32, device=device)
+            self._packed = (key, masked, w_pad, b_pad, cols)
+        return self._packed[1:]
+
+    def forward(self, inputs, context=None):
+        if not self._fused_forward_ok(inputs, context):
+            return super().forward(inputs, context)
+        net = self.autoregressive_net
+        hidden = self._hidden(inputs, None)
+        masked, w_pad, b_pad, cols = self._packed_final_layer(inputs.device)
+        kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
+                  min_bin_height=self.min_bin_height, min_derivative=self.min_derivative, wh_divisor=1.0,
+                  enable_identity_init=True)
+        n = inputs.shape[0]
+        body = n - n % ops.FUSED_ROWS
+        outputs, logabsdet = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_pad, b_pad, cols, **kw)
+        if body < n:   # the < 32 leftover rows: masked final Linear + the stand-alone kernel
+            params = F.linear(hidden[body:], masked, net.final_layer.bias)
+            out_b, lad_b = self._elementwise_forward(inputs[body:], params)
+            outputs, logabsdet = torch.cat((outputs, out_b)), torch.cat((logabsdet, lad_b))
+        return outputs, logabsdet
+
 
 class MaskedSumOfSigmoidsTransform(AutoregressiveTransform):
     """Sum-of-sigmoids AR layer (autoregressive.py:266-318): MADE emits 3S+1 raw values per feature;

@@ -116,7 +116,8 @@ class CouplingTransform(Transform):
 
     def _conditioner(self, inputs, identity_split, context):
         """``transform_net(identity_split, context)``.  For this package's ResidualNet with the shape
-        ``fc_resnet_hidden`` covers (hidden 64, <= 2 blocks, ReLU) the hidden layers run in that one kernel,
+        ``fc_resnet_hidden`` covers (hidden 64, <= 4 blocks, ReLU; with a [N, <= 32] context <= 3 blocks) the hidden
+        layers run in that one kernel,
         straight from the full input rows, and only the final Linear stays a library GEMM -- for every coupling
         bijector (affine, additive, all splines), inference only."""
         from flowconductor_amd.nn.nets.resnet import ResidualNet

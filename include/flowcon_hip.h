@@ -102,7 +102,7 @@ int fc_rq_spline_backward(const float* x, const float* params, const int32_t* co
  *   h = W0 x[:, id_cols] + b0;  per block: h += W2 relu(W1 relu(h) + b1) + b2          -> h [n, 64]
  * Products on the f16 matrix cores as three-term scaled two-piece splits (f32-GEMM accuracy); a wave carries
  * 16 samples through all layers in registers; the only HBM traffic is x in and h out.
- * Specialised: hidden == 64, num_blocks <= 4, ReLU, no context / batch norm / active dropout,
+ * Specialised: hidden == 64, num_blocks <= 4, ReLU, no batch norm / active dropout (context: next entry),
  * in_features <= 64, n % 16 == 0, h 16-byte aligned.
  * Weights are the nn.Linear tensors as they are, row-major f32: w0 [64, in_features]; wb [blocks][2][64][64]
  * (linear_layers[0], linear_layers[1] of each block); b0 [64]; bb [blocks][2][64]. */

@@ -108,3 +108,32 @@ def test_incremental_inverse_not_used_when_gradients_are_needed(device):
     assert not t._incremental_ok(x)
     with torch.no_grad():
         assert t._incremental_ok(x)
+
+
+@pytest.mark.parametrize("features,n", [(6, 1000), (32, 4096), (17, 77), (3, 32)])
+def test_rq_autoregressive_forward_on_fused_kernels(features, n, device, monkeypatch):
+    """Density direction of the RQ-spline AR layer (autoregressive.py:529-621; K = 8, linear tails, hidden 64): MADE
+    hidden stack in fc_resnet_hidden, masked final Linear + spline (identity-init softplus beta, no 1/sqrt(H)
+    division) in fc_rq_spline_fused_linear.  Against the oracle in float32 / float64 and the unfused path."""
+    from flowconductor_amd import ops
+
+    torch.manual_seed(features)
+    t = _build("rq_linear_tails", features, 64).eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    x = torch.randn(n, features) * 1.4
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(t, x.clone())
+        ref_y64, ref_lad64 = O.transform_apply(copy.deepcopy(t).double(), x.double())
+    t = t.to(device)
+    with torch.no_grad():
+        with ops.KernelTimer("fc_rq_spline_fused_linear") as timer:
+            y, lad = t(x.to(device))
+        assert len(timer.pairs) == 1, "the fused final-layer + spline kernel did not run"
+        monkeypatch.setenv("FC_FUSED", "0")
+        y_unfused, lad_unfused = t(x.to(device))
+    tol_y = 2e-5 * max(1.0, float(ref_y.abs().max())) + 4 * maxdiff(ref_y, ref_y64)
+    tol_l = 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10) + 4 * maxdiff(ref_lad, ref_lad64)
+    assert maxdiff(y, ref_y64) <= tol_y and maxdiff(lad, ref_lad64) <= tol_l
+    assert maxdiff(y, y_unfused) <= tol_y and maxdiff(lad, lad_unfused) <= tol_l
