@@ -274,10 +274,11 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
 
     # ---- fused final conditioner layer -------------------------------------------
     # When the conditioner is this package's ResidualNet with the north-star shape (hidden 64, K = 8, linear
-    # tails, up to 32 transformed dims) its last nn.Linear is evaluated INSIDE the spline kernel on
-    # the matrix cores (split-f16 products, f32-GEMM accuracy), so the [N, 736] parameter tensor never
-    # touches HBM; the hidden layers run in fc_resnet_hidden.  Inference only.  Any other conditioner /
-    # shape takes the generic path; FC_FUSED=0 disables it.
+    # tails) its last nn.Linear is evaluated INSIDE the spline kernel on the matrix cores (split-f16
+    # products, f32-GEMM accuracy), so the [N, 736] parameter tensor never touches HBM; the hidden layers
+    # run in fc_resnet_hidden.  The kernel takes up to 32 transformed dims per launch: wider layers
+    # (D <= 128) chain one launch per 32 dims, each passing the other columns through.  Inference only.
+    # Any other conditioner / shape takes the generic path; FC_FUSED=0 disables it.
 
     def _fused_ok(self, inputs):
         from flowconductor_amd.nn.nets.resnet import ResidualNet
@@ -287,15 +288,26 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             return False   # training: conditioner on PyTorch autograd + the spline's own backward kernel
         return (os.environ.get("FC_FUSED", "1") != "0" and type(net) is ResidualNet and inputs.dim() == 2
                 and inputs.is_cuda and inputs.dtype == torch.float32
-                and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], self.num_transform_features,
+                and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1],
+                                               min(self.num_transform_features, ops.FUSED_DT),
                                                net.hidden_features, self.num_bins, self.tails))
 
-    def _packed_final_layer(self):
+    def _fused_chunks(self, device):
+        """[(w_pad, bias_pad, cols)] per group of <= 32 transformed dims: the final Linear's rows of those dims in
+        the kernel's layout + their column indices."""
         lin = self.transform_net.final_layer
         key = (lin.weight._version, lin.bias._version, lin.weight.device, lin.weight.data_ptr())
         if getattr(self, "_packed", None) is None or self._packed[0] != key:
-            self._packed = (key,) + ops.pack_final_layer(lin.weight, lin.bias, self.num_bins)
-        return self._packed[1], self._packed[2]
+            per_dim = 3 * self.num_bins - 1
+            cols = self._cols(device)
+            chunks = []
+            for lo in range(0, self.num_transform_features, ops.FUSED_DT):
+                hi = min(lo + ops.FUSED_DT, self.num_transform_features)
+                rows = slice(lo * per_dim, hi * per_dim)
+                chunks.append(ops.pack_final_layer(lin.weight[rows], lin.bias[rows], self.num_bins)
+                              + (cols[lo:hi].contiguous(),))
+            self._packed = (key, chunks)
+        return self._packed[1]
 
     def _apply_accumulate(self, inputs, context, inverse, total):
         """CompositeTransform fast path: the fused kernel adds this layer's logabsdet onto ``total`` itself."""
@@ -329,19 +341,24 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             if inverse and self.unconditional_transform is not None:
                 identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
             hidden = net.hidden(identity_split, context)
-        w_pad, bias_pad = self._packed_final_layer()
+        chunks = self._fused_chunks(inputs.device)
         kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                   min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
                   wh_divisor=_softmax_divisor(net, warn=False), inverse=inverse)
+
+        def fused(rows, h, accum):
+            # the groups only depend on the identity columns: any order, each launch passes the rest through
+            lad = accum
+            for w_pad, bias_pad, cols in chunks:
+                rows, lad = ops.rq_spline_fused_linear(rows, h, w_pad, bias_pad, cols, logabsdet_accum=lad, **kw)
+            return rows, lad
+
         body = n - n % ops.FUSED_ROWS
-        cols = self._cols(inputs.device)
         if body == n:
-            outputs, logabsdet = ops.rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols,
-                                                            logabsdet_accum=total, **kw)
+            outputs, logabsdet = fused(inputs, hidden, total)
         else:
             # the < 32 leftover rows go through the final Linear + the stand-alone kernel
-            out_a, lad_a = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_pad, bias_pad, cols,
-                                                      logabsdet_accum=None if total is None else total[:body], **kw)
+            out_a, lad_a = fused(inputs[:body], hidden[:body], None if total is None else total[:body])
             out_b, lad_b = self._coupling_kernel(inputs[body:].contiguous(), net.final_layer(hidden[body:]), inverse)
             outputs = torch.cat((out_a, out_b))
             if total is None:

@@ -248,10 +248,11 @@ def test_made_hidden_stack_on_hip_kernel(kind, inverse, device, monkeypatch):
     assert maxdiff(y, y2) <= tol * scale
 
 
-@pytest.mark.parametrize("features,n", [(32, 1000), (20, 333), (63, 200)])
+@pytest.mark.parametrize("features,n", [(32, 1000), (20, 333), (63, 200), (128, 500), (100, 333), (70, 64)])
 def test_fused_flow_other_widths(features, n, device, monkeypatch):
     """Flows whose coupling layers transform fewer than 32 dims (D = 32 -> 16, D = 20 -> 10) take the fused kernels
-    too, also with an odd feature count (63: rows that are not a whole number of float4).  Against the oracle."""
+    too, also with an odd feature count (63: rows that are not a whole number of float4); layers that transform more
+    than 32 dims (D = 128 -> 64, 100 -> 50, 70 -> 35) chain one launch per 32 dims.  Against the oracle."""
     from flowconductor_amd import distributions, flows, transforms, utils
     from flowconductor_amd.nn import nets
 
@@ -270,5 +271,12 @@ def test_fused_flow_other_widths(features, n, device, monkeypatch):
     flow = flow.to(device)
     with torch.no_grad(), ops.KernelTimer("fc_rq_spline_fused_linear") as timer:
         lp = flow.log_prob(x.to(device))
-    assert len(timer.pairs) == 4, len(timer.pairs)
+    transformed = [int(l.num_transform_features) for l in layers]
+    assert len(timer.pairs) == sum(-(-t // 32) for t in transformed), len(timer.pairs)
     assert maxdiff(lp, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    # sampling direction through the same chained launches
+    with torch.no_grad():
+        z, lad = flow._transform(x.to(device))
+        back, lad_inv = flow._transform.inverse(z)
+    assert maxdiff(back, x) <= 2e-4 * max(1.0, float(x.abs().max()))
+    assert maxdiff(lad + lad_inv, torch.zeros_like(lad)) <= 2e-3
