@@ -69,7 +69,7 @@ struct HiddenLds {
   static constexpr int kFragG = 1 * 4 * 2;                // fragments of a 64 x C gate layer (C <= 32)
   static constexpr int kFragsMain = kFrag0 + 2 * NB * kFragL;
   static constexpr int kFrags = kFragsMain + (kCtx ? NB * kFragG : 0);
-  static constexpr size_t kBytes = (size_t)kFrags * 64 * 16 + kLayers * 64 * 4 + 16 * 4 + 32 * K0S * 4 + 128;
+  static constexpr size_t kBytes = (size_t)kFrags * 64 * 16 + kLayers * 64 * 4 + 16 * 4 + 32 * K0S * 4 + 16 * 8 * 4;
   static_assert(kLayers <= 16, "wun holds 16 entries");
   static_assert(kBytes <= 160 * 1024, "weight fragments exceed the CU's LDS");
 };
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
   float* bias = reinterpret_cast<float*>(hsmem + (size_t)L::kFrags * 64 * 16);   // [layer][g][16]
   float* wun = bias + L::kLayers * 64;                                             // [layer] (padded to 16)
   int* ids = reinterpret_cast<int*>(wun + 16);                                      // [32 K0S]
-  float* red = reinterpret_cast<float*>(ids + 32 * K0S);                           // [8] + pad
+  float* red = reinterpret_cast<float*>(ids + 32 * K0S);                           // [layer][8 waves]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s16 = lane & 15, g = lane >> 4;
@@ -91,38 +91,82 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
   // ---- once per workgroup: scale, split and lay out the weights -----------------------------------
   // operand column i of the initial layer: identity column of x (>= 0), context feature -2 - j, or padding (-1)
   for (int i = tid; i < 32 * K0S; i += kHidThreads) ids[i] = i < k0 ? a.id_cols[i] : (i < k0 + C ? -2 - (i - k0) : -1);
+  // Two rounds of global loads for ALL layers together (maxima, then fragments) with one barrier pair between them:
+  // layer by layer the dependent load latencies and barriers of 5-13 layers cost ~15 us per launch.
+  auto layer_src = [&](int l, const float*& w, const float*& b, int& kin, int& nks, int& base) {
+    const bool gate = l >= L::kMain;
+    w = l == 0 ? a.w0 : gate ? a.wc + (size_t)(l - L::kMain) * kHid * C : a.wb + (size_t)(l - 1) * kHid * kHid;
+    b = l == 0 ? a.b0 : gate ? a.bc + (size_t)(l - L::kMain) * kHid : a.bb + (size_t)(l - 1) * kHid;
+    kin = l == 0 ? k0 + C : gate ? C : kHid;
+    nks = l == 0 ? K0S : gate ? 1 : 2;
+    base = l == 0 ? 0 : gate ? L::kFragsMain + (l - L::kMain) * L::kFragG : L::kFrag0 + (l - 1) * L::kFragL;
+  };
+  float wmax[L::kLayers];
 #pragma unroll
   for (int l = 0; l < L::kLayers; ++l) {
-    const bool gate = l >= L::kMain;
-    const float* w = l == 0 ? a.w0 : gate ? a.wc + (size_t)(l - L::kMain) * kHid * C : a.wb + (size_t)(l - 1) * kHid * kHid;
-    const float* b = l == 0 ? a.b0 : gate ? a.bc + (size_t)(l - L::kMain) * kHid : a.bb + (size_t)(l - 1) * kHid;
-    const int kin = l == 0 ? k0 + C : gate ? C : kHid;
+    const float *w, *b;
+    int kin, nks, base;
+    layer_src(l, w, b, kin, nks, base);
     float m = 0.f;
-    for (int i = tid; i < kHid * kin; i += kHidThreads) m = fmaxf(m, fabsf(w[i]));
+    if (kin == kHid) {
+      // 64 x 64 layer: 8 consecutive weights per thread as two independent 16-byte loads
+      const float4* w4 = reinterpret_cast<const float4*>(w) + 2 * tid;
+      const float4 p = w4[0], q = w4[1];
+      m = fmaxf(fmaxf(fmaxf(fabsf(p.x), fabsf(p.y)), fmaxf(fabsf(p.z), fabsf(p.w))),
+                fmaxf(fmaxf(fabsf(q.x), fabsf(q.y)), fmaxf(fabsf(q.z), fabsf(q.w))));
+    } else {
+      // four loads in flight per step (a plain accumulation loop waits for every load in turn)
+      const int total = kHid * kin;
+      for (int i = tid; i < total; i += 4 * kHidThreads) {
+        const float v0 = w[i];
+        const float v1 = i + kHidThreads < total ? w[i + kHidThreads] : 0.f;
+        const float v2 = i + 2 * kHidThreads < total ? w[i + 2 * kHidThreads] : 0.f;
+        const float v3 = i + 3 * kHidThreads < total ? w[i + 3 * kHidThreads] : 0.f;
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
+      }
+    }
+    wmax[l] = m;
+  }
+#pragma unroll
+  for (int l = 0; l < L::kLayers; ++l) {
+    float m = wmax[l];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    __syncthreads();   // red is free again
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    m = red[0];
+    if (lane == 0) red[l * (kHidThreads / 64) + wave] = m;
+  }
+  __syncthreads();
 #pragma unroll
-    for (int i = 1; i < kHidThreads / 64; ++i) m = fmaxf(m, red[i]);
+  for (int l = 0; l < L::kLayers; ++l) {
+    const float *w, *b;
+    int kin, nks, base;
+    layer_src(l, w, b, kin, nks, base);
+    float m = red[l * (kHidThreads / 64)];
+#pragma unroll
+    for (int i = 1; i < kHidThreads / 64; ++i) m = fmaxf(m, red[l * (kHidThreads / 64) + i]);
     float sc, un;
     pow2_scale(m, sc, un);
     if (tid == 0) wun[l] = un;
     // fragment entry e = (ks * 4 + t) * 64 + lane': W[feat(t, lane' & 15)][32 ks + 8 (lane' >> 4) + j]
-    const int nks = l == 0 ? K0S : gate ? 1 : 2;
-    const int base = l == 0 ? 0 : gate ? L::kFragsMain + (l - L::kMain) * L::kFragG : L::kFrag0 + (l - 1) * L::kFragL;
     for (int e = tid; e < nks * 4 * 64; e += kHidThreads) {
       const int ln = e & 63, t = (e >> 6) & 3, ks = e >> 8;
       const int rho = ln & 15, f = hid_feat(t, rho >> 2, rho & 3);
       f16x8 hi, lo;
+      float v[8];
+      if (kin == kHid) {   // 8 consecutive weights of a row, 32-byte aligned: two 16-byte loads
+        const float4* w4 = reinterpret_cast<const float4*>(w + (size_t)f * kHid + 32 * ks + 8 * (ln >> 4));
+        const float4 p = w4[0], q = w4[1];
+        v[0] = p.x, v[1] = p.y, v[2] = p.z, v[3] = p.w, v[4] = q.x, v[5] = q.y, v[6] = q.z, v[7] = q.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 32 * ks + 8 * (ln >> 4) + j;
+          v[j] = k < kin ? w[(size_t)f * kin + k] : 0.f;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int k = 32 * ks + 8 * (ln >> 4) + j;
-        const float v = k < kin ? w[(size_t)f * kin + k] * sc : 0.f;
         _Float16 ph, pl;
-        split2(v, ph, pl);
+        split2(v[j] * sc, ph, pl);
         hi[j] = ph;
         lo[j] = pl;
       }
@@ -358,7 +402,7 @@ extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols
   if (n % 16 != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
   if (!x || !h || !id_cols || !w0 || !b0 || (num_blocks > 0 && (!wb || !bb))) return hipErrorInvalidValue;
-  if (((uintptr_t)h & 15u) != 0) return hipErrorInvalidValue;
+  if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)wb & 15u) != 0) return hipErrorInvalidValue;
   fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, nullptr, nullptr, nullptr, 0};
   return fc::dispatch_hidden<false>(a, num_blocks, static_cast<hipStream_t>(stream));
 }
@@ -377,7 +421,7 @@ extern "C" int fc_resnet_hidden_context(const float* x, const float* context, fl
   if (n == 0) return hipSuccess;
   if (!x || !context || !h || !id_cols || !w0 || !b0 || (num_blocks > 0 && (!wb || !bb || !wc || !bc)))
     return hipErrorInvalidValue;
-  if (((uintptr_t)h & 15u) != 0) return hipErrorInvalidValue;
+  if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)wb & 15u) != 0) return hipErrorInvalidValue;
   fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, context, wc, bc, context_features};
   return fc::dispatch_hidden<true>(a, num_blocks, static_cast<hipStream_t>(stream));
 }

@@ -1,6 +1,5 @@
 """Flow-level behaviour and the BASELINE.json configurations at (or near) their full sizes,
 checked through size-independent properties plus oracle spot-checks on row subsets."""
-import numpy as np
 import pytest
 import torch
 

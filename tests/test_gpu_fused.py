@@ -1,6 +1,5 @@
 """Final-conditioner-layer + RQ-spline fused kernel (fc_rq_spline_fused_linear) vs the unfused HIP path
 and the CPU oracle."""
-import os
 
 import pytest
 import torch
