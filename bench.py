@@ -47,7 +47,7 @@ def build_flow():
     return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([FEATURES])).eval()
 
 
-TRAFFIC_PROFILE = "profiles/r01g_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r01h_hbm_traffic.json"
 
 
 def measured_traffic_per_launch(entry, rows_per_launch):
@@ -297,11 +297,11 @@ def main():
                                "frac": f_gbs / HBM_PEAK_GBS,
                                "traffic": measured_traffic_per_launch("fc_rq_spline_fused_linear", rows_per_launch),
                                "traffic_source": src,
-                               "kernel": "fc_rq_spline_fused_linear -> fc::rq_fused_linear_kernel3<false, 64, 2>",
+                               "kernel": "fc_rq_spline_fused_linear -> fc::rq_fused_linear_kernel3<false, 64, 2, true, true>",
                                "launches_timed": len(fused_ms), "avg_launch_ms": f_avg,
                                "algorithmic_bytes_per_launch": f_bytes,
                                "share_of_step": sum(fused_ms) / (1e3 * elapsed),
-                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01g_fused_sq_counters.txt",
+                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01h_fused_sq_counters.txt",
                                # BASELINE.md section 4 prices a coupling bijector at B = 4 d_t (P + 2) + 8 bytes per
                                # sample and layer (parameters read from HBM).  The fused kernel never moves them; in
                                # that accounting it delivers:
@@ -324,7 +324,7 @@ def main():
                 out["roofline_hidden"] = {"bound": "hbm", "achieved": h_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": h_gbs / HBM_PEAK_GBS,
                                           "traffic": measured_traffic_per_launch("fc_resnet_hidden", rows_per_launch),
-                                          "kernel": "fc_resnet_hidden -> fc::resnet_hidden_kernel<2, 1>",
+                                          "kernel": "fc_resnet_hidden -> fc::resnet_hidden_kernel<2, 1, false>",
                                           "launches_timed": len(hidden_ms), "avg_launch_ms": h_avg,
                                           "algorithmic_bytes_per_launch": h_bytes,
                                           "share_of_step": sum(hidden_ms) / (1e3 * elapsed),
