@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kMaxBlock) void tile_kernel_pf(Op op, TileArgs a, i
           const float* r = ls + s * d_t;
           for (int j = 0; j < d_t; ++j) tot += r[j];
         }
-        a.logabsdet[n0 + s] = (a.lad_mode & 2) ? -tot : tot;
+        emit_lad(a.logabsdet + n0 + s, tot, a.lad_mode);
       }
     }
     float4* yg = reinterpret_cast<float4*>(a.y + n0 * D);
@@ -394,7 +394,7 @@ inline hipError_t launch_tile(const Op& op, TileArgs a, hipStream_t stream) {
   // < S leftover samples through the one-tile-per-workgroup kernel below.
   const int64_t full_tiles = a.N / plan.S;
   const int64_t pvec = ((int64_t)plan.S * a.rowlen) / 4, xvec = ((int64_t)plan.S * a.D) / 4;
-  if (plan.vec_ok && !a.shared_params && plan.block == kMaxBlock && a.lad_mode != 1 && a.lad_mode != 3 &&
+  if (plan.vec_ok && !a.shared_params && plan.block == kMaxBlock &&
       full_tiles >= 64 && pvec <= 8 * kMaxBlock && xvec <= 2 * kMaxBlock) {
     TileArgs body = a;
     body.N = full_tiles * plan.S;

@@ -445,16 +445,21 @@ AFFINE_SCALE_SOFTPLUS = 6
 
 
 def affine_coupling(inputs, params, cols=None, *, activation=AFFINE_SIGMOID_PLUS2, inverse=False,
-                    shared_params=False):
+                    shared_params=False, logabsdet_accum=None):
     """Affine bijector on ``inputs[:, cols]`` with per-sample ``params`` rows; records an autograd node when
-    gradients are required (forward direction, per-sample parameters).  See ``_affine_coupling_nograd``."""
+    gradients are required (forward direction, per-sample parameters).  See ``_affine_coupling_nograd``.
+    ``logabsdet_accum``: running total the kernel adds onto (no-grad calls; otherwise added here)."""
     if torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad):
         if inverse or shared_params:
             raise RuntimeError("flowconductor_amd: gradients are implemented for the forward direction of the "
                                "affine bijector with per-sample parameters; wrap other calls in torch.no_grad().")
-        return _AffineFunction.apply(inputs, params, cols, activation)
+        outputs, logabsdet = _AffineFunction.apply(inputs, params, cols, activation)
+        if logabsdet_accum is not None:
+            logabsdet_accum += logabsdet
+            logabsdet = logabsdet_accum
+        return outputs, logabsdet
     return _affine_coupling_nograd(inputs, params, cols, activation=activation, inverse=inverse,
-                                   shared_params=shared_params)
+                                   shared_params=shared_params, logabsdet_accum=logabsdet_accum)
 
 
 class _AffineFunction(torch.autograd.Function):
@@ -486,11 +491,12 @@ class _AffineFunction(torch.autograd.Function):
 
 
 def _affine_coupling_nograd(inputs, params, cols=None, *, activation=AFFINE_SIGMOID_PLUS2, inverse=False,
-                            shared_params=False):
+                            shared_params=False, logabsdet_accum=None):
     """Affine bijector on ``inputs[:, cols]`` with per-sample ``params`` rows.
 
     Row layouts per ``activation``: see ``FC_AFFINE_*`` in include/flowcon_hip.h.
     Semantics: reference coupling.py:234-269, autoregressive/autoregressive.py:97-129.
+    With ``logabsdet_accum`` (contiguous f32 [N]) the kernel adds the layer's logabsdet onto it and returns it.
     """
     lib = _hip.load()
     x = _prep_2d(inputs)
@@ -504,10 +510,15 @@ def _affine_coupling_nograd(inputs, params, cols=None, *, activation=AFFINE_SIGM
     if p.numel() != want:
         raise ValueError("params has %d elements, expected %d" % (p.numel(), want))
     y = torch.empty_like(x)
-    lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    if logabsdet_accum is not None:
+        lad = logabsdet_accum
+        if lad.dtype != torch.float32 or lad.shape != (n,) or not lad.is_contiguous() or lad.device != x.device:
+            raise ValueError("logabsdet_accum must be a contiguous float32 [N] tensor on the inputs' device")
+    else:
+        lad = torch.empty(n, dtype=torch.float32, device=x.device)
     _call("fc_affine", lib.fc_affine, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(p), _hip.ptr(cols),
           _hip.ptr(lad), n, d, d_t, activation, 1 if inverse else 0, 1 if shared_params else 0,
-          LAD_STORE, _hip.stream_ptr(x.device))
+          LAD_STORE if logabsdet_accum is None else LAD_ACCUMULATE, _hip.stream_ptr(x.device))
     return y, lad
 
 

@@ -91,10 +91,13 @@ class CouplingTransform(Transform):
 
     def _run(self, inputs, context, inverse):
         self._check(inputs)
-        identity_split = inputs[:, self.identity_features, ...]
-        logabsdet_identity = None
-        if inverse and self.unconditional_transform is not None:
-            identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
+        # the identity half as a tensor of its own (a gather) only where something consumes it: the
+        # hidden-layer kernel reads the identity columns straight from the full rows
+        identity_split = logabsdet_identity = None
+        if self.unconditional_transform is not None:
+            identity_split = inputs[:, self.identity_features, ...]
+            if inverse:
+                identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
 
         transform_params = self._conditioner(inputs, identity_split, context)
 
@@ -134,9 +137,11 @@ class CouplingTransform(Transform):
             hidden = net.hidden_hip(inputs[:body], self._id_cols(inputs.device),
                                     None if context is None else context[:body])
             if body < n:
-                hidden = torch.cat((hidden, net.hidden(identity_split[body:],
+                hidden = torch.cat((hidden, net.hidden(inputs[body:, self.identity_features],
                                                        None if context is None else context[body:])))
             return net.final_layer(hidden)
+        if identity_split is None:
+            identity_split = inputs[:, self.identity_features, ...]
         return net(identity_split, context)
 
     def forward(self, inputs, context=None):
@@ -184,14 +189,25 @@ class AffineCouplingTransform(CouplingTransform):
             return ops.AFFINE_SOFTPLUS_CLAMP3
         return ops.AFFINE_SCALE_GIVEN
 
-    def _coupling_kernel(self, inputs, transform_params, inverse):
+    def _coupling_kernel(self, inputs, transform_params, inverse, total=None):
         code = self._activation_code()
         if code == ops.AFFINE_SCALE_GIVEN:
             d_t = self.num_transform_features
             scale = self.scale_activation(transform_params[:, d_t:])
             transform_params = torch.cat((transform_params[:, :d_t], scale), dim=1)
         return ops.affine_coupling(inputs, transform_params, self._cols(inputs.device),
-                                   activation=code, inverse=inverse)
+                                   activation=code, inverse=inverse, logabsdet_accum=total)
+
+    def _apply_accumulate(self, inputs, context, inverse, total):
+        """CompositeTransform fast path: the kernel adds this layer's logabsdet onto ``total`` itself."""
+        if inputs.dim() != 2 or self.unconditional_transform is not None or not inputs.is_cuda:
+            outputs, logabsdet = self._run(inputs, context, inverse)
+            total += logabsdet
+            return outputs
+        self._check(inputs)
+        transform_params = self._conditioner(inputs, None, context)
+        outputs, _ = self._coupling_kernel(inputs, transform_params, inverse, total=total)
+        return outputs
 
     def _param_rows_nchw(self, transform_params, shape):
         return _rows_from_nchw(transform_params)[0]
@@ -203,7 +219,8 @@ class AdditiveCouplingTransform(AffineCouplingTransform):
     def _transform_dim_multiplier(self):
         return 1
 
-    def _coupling_kernel(self, inputs, transform_params, inverse):
+    def _coupling_kernel(self, inputs, transform_params, inverse, total=None):
+        # logabsdet == 0: nothing to add onto a running total
         return ops.affine_coupling(inputs, transform_params, self._cols(inputs.device),
                                    activation=ops.AFFINE_ADDITIVE, inverse=inverse)
 
