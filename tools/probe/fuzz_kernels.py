@@ -41,10 +41,33 @@ for c in range(cases):
     worst["hidden"] = max(worst.get("hidden", 0.0), err)
     assert err < 5e-5, ("hidden", in_f, blocks, d, n, err)
 
-    # ---- fused final layer + spline against the unfused HIP path
-    d = 4 * ri(8, 32)
+    # ---- hidden kernel with a context (concatenated into the initial layer, GLU gate per block)
+    ctx_f, blocks = ri(1, 32), ri(0, 3)
+    in_f = ri(1, 64 - ctx_f)
+    d = ri(in_f, 128)
+    n = 16 * ri(1, 300)
+    torch.manual_seed(seed * 1000 + c + 500)
+    net = nets.ResidualNet(in_f, 8, hidden_features=64, context_features=ctx_f, num_blocks=blocks).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(float(torch.rand(1, generator=g)) * 3 + 0.3)
+    ids = torch.randperm(d, generator=g)[:in_f].sort().values
+    x = torch.randn(n, d, generator=g) * float(10 ** (torch.rand(1, generator=g) * 4 - 2))
+    ctx = torch.randn(n, ctx_f, generator=g) * float(10 ** (torch.rand(1, generator=g) * 2 - 1))
+    with torch.no_grad():
+        ref = net.double().hidden(x.double()[:, ids], ctx.double()).float()
+        net = net.float().to(dev)
+        assert net.hip_hidden_supported(d, ctx.to(dev))
+        got = net.hidden_hip(x.to(dev), ids.to(dev), ctx.to(dev)).cpu()
+    err = float((got - ref).abs().max() / max(1e-30, float(ref.abs().max())))
+    worst["hidden_ctx"] = max(worst.get("hidden_ctx", 0.0), err)
+    assert err < 5e-5, ("hidden_ctx", in_f, ctx_f, blocks, d, n, err)
+
+    # ---- fused final layer + spline against the unfused HIP path: any D <= 128, 1..32 transformed dims
+    d_t = ri(1, 32)
+    d = ri(d_t, 128)
     n = 32 * ri(1, 200)
-    k, d_t = 8, 32
+    k = 8
     x = torch.randn(n, d, generator=g) * 1.7
     h = torch.randn(n, 64, generator=g) * float(10 ** (torch.rand(1, generator=g) * 4 - 2))
     w = torch.randn(d_t * 23, 64, generator=g) * 0.2 / float(h.abs().mean())
