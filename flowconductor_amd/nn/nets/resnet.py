@@ -78,13 +78,14 @@ class ResidualNet(nn.Module):
 
     # ---- device fast path for the hidden layers (inference) ------------------------------------------
     def hip_hidden_supported(self, features_total, context=None):
-        """True when ``fc_resnet_hidden`` covers this net: hidden 64, <= 4 blocks, ReLU, no batch norm, dropout
+        """True when ``fc_resnet_hidden`` covers this net: hidden <= 64 (narrower nets run zero-padded in the
+        64-wide kernel), <= 4 blocks, ReLU, no batch norm, dropout
         inactive, input width (identity features + context features) <= 64; a context must be a [N, C <= 32] f32
         tensor matching ``context_features`` and allows <= 3 blocks (the gate layers' fragments share the LDS)."""
         def is_relu(f):
             return isinstance(f, torch.nn.ReLU) or f is F.relu or f is torch.relu
 
-        if self.hidden_features != 64 or len(self.blocks) > 4:
+        if self.hidden_features > 64 or len(self.blocks) > 4:
             return False
         in_f = self.initial_layer.in_features
         if (self.context_features is None) != (context is None):
@@ -107,8 +108,24 @@ class ResidualNet(nn.Module):
                 return False
         return True
 
+    def hidden_padded(self, inputs, context=None):
+        """``hidden`` on PyTorch, zero-padded to the kernel's 64 columns (leftover rows next to ``hidden_hip``)."""
+        h = self.hidden(inputs, context)
+        return h if h.shape[1] == 64 else F.pad(h, (0, 64 - h.shape[1]))
+
+    def final_from_padded(self, hidden64):
+        """``final_layer`` applied to a [N, 64] zero-padded hidden activation."""
+        lin = self.final_layer
+        if lin.in_features == 64:
+            return lin(hidden64)
+        key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device)
+        if getattr(self, "_final_padded", None) is None or self._final_padded[0] != key:
+            self._final_padded = (key, F.pad(lin.weight.detach(), (0, 64 - lin.in_features)))
+        return F.linear(hidden64, self._final_padded[1], lin.bias)
+
     def hidden_hip(self, rows, id_cols, context=None):
-        """h [N, 64] from FULL input rows + the identity column indices (N a multiple of 16) [+ context rows]."""
+        """h [N, 64] from FULL input rows + the identity column indices (N a multiple of 16) [+ context rows]; for a
+        narrower net columns ``hidden_features``.. are zero."""
         from flowconductor_amd import ops
 
         key = tuple((p._version, p.data_ptr()) for p in self.parameters())

@@ -318,27 +318,40 @@ FUSED_ROWS, FUSED_HIDDEN, FUSED_DT, FUSED_BINS = 32, 64, 32, 8
 
 def fused_linear_supported(n, d, d_t, hidden, num_bins, tails):
     """Shapes the fused final-layer + RQ-spline kernel is specialised for (the north-star layer)."""
-    return (hidden == FUSED_HIDDEN and 1 <= d_t <= FUSED_DT and num_bins == FUSED_BINS and tails == "linear"
+    return (1 <= hidden <= FUSED_HIDDEN and 1 <= d_t <= FUSED_DT and num_bins == FUSED_BINS and tails == "linear"
             and d <= 128 and n >= FUSED_ROWS)
 
 
 HIDDEN_ROWS = 16
 
 
+def _pad_to(t, shape):
+    """``t`` zero-padded at the end of every dim up to ``shape`` (returns ``t`` itself when nothing is missing)."""
+    if tuple(t.shape) == tuple(shape):
+        return t.contiguous()
+    out = t.new_zeros(shape)
+    out[tuple(slice(0, k) for k in t.shape)] = t
+    return out
+
+
 def pack_resnet_hidden(net):
-    """Weights of the hidden layers of a ResidualNet (hidden 64, <= 4 blocks) as ``fc_resnet_hidden`` takes
+    """Weights of the hidden layers of a ResidualNet (hidden <= 64, <= 4 blocks) as ``fc_resnet_hidden`` takes
     them: the nn.Linear tensors row-major, the block layers stacked [blocks, 2, 64, 64] / [blocks, 2, 64]; with a
-    context also the blocks' ``context_layer`` stacked [blocks, 64, C] / [blocks, 64]."""
-    w0 = net.initial_layer.weight.detach().contiguous()
-    b0 = net.initial_layer.bias.detach().contiguous()
+    context also the blocks' ``context_layer`` stacked [blocks, 64, C] / [blocks, 64].  A narrower net is embedded
+    in the 64-wide kernel by zero padding: the extra hidden units have zero weights and biases, stay 0 through ReLU
+    and the residual stream, and meet zero columns in every following layer."""
+    hw = FUSED_HIDDEN
+    w0 = _pad_to(net.initial_layer.weight.detach(), (hw, net.initial_layer.in_features))
+    b0 = _pad_to(net.initial_layer.bias.detach(), (hw,))
     ws, bs, wcs, bcs = [], [], [], []
     for block in net.blocks:
         for lin in block.linear_layers:
-            ws.append(lin.weight.detach())
-            bs.append(lin.bias.detach())
+            ws.append(_pad_to(lin.weight.detach(), (hw, hw)))
+            bs.append(_pad_to(lin.bias.detach(), (hw,)))
         if getattr(block, "context_layer", None) is not None:
-            wcs.append(block.context_layer.weight.detach())
-            bcs.append(block.context_layer.bias.detach())
+            cl = block.context_layer
+            wcs.append(_pad_to(cl.weight.detach(), (hw, cl.in_features)))
+            bcs.append(_pad_to(cl.bias.detach(), (hw,)))
     wb = torch.stack(ws).contiguous() if ws else None
     bb = torch.stack(bs).contiguous() if bs else None
     wc = torch.stack(wcs).contiguous() if wcs else None
@@ -377,18 +390,20 @@ def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks, context=None
 
 
 def pack_final_layer(weight, bias, num_bins=FUSED_BINS):
-    """[d_t*23, 64] weight / [d_t*23] bias of the conditioner's final Linear -> (w_pad [dp*24, 64], bias_pad
-    [dp*24]): one zero row / entry appended per dim so that a dim is 24 = 6 x 4 accumulator registers, and zero
-    dims appended up to dp = ceil(d_t / 4) * 4 (a wave owns 4 dims)."""
+    """[d_t*23, H <= 64] weight / [d_t*23] bias of the conditioner's final Linear -> (w_pad [dp*24, 64], bias_pad
+    [dp*24]): one zero row / entry appended per dim so that a dim is 24 = 6 x 4 accumulator registers, zero
+    dims appended up to dp = ceil(d_t / 4) * 4 (a wave owns 4 dims), zero columns up to the kernel's 64 hidden
+    units (they meet the zero activations of a zero-padded hidden stack)."""
     p = 3 * num_bins - 1
     d_t = weight.shape[0] // p
     dp = -(-d_t // 4) * 4
-    w = weight.detach().reshape(d_t, p, weight.shape[1])
-    wpad = w.new_zeros(dp, p + 1, weight.shape[1])
-    wpad[:d_t, :p] = w
+    hidden = weight.shape[1]
+    w = weight.detach().reshape(d_t, p, hidden)
+    wpad = w.new_zeros(dp, p + 1, FUSED_HIDDEN)
+    wpad[:d_t, :p, :hidden] = w
     bpad = bias.new_zeros(dp, p + 1)
     bpad[:d_t, :p] = bias.detach().reshape(d_t, p)
-    return wpad.reshape(dp * (p + 1), weight.shape[1]).contiguous(), bpad.reshape(-1).contiguous()
+    return wpad.reshape(dp * (p + 1), FUSED_HIDDEN).contiguous(), bpad.reshape(-1).contiguous()
 
 
 def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, tail_bound,

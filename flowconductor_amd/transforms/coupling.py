@@ -137,9 +137,9 @@ class CouplingTransform(Transform):
             hidden = net.hidden_hip(inputs[:body], self._id_cols(inputs.device),
                                     None if context is None else context[:body])
             if body < n:
-                hidden = torch.cat((hidden, net.hidden(inputs[body:, self.identity_features],
-                                                       None if context is None else context[body:])))
-            return net.final_layer(hidden)
+                hidden = torch.cat((hidden, net.hidden_padded(inputs[body:, self.identity_features],
+                                                              None if context is None else context[body:])))
+            return net.final_from_padded(hidden)
         if identity_split is None:
             identity_split = inputs[:, self.identity_features, ...]
         return net(identity_split, context)
@@ -351,13 +351,13 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             hidden = net.hidden_hip(inputs[:body16], self._id_cols(inputs.device),
                                     None if context is None else context[:body16])
             if body16 < n:
-                hidden = torch.cat((hidden, net.hidden(inputs[body16:, self.identity_features],
-                                                       None if context is None else context[body16:])))
+                hidden = torch.cat((hidden, net.hidden_padded(inputs[body16:, self.identity_features],
+                                                              None if context is None else context[body16:])))
         else:
             identity_split = inputs[:, self.identity_features]
             if inverse and self.unconditional_transform is not None:
                 identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
-            hidden = net.hidden(identity_split, context)
+            hidden = net.hidden_padded(identity_split, context)
         chunks = self._fused_chunks(inputs.device)
         kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                   min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
@@ -376,7 +376,8 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         else:
             # the < 32 leftover rows go through the final Linear + the stand-alone kernel
             out_a, lad_a = fused(inputs[:body], hidden[:body], None if total is None else total[:body])
-            out_b, lad_b = self._coupling_kernel(inputs[body:].contiguous(), net.final_layer(hidden[body:]), inverse)
+            out_b, lad_b = self._coupling_kernel(inputs[body:].contiguous(), net.final_from_padded(hidden[body:]),
+                                                 inverse)
             outputs = torch.cat((out_a, out_b))
             if total is None:
                 logabsdet = torch.cat((lad_a, lad_b))

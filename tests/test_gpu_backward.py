@@ -86,7 +86,7 @@ def test_coupling_layer_trains_through_hip_path(device):
         y, lad = t_gpu(x.to(device))
         ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
     assert len(timer.pairs) == 1, "the backward kernel did not run"
-    assert maxdiff(y.detach().cpu().double(), y_ref.detach()) <= 2e-5 * float(y_ref.abs().max())
+    assert maxdiff(y.detach().cpu().double(), y_ref.detach()) <= 2e-5 * float(y_ref.detach().abs().max())
     for (name, p_ref), (_, p) in zip(t_cpu.named_parameters(), t_gpu.named_parameters()):
         assert p.grad is not None, name
         scale = max(1e-6, float(p_ref.grad.abs().max()))

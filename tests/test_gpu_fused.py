@@ -1,6 +1,8 @@
 """Final-conditioner-layer + RQ-spline fused kernel (fc_rq_spline_fused_linear) vs the unfused HIP path
 and the CPU oracle."""
 
+import copy
+
 import pytest
 import torch
 
@@ -64,6 +66,71 @@ def test_resnet_hidden_kernel_matches_torch(in_f, blocks, d, n, device):
         got = net.to(device).hidden_hip(x.to(device), ids.to(device))
     assert got.shape == (n, 64)
     assert maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("hidden,in_f,blocks,ctx_f", [(32, 16, 2, None), (48, 20, 1, None), (7, 3, 4, None),
+                                                     (32, 16, 2, 6), (50, 10, 3, 32)])
+def test_resnet_hidden_kernel_narrow_nets_zero_padded(hidden, in_f, blocks, ctx_f, device):
+    """Conditioners with fewer than 64 hidden units run in the 64-wide kernel on zero-padded weights: the padding
+    units stay exactly 0, the real ones match the module in float64."""
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(hidden + in_f)
+    net = nets.ResidualNet(in_f, 8, hidden_features=hidden, context_features=ctx_f, num_blocks=blocks).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    d, n = 2 * in_f + 1, 4096
+    ids = torch.randperm(d)[:in_f].sort().values
+    x = torch.randn(n, d)
+    c = None if ctx_f is None else torch.randn(n, ctx_f)
+    with torch.no_grad():
+        ref = copy.deepcopy(net).double().hidden(x.double()[:, ids], None if c is None else c.double())
+        ref32 = net.hidden(x[:, ids], c)
+        net = net.to(device)
+        cd = None if c is None else c.to(device)
+        assert net.hip_hidden_supported(d, cd)
+        got = net.hidden_hip(x.to(device), ids.to(device), cd)
+        out = net.final_from_padded(got)
+        out_ref = net.final_layer(net.hidden(x.to(device)[:, ids.to(device)], cd))
+    assert got.shape == (n, 64)
+    assert float(got[:, hidden:].abs().max()) == 0.0
+    assert maxdiff(got[:, :hidden], ref) <= 1e-5 * max(1.0, float(ref.abs().max())) + 4 * maxdiff(ref32, ref)
+    assert maxdiff(out, out_ref) <= 2e-5 * max(1.0, float(out_ref.abs().max()))
+
+
+@pytest.mark.parametrize("hidden_features,n", [(32, 1000), (20, 77)])
+def test_fused_flow_narrow_conditioners(hidden_features, n, device, monkeypatch):
+    """RQ and affine coupling flows whose conditioners have fewer than 64 hidden units take the same fused kernels
+    (1/sqrt(hidden_features) division with the real width).  Against the oracle."""
+    from flowconductor_amd import distributions, flows, transforms, utils
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(hidden_features)
+    features = 24
+
+    def net(a, b):
+        return nets.ResidualNet(a, b, hidden_features=hidden_features, num_blocks=2)
+
+    layers = []
+    for i in range(4):
+        mask = utils.create_alternating_binary_mask(features, even=(i % 2 == 0))
+        layers.append(transforms.PiecewiseRationalQuadraticCouplingTransform(mask, net, num_bins=8, tails="linear",
+                                                                             tail_bound=3.0))
+        layers.append(transforms.AffineCouplingTransform(mask, net))
+    flow = flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([features])).eval()
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.mul_(1.5)
+    x = torch.randn(n, features) * 1.2
+    with torch.no_grad():
+        ref = O.flow_log_prob(flow, x)
+    flow = flow.to(device)
+    with torch.no_grad(), ops.KernelTimer("fc_rq_spline_fused_linear") as fused, \
+            ops.KernelTimer("fc_resnet_hidden") as hid:
+        lp = flow.log_prob(x.to(device))
+    assert len(fused.pairs) == 4 and len(hid.pairs) == 8
+    assert maxdiff(lp, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("xscale", [1e-6, 1.0, 3e5])

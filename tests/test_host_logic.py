@@ -164,6 +164,16 @@ def test_pack_resnet_hidden_stacks_linear_weights():
     assert torch.equal(wb[1], net.blocks[0].linear_layers[1].weight) and torch.equal(bb[2], net.blocks[1].linear_layers[0].bias)
     w0, b0, wb, bb, wc, bc = ops.pack_resnet_hidden(nets.ResidualNet(6, 8, hidden_features=64, num_blocks=0))
     assert wb is None and bb is None and w0.shape == (64, 6)
+    # a narrower net is zero-padded to the kernel's 64 hidden units
+    narrow = nets.ResidualNet(6, 8, hidden_features=20, num_blocks=1)
+    w0, b0, wb, bb, wc, bc = ops.pack_resnet_hidden(narrow)
+    assert w0.shape == (64, 6) and wb.shape == (2, 64, 64) and float(w0[20:].abs().max()) == 0.0
+    assert torch.equal(wb[0, :20, :20], narrow.blocks[0].linear_layers[0].weight) and float(wb[:, 20:].abs().max()) == 0.0
+    assert float(wb[:, :, 20:].abs().max()) == 0.0 and float(bb[:, 20:].abs().max()) == 0.0
+    wp, bp = ops.pack_final_layer(torch.ones(2 * 23, 20), torch.ones(2 * 23))
+    assert wp.shape == (4 * 24, 64) and float(wp[:, 20:].abs().max()) == 0.0 and float(wp[:23, :20].min()) == 1.0
+    assert narrow.hidden_padded(torch.zeros(3, 6)).shape == (3, 64)
+    assert torch.allclose(narrow.final_from_padded(narrow.hidden_padded(torch.ones(3, 6))), narrow(torch.ones(3, 6)), atol=1e-6)
     # with a context: the initial layer is [identity | context] wide, the blocks' gate layers are stacked
     net = nets.ResidualNet(10, 8, hidden_features=64, context_features=5, num_blocks=3)
     w0, b0, wb, bb, wc, bc = ops.pack_resnet_hidden(net)
