@@ -27,8 +27,9 @@ class AutoregressiveTransform(Transform):
 
     def _hidden(self, inputs, context):
         """Everything before the conditioner's final layer, or None when the net is not a MADE-like module with
-        ``hidden`` / ``final_layer``.  A MADE whose hidden stack ``fc_resnet_hidden`` covers (hidden 64, residual
-        blocks, ReLU, no context) runs it there on pre-masked weights -- inference only."""
+        ``hidden`` / ``final_layer``.  A MADE whose hidden stack ``fc_resnet_hidden`` covers (hidden <= 64, residual
+        blocks, ReLU, no context) runs it there on pre-masked weights -- inference only; the result then has the
+        kernel's 64 columns (zeros beyond a narrower MADE's width; ``_final`` accounts for them)."""
         net = self.autoregressive_net
         if not (hasattr(net, "hidden") and hasattr(net, "final_layer")):
             return None
@@ -40,9 +41,27 @@ class AutoregressiveTransform(Transform):
             body = n - n % ops.HIDDEN_ROWS
             hidden = net.hidden_hip(inputs[:body].contiguous())
             if body < n:
-                hidden = torch.cat((hidden, net.hidden(inputs[body:])))
+                tail = net.hidden(inputs[body:])
+                if tail.shape[1] != hidden.shape[1]:
+                    tail = F.pad(tail, (0, hidden.shape[1] - tail.shape[1]))
+                hidden = torch.cat((hidden, tail))
             return hidden
         return net.hidden(inputs, context)
+
+    def _final(self, hidden, rows=None):
+        """Final layer on ``hidden`` ([N, H], or [N, 64] zero-padded from the kernel); ``rows``: a slice of its
+        outputs (the parameters of one dim)."""
+        net = self.autoregressive_net
+        final = net.final_layer
+        if hidden.shape[1] == final.in_features and rows is None:
+            return final(hidden)
+        if hasattr(net, "masked_final"):
+            weight, bias = net.masked_final(hidden.shape[1])
+        else:
+            weight, bias = final.weight, final.bias
+        if rows is not None:
+            weight, bias = weight[rows], None if bias is None else bias[rows]
+        return F.linear(hidden, weight, bias)
 
     def _needs_grad(self, inputs):
         return torch.is_grad_enabled() and (inputs.requires_grad
@@ -53,7 +72,7 @@ class AutoregressiveTransform(Transform):
         hidden = self._hidden(inputs, context) if inputs.dim() == 2 else None
         if hidden is None:
             return self.autoregressive_net(inputs, context)
-        return self.autoregressive_net.final_layer(hidden)
+        return self._final(hidden)
 
     def forward(self, inputs, context=None):
         autoregressive_params = self._conditioner(inputs, context)
@@ -96,15 +115,13 @@ class AutoregressiveTransform(Transform):
         final = net.final_layer
         features = inputs.shape[1]
         per_dim = final.out_features // features
-        weight = (final.weight * final.mask).detach().view(features, per_dim, final.in_features)
-        bias = final.bias.detach().view(features, per_dim) if final.bias is not None else None
         columns = inputs.t().contiguous()           # row d = the d-th column, contiguous
         outputs = torch.zeros_like(inputs)
         logabsdet = None
         with ops.deferred_errors():
             for d in range(features):
                 hidden = self._hidden(outputs, context)
-                params = F.linear(hidden, weight[d], None if bias is None else bias[d])
+                params = self._final(hidden, slice(d * per_dim, (d + 1) * per_dim))
                 column, lad = self._elementwise_inverse(columns[d].unsqueeze(1), params)
                 outputs[:, d] = column[:, 0]
                 logabsdet = lad if logabsdet is None else logabsdet + lad
@@ -241,9 +258,10 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         return (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
                 and os.environ.get("FC_FUSED", "1") != "0" and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
                 and isinstance(net, made_module.MADE) and not hasattr(net, "hidden_features")
-                and net.final_layer.in_features == 64 and net.hip_hidden_supported()
-                and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], inputs.shape[1], 64,
-                                               self.num_bins, self.tails)
+                and net.final_layer.in_features <= 64 and net.hip_hidden_supported()
+                and inputs.shape[0] >= ops.FUSED_ROWS
+                and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], inputs.shape[1],
+                                               net.final_layer.in_features, self.num_bins, self.tails)
                 and not net._forward_hooks and not net._forward_pre_hooks and not self._needs_grad(inputs))
 
     def _packed_final_layer(self, device):
@@ -269,8 +287,7 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
         body = n - n % ops.FUSED_ROWS
         outputs, logabsdet = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_pad, b_pad, cols, **kw)
         if body < n:   # the < 32 leftover rows: masked final Linear + the stand-alone kernel
-            params = F.linear(hidden[body:], masked, net.final_layer.bias)
-            out_b, lad_b = self._elementwise_forward(inputs[body:], params)
+            out_b, lad_b = self._elementwise_forward(inputs[body:], self._final(hidden[body:]))
             outputs, logabsdet = torch.cat((outputs, out_b)), torch.cat((logabsdet, lad_b))
         return outputs, logabsdet
 

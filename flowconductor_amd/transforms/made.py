@@ -172,7 +172,7 @@ class MADE(nn.Module):
             return isinstance(f, torch.nn.ReLU) or f is F.relu or f is torch.relu
 
         if (not self.use_residual_blocks or hasattr(self, "context_layer") or len(self.blocks) > 4
-                or self.initial_layer.out_features != 64 or self.initial_layer.in_features > 64
+                or self.initial_layer.out_features > 64 or self.initial_layer.in_features > 64
                 or not is_relu(self.activation)):
             return False
         for block in self.blocks:
@@ -183,17 +183,34 @@ class MADE(nn.Module):
         return True
 
     def hidden_hip(self, rows):
-        """h [N, 64] of ``rows`` [N, features] (N a multiple of 16) by ``fc_resnet_hidden`` on pre-masked weights."""
+        """h [N, 64] of ``rows`` [N, features] (N a multiple of 16) by ``fc_resnet_hidden`` on pre-masked weights; a
+        narrower MADE runs zero-padded (columns ``hidden_features``.. of the result are zero)."""
         from flowconductor_amd import ops
 
         layers = [self.initial_layer] + [lin for block in self.blocks for lin in block.linear_layers]
         key = tuple((lin.weight._version, lin.bias._version, lin.weight.data_ptr()) for lin in layers)
         if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
-            masked = [(lin.weight * lin.mask).detach().contiguous() for lin in layers]
-            biases = [lin.bias.detach() for lin in layers]
+            hw = ops.FUSED_HIDDEN
+            masked = [ops._pad_to((lin.weight * lin.mask).detach(), (hw, lin.in_features if i == 0 else hw))
+                      for i, lin in enumerate(layers)]
+            biases = [ops._pad_to(lin.bias.detach(), (hw,)) for lin in layers]
             wb = torch.stack(masked[1:]).contiguous() if len(masked) > 1 else None
             bb = torch.stack(biases[1:]).contiguous() if len(biases) > 1 else None
             ids = torch.arange(self.initial_layer.in_features, dtype=torch.int32, device=rows.device)
             self._hip_packed = (key, (masked[0], biases[0].contiguous(), wb, bb), ids)
         return ops.resnet_hidden(rows, self._hip_packed[2], self._hip_packed[1], self.initial_layer.in_features,
                                  len(self.blocks))
+
+    def masked_final(self, width=None):
+        """(weight * mask [out, width], bias) of the final layer, cached per parameter version; ``width`` = 64 pads
+        the columns with zeros (for a zero-padded hidden activation)."""
+        lin = self.final_layer
+        width = lin.in_features if width is None else width
+        key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device, width)
+        cache = getattr(self, "_masked_final", None)
+        if cache is None or cache[0] != key:
+            w = (lin.weight * lin.mask).detach()
+            if width != lin.in_features:
+                w = F.pad(w, (0, width - lin.in_features))
+            self._masked_final = cache = (key, w.contiguous())
+        return cache[1], lin.bias

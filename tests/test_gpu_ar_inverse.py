@@ -137,3 +137,34 @@ def test_rq_autoregressive_forward_on_fused_kernels(features, n, device, monkeyp
     tol_l = 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10) + 4 * maxdiff(ref_lad, ref_lad64)
     assert maxdiff(y, ref_y64) <= tol_y and maxdiff(lad, ref_lad64) <= tol_l
     assert maxdiff(y, y_unfused) <= tol_y and maxdiff(lad, lad_unfused) <= tol_l
+
+
+def test_readme_maf_flow_runs_its_made_on_the_hidden_kernel(device):
+    """BASELINE configs[0] (the README flow: 2 x [MAF(features=2, hidden_features=4), RandomPermutation]): a MADE with
+    4 hidden units runs zero-padded in the 64-wide hidden-layer kernel; log_prob and samples against the oracle."""
+    from flowconductor_amd import distributions, flows, ops, transforms
+
+    torch.manual_seed(0)
+    layers = []
+    for _ in range(2):
+        layers.append(transforms.MaskedAffineAutoregressiveTransform(features=2, hidden_features=4))
+        layers.append(transforms.RandomPermutation(features=2))
+    flow = flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([2])).eval()
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.mul_(2.0)
+    x = torch.randn(4096, 2)
+    with torch.no_grad():
+        ref = O.flow_log_prob(flow, x)
+        z_ref, _ = O.transform_apply(flow._transform, x.clone())
+    flow = flow.to(device)
+    with torch.no_grad():
+        assert flow._transform._transforms[0].autoregressive_net.hip_hidden_supported()
+        with ops.KernelTimer("fc_resnet_hidden") as timer:
+            lp = flow.log_prob(x.to(device))
+        assert len(timer.pairs) == 2, "the MADE hidden stacks did not run in fc_resnet_hidden"
+        z, _ = flow._transform(x.to(device))
+        back, _ = flow._transform.inverse(z)
+    assert maxdiff(lp, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert maxdiff(z, z_ref) <= 2e-5 * max(1.0, float(z_ref.abs().max()))
+    assert maxdiff(back, x) <= 1e-4 * max(1.0, float(x.abs().max()))

@@ -112,7 +112,7 @@ def test_flow_loss_backward_step(device):
         loss = -flow.log_prob(x).mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(torch.isfinite(torch.tensor(losses)))
     assert losses[-1] < losses[0]
 
@@ -184,6 +184,6 @@ def test_readme_maf_flow_trains(device):
         loss = -flow.log_prob(x).mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(torch.isfinite(torch.tensor(losses)))
     assert losses[-1] < losses[0]
