@@ -93,8 +93,9 @@ SIGNATURES = {
                             ctypes.POINTER(SplineConfig), _P],
     "fc_rq_spline_fused_linear": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32,
                                   ctypes.POINTER(RQConfig), _P],
-    "fc_resnet_hidden": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P],
-    "fc_resnet_hidden_context": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P],
+    "fc_resnet_hidden": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, ctypes.c_float, _P],
+    "fc_resnet_hidden_context": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32,
+                                 ctypes.c_float, _P],
     "fc_affine": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "fc_dense_mm": [_P, _P, _P, _P, _I64, _I32, _P],
     "fc_sylvester_mm": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],

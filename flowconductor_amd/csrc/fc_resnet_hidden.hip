@@ -54,6 +54,8 @@ struct HiddenArgs {
   const float* wc;        // [blocks][64][C]  context_layer.weight of each block
   const float* bc;        // [blocks][64]
   int C;                  // context features (<= 32), 0 without context
+  int act;                // FC_ACT_* (kAct == 1 kernels only; kAct == 0 is ReLU)
+  float act_param;        // ELU alpha / LeakyReLU negative slope
 };
 
 // feature held by accumulator tile t, register r of a lane in group g
@@ -74,7 +76,8 @@ struct HiddenLds {
   static_assert(kBytes <= 160 * 1024, "weight fragments exceed the CU's LDS");
 };
 
-template <int NB, int K0S, bool kCtx>
+// kAct: 0 = ReLU (the north-star conditioner; nothing but a v_max), 1 = the activation named by a.act
+template <int NB, int K0S, bool kCtx, int kAct>
 __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(HiddenArgs a) {
   using L = HiddenLds<NB, K0S, kCtx>;
   extern __shared__ __attribute__((aligned(16))) unsigned char hsmem[];
@@ -181,6 +184,29 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
   }
   __syncthreads();
 
+  // the blocks' activation (resnet.py:42,46) on a lane's 16 values: ReLU, or what the module was built with (one
+  // uniform switch per site, a straight 16-element loop inside each case)
+  auto activate16 = [&](const f32x4 (&in)[4], f32x4 (&out)[4]) {
+#define FC_ACT_LOOP(expr)                                            \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t)                      \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r) {                    \
+    const float v = in[t][r];                                        \
+    out[t][r] = (expr);                                              \
+  }
+    if constexpr (kAct == 0) {
+      FC_ACT_LOOP(fmaxf(v, 0.f))
+    } else {
+      switch (a.act) {
+        case FC_ACT_TANH: FC_ACT_LOOP(tanhf(v)) break;
+        case FC_ACT_SILU: FC_ACT_LOOP(div_lean(v, 1.f + exp_lean(fminf(-v, 87.f)))) break;          // x * sigmoid(x)
+        case FC_ACT_ELU: FC_ACT_LOOP(v > 0.f ? v : a.act_param * (exp_lean(v) - 1.f)) break;       // ATen: (exp(x) - 1) * alpha
+        case FC_ACT_LEAKY_RELU: FC_ACT_LOOP(v > 0.f ? v : v * a.act_param) break;
+        case FC_ACT_SIGMOID: FC_ACT_LOOP(div_lean(1.f, 1.f + exp_lean(fminf(-v, 87.f)))) break;
+        default: FC_ACT_LOOP(fmaxf(v, 0.f)) break;
+      }
+    }
+#undef FC_ACT_LOOP
+  };
   // B operand of one layer from this lane's 16 activations v[t][r]: scale by the row maximum, split
   auto make_operand = [&](const f32x4 (&v)[4], f16x8 (&bh)[2], f16x8 (&bl)[2]) {
     float m = 0.f;
@@ -307,17 +333,11 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       f32x4 act[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) act[t][r] = fmaxf(h[t][r], 0.f);
+      activate16(h, act);
       un = make_operand(act, bh, bl);
       layer(L::kFrag0 + (2 * b) * L::kFragL, 2, bh, bl, acc);
       finish(1 + 2 * b, un, acc, tmid);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) act[t][r] = fmaxf(tmid[t][r], 0.f);
+      activate16(tmid, act);
       un = make_operand(act, bh, bl);
       layer(L::kFrag0 + (2 * b + 1) * L::kFragL, 2, bh, bl, acc);
       finish(2 + 2 * b, un, acc, tmid);
@@ -346,22 +366,22 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
   }
 }
 
-template <int NB, int K0S, bool kCtx>
+template <int NB, int K0S, bool kCtx, int kAct>
 hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
   using L = HiddenLds<NB, K0S, kCtx>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx, kAct>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S, kCtx>), dim3((unsigned)grid), dim3(kHidThreads), L::kBytes,
+  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S, kCtx, kAct>), dim3((unsigned)grid), dim3(kHidThreads), L::kBytes,
                      s, a);
   return hipGetLastError();
 }
 
-template <bool kCtx>
+template <bool kCtx, int kAct>
 hipError_t dispatch_hidden(const HiddenArgs& a, int num_blocks, hipStream_t s) {
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
@@ -375,19 +395,19 @@ hipError_t dispatch_hidden(const HiddenArgs& a, int num_blocks, hipStream_t s) {
   const int64_t need = (a.blocks16 + 7) / 8;
   if (grid > need) grid = need;
   switch (num_blocks * 2 + (wide ? 1 : 0)) {
-    case 0: return launch_hidden<0, 1, kCtx>(a, grid, s);
-    case 1: return launch_hidden<0, 2, kCtx>(a, grid, s);
-    case 2: return launch_hidden<1, 1, kCtx>(a, grid, s);
-    case 3: return launch_hidden<1, 2, kCtx>(a, grid, s);
-    case 4: return launch_hidden<2, 1, kCtx>(a, grid, s);
-    case 5: return launch_hidden<2, 2, kCtx>(a, grid, s);
-    case 6: return launch_hidden<3, 1, kCtx>(a, grid, s);
-    case 7: return launch_hidden<3, 2, kCtx>(a, grid, s);
+    case 0: return launch_hidden<0, 1, kCtx, kAct>(a, grid, s);
+    case 1: return launch_hidden<0, 2, kCtx, kAct>(a, grid, s);
+    case 2: return launch_hidden<1, 1, kCtx, kAct>(a, grid, s);
+    case 3: return launch_hidden<1, 2, kCtx, kAct>(a, grid, s);
+    case 4: return launch_hidden<2, 1, kCtx, kAct>(a, grid, s);
+    case 5: return launch_hidden<2, 2, kCtx, kAct>(a, grid, s);
+    case 6: return launch_hidden<3, 1, kCtx, kAct>(a, grid, s);
+    case 7: return launch_hidden<3, 2, kCtx, kAct>(a, grid, s);
     default: break;
   }
   if constexpr (!kCtx) {
-    if (wide) return launch_hidden<4, 2, false>(a, grid, s);
-    return launch_hidden<4, 1, false>(a, grid, s);
+    if (wide) return launch_hidden<4, 2, false, kAct>(a, grid, s);
+    return launch_hidden<4, 1, false, kAct>(a, grid, s);
   }
   return hipErrorInvalidValue;
 }
@@ -396,22 +416,28 @@ hipError_t dispatch_hidden(const HiddenArgs& a, int num_blocks, hipStream_t s) {
 
 extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const float* w0,
                                 const float* b0, const float* wb, const float* bb, int64_t n, int32_t d,
-                                int32_t in_features, int32_t hidden, int32_t num_blocks, void* stream) {
+                                int32_t in_features, int32_t hidden, int32_t num_blocks, int32_t activation,
+                                float activation_param, void* stream) {
   if (n < 0 || d <= 0 || hidden != fc::kHid || num_blocks < 0 || num_blocks > 4) return hipErrorInvalidValue;
+  if (activation < FC_ACT_RELU || activation > FC_ACT_SIGMOID) return hipErrorInvalidValue;
   if (in_features <= 0 || in_features > 64 || in_features > d) return hipErrorInvalidValue;
   if (n % 16 != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
   if (!x || !h || !id_cols || !w0 || !b0 || (num_blocks > 0 && (!wb || !bb))) return hipErrorInvalidValue;
   if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)wb & 15u) != 0) return hipErrorInvalidValue;
-  fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, nullptr, nullptr, nullptr, 0};
-  return fc::dispatch_hidden<false>(a, num_blocks, static_cast<hipStream_t>(stream));
+  fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, nullptr, nullptr, nullptr, 0,
+                   activation, activation_param};
+  if (activation == FC_ACT_RELU) return fc::dispatch_hidden<false, 0>(a, num_blocks, static_cast<hipStream_t>(stream));
+  return fc::dispatch_hidden<false, 1>(a, num_blocks, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int fc_resnet_hidden_context(const float* x, const float* context, float* h, const int32_t* id_cols,
                                         const float* w0, const float* b0, const float* wb, const float* bb,
                                         const float* wc, const float* bc, int64_t n, int32_t d,
                                         int32_t in_features, int32_t context_features, int32_t hidden,
-                                        int32_t num_blocks, void* stream) {
+                                        int32_t num_blocks, int32_t activation, float activation_param,
+                                        void* stream) {
+  if (activation < FC_ACT_RELU || activation > FC_ACT_SIGMOID) return hipErrorInvalidValue;
   // 3 blocks: weight fragments of 4 blocks + 4 gate layers would need 168 KB of LDS
   if (n < 0 || d <= 0 || hidden != fc::kHid || num_blocks < 0 || num_blocks > 3) return hipErrorInvalidValue;
   if (in_features <= 0 || in_features > d || context_features <= 0 || context_features > 32 ||
@@ -422,6 +448,8 @@ extern "C" int fc_resnet_hidden_context(const float* x, const float* context, fl
   if (!x || !context || !h || !id_cols || !w0 || !b0 || (num_blocks > 0 && (!wb || !bb || !wc || !bc)))
     return hipErrorInvalidValue;
   if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)wb & 15u) != 0) return hipErrorInvalidValue;
-  fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, context, wc, bc, context_features};
-  return fc::dispatch_hidden<true>(a, num_blocks, static_cast<hipStream_t>(stream));
+  fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, context, wc, bc, context_features,
+                   activation, activation_param};
+  if (activation == FC_ACT_RELU) return fc::dispatch_hidden<true, 0>(a, num_blocks, static_cast<hipStream_t>(stream));
+  return fc::dispatch_hidden<true, 1>(a, num_blocks, static_cast<hipStream_t>(stream));
 }

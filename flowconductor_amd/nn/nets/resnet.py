@@ -79,11 +79,14 @@ class ResidualNet(nn.Module):
     # ---- device fast path for the hidden layers (inference) ------------------------------------------
     def hip_hidden_supported(self, features_total, context=None):
         """True when ``fc_resnet_hidden`` covers this net: hidden <= 64 (narrower nets run zero-padded in the
-        64-wide kernel), <= 4 blocks, ReLU, no batch norm, dropout
+        64-wide kernel), <= 4 blocks, an activation ``ops.activation_code`` knows (ReLU, tanh, SiLU, ELU, LeakyReLU,
+        sigmoid; the same in every block), no batch norm, dropout
         inactive, input width (identity features + context features) <= 64; a context must be a [N, C <= 32] f32
         tensor matching ``context_features`` and allows <= 3 blocks (the gate layers' fragments share the LDS)."""
-        def is_relu(f):
-            return isinstance(f, torch.nn.ReLU) or f is F.relu or f is torch.relu
+        from flowconductor_amd import ops
+
+        def known(f):
+            return ops.activation_code(f) is not None
 
         if self.hidden_features > 64 or len(self.blocks) > 4:
             return False
@@ -102,7 +105,9 @@ class ResidualNet(nn.Module):
         if in_f > 64 or (context is None and in_f > features_total):
             return False
         for block in self.blocks:
-            if block.use_batch_norm or not is_relu(block.activation):
+            if block.use_batch_norm or not known(block.activation):
+                return False
+            if ops.activation_code(block.activation) != ops.activation_code(self.blocks[0].activation):
                 return False
             if block.dropout.p > 0 and self.training:
                 return False
@@ -132,4 +137,5 @@ class ResidualNet(nn.Module):
         if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
             self._hip_packed = (key, ops.pack_resnet_hidden(self))
         in_features = self.initial_layer.in_features - (self.context_features or 0)
-        return ops.resnet_hidden(rows, id_cols, self._hip_packed[1], in_features, len(self.blocks), context)
+        act = ops.activation_code(self.blocks[0].activation) if len(self.blocks) else (ops.ACT_RELU, 0.0)
+        return ops.resnet_hidden(rows, id_cols, self._hip_packed[1], in_features, len(self.blocks), context, act)

@@ -359,8 +359,36 @@ def pack_resnet_hidden(net):
     return w0, b0, wb, bb, wc, bc
 
 
-def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks, context=None):
+ACT_RELU, ACT_TANH, ACT_SILU, ACT_ELU, ACT_LEAKY_RELU, ACT_SIGMOID = range(6)
+
+
+def activation_code(fn):
+    """``(FC_ACT_* code, parameter)`` of an activation callable / module the hidden-layer kernel knows, else None."""
+    import torch.nn as nn
+    from torch.nn import functional as F
+
+    if isinstance(fn, nn.ReLU) or fn in (F.relu, torch.relu):
+        return ACT_RELU, 0.0
+    if isinstance(fn, nn.Tanh) or fn in (torch.tanh, F.tanh):
+        return ACT_TANH, 0.0
+    if isinstance(fn, nn.SiLU) or fn is F.silu:
+        return ACT_SILU, 0.0
+    if isinstance(fn, nn.ELU):
+        return ACT_ELU, float(fn.alpha)
+    if fn is F.elu:
+        return ACT_ELU, 1.0
+    if isinstance(fn, nn.LeakyReLU):
+        return ACT_LEAKY_RELU, float(fn.negative_slope)
+    if fn is F.leaky_relu:
+        return ACT_LEAKY_RELU, 0.01
+    if isinstance(fn, nn.Sigmoid) or fn in (torch.sigmoid, F.sigmoid):
+        return ACT_SIGMOID, 0.0
+    return None
+
+
+def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks, context=None, activation=(ACT_RELU, 0.0)):
     """Hidden layers of the conditioner on the rows of ``inputs`` (multiple of 16 rows) -> h [N, 64].
+    ``activation``: ``activation_code`` of the blocks' activation.
     ``in_features`` = number of identity columns read from ``inputs``; ``context`` [N, C] (C <= 32,
     in_features + C <= 64) enters the initial layer after them and gates every block (``packed`` then carries
     the context layers)."""
@@ -376,7 +404,7 @@ def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks, context=None
     if context is None:
         _call("fc_resnet_hidden", lib.fc_resnet_hidden, x.device, _hip.ptr(x), _hip.ptr(h), _hip.ptr(ids),
               _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(wb), _hip.ptr(bb), n, d, in_features, 64, num_blocks,
-              _hip.stream_ptr(x.device))
+              int(activation[0]), float(activation[1]), _hip.stream_ptr(x.device))
         return h
     wc, bc = packed[4:6]
     c = _prep_2d(context)
@@ -385,7 +413,8 @@ def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks, context=None
         raise ValueError("context rows / width do not match the inputs / the initial layer")
     _call("fc_resnet_hidden_context", lib.fc_resnet_hidden_context, x.device, _hip.ptr(x), _hip.ptr(c), _hip.ptr(h),
           _hip.ptr(ids), _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(wb), _hip.ptr(bb), _hip.ptr(wc), _hip.ptr(bc), n, d,
-          in_features, c.shape[1], 64, num_blocks, _hip.stream_ptr(x.device))
+          in_features, c.shape[1], 64, num_blocks, int(activation[0]), float(activation[1]),
+          _hip.stream_ptr(x.device))
     return h
 
 

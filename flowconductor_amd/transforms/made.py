@@ -168,8 +168,11 @@ class MADE(nn.Module):
     # nn/nets/resnet.py:55-100); with the masks multiplied into the weights once its
     # hidden stack runs in the same kernel, fc_resnet_hidden.
     def hip_hidden_supported(self):
-        def is_relu(f):
-            return isinstance(f, torch.nn.ReLU) or f is F.relu or f is torch.relu
+        from flowconductor_amd import ops
+
+        def is_relu(f):   # any activation the kernel knows, the same one in every block
+            code = ops.activation_code(f)
+            return code is not None and code == ops.activation_code(self.activation)
 
         if (not self.use_residual_blocks or hasattr(self, "context_layer") or len(self.blocks) > 4
                 or self.initial_layer.out_features > 64 or self.initial_layer.in_features > 64
@@ -199,7 +202,7 @@ class MADE(nn.Module):
             ids = torch.arange(self.initial_layer.in_features, dtype=torch.int32, device=rows.device)
             self._hip_packed = (key, (masked[0], biases[0].contiguous(), wb, bb), ids)
         return ops.resnet_hidden(rows, self._hip_packed[2], self._hip_packed[1], self.initial_layer.in_features,
-                                 len(self.blocks))
+                                 len(self.blocks), None, ops.activation_code(self.activation))
 
     def masked_final(self, width=None):
         """(weight * mask [out, width], bias) of the final layer, cached per parameter version; ``width`` = 64 pads

@@ -102,13 +102,22 @@ int fc_rq_spline_backward(const float* x, const float* params, const int32_t* co
  *   h = W0 x[:, id_cols] + b0;  per block: h += W2 relu(W1 relu(h) + b1) + b2          -> h [n, 64]
  * Products on the f16 matrix cores as three-term scaled two-piece splits (f32-GEMM accuracy); a wave carries
  * 16 samples through all layers in registers; the only HBM traffic is x in and h out.
- * Specialised: hidden == 64, num_blocks <= 4, ReLU, no batch norm / active dropout (context: next entry),
+ * `activation` (FC_ACT_*) is the blocks' activation: ReLU kernels carry nothing but a v_max; the others share one
+ * kernel family with a uniform switch (tanh, SiLU, ELU, LeakyReLU, sigmoid as ATen computes them in float32).
+ * Specialised: hidden == 64, num_blocks <= 4, no batch norm / active dropout (context: next entry),
  * in_features <= 64, n % 16 == 0, h 16-byte aligned.
  * Weights are the nn.Linear tensors as they are, row-major f32: w0 [64, in_features]; wb [blocks][2][64][64]
  * (linear_layers[0], linear_layers[1] of each block); b0 [64]; bb [blocks][2][64]. */
+#define FC_ACT_RELU 0
+#define FC_ACT_TANH 1
+#define FC_ACT_SILU 2
+#define FC_ACT_ELU 3        /* activation_param = alpha */
+#define FC_ACT_LEAKY_RELU 4 /* activation_param = negative slope */
+#define FC_ACT_SIGMOID 5
 int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const float* w0,
                      const float* b0, const float* wb, const float* bb, int64_t n, int32_t d,
-                     int32_t in_features, int32_t hidden, int32_t num_blocks, void* stream);
+                     int32_t in_features, int32_t hidden, int32_t num_blocks, int32_t activation,
+                     float activation_param, void* stream);
 
 /* The same with a context (resnet.py:48-49, 94-97): the initial layer sees [x[:, id_cols] | context]
  * (w0 [64, in_features + context_features]) and every block gates its output,
@@ -118,7 +127,8 @@ int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const flo
 int fc_resnet_hidden_context(const float* x, const float* context, float* h, const int32_t* id_cols,
                              const float* w0, const float* b0, const float* wb, const float* bb,
                              const float* wc, const float* bc, int64_t n, int32_t d, int32_t in_features,
-                             int32_t context_features, int32_t hidden, int32_t num_blocks, void* stream);
+                             int32_t context_features, int32_t hidden, int32_t num_blocks,
+                             int32_t activation, float activation_param, void* stream);
 
 /* ---- linear / quadratic / cubic splines ------------------------------------------------------ */
 #define FC_SPLINE_LINEAR 0    /* row per dim: [K pdf]                          (splines/linear.py:38-105) */

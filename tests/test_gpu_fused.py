@@ -133,6 +133,52 @@ def test_fused_flow_narrow_conditioners(hidden_features, n, device, monkeypatch)
     assert maxdiff(lp, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+def _activations():
+    from torch import nn
+    from torch.nn import functional as F
+
+    return {"tanh": torch.tanh, "silu": F.silu, "elu": nn.ELU(alpha=1.3), "leaky_relu": nn.LeakyReLU(0.2),
+            "sigmoid": nn.Sigmoid(), "f_elu": F.elu, "f_leaky_relu": F.leaky_relu, "nn_tanh": nn.Tanh()}
+
+
+@pytest.mark.parametrize("name", ["tanh", "silu", "elu", "leaky_relu", "sigmoid", "f_elu", "f_leaky_relu", "nn_tanh"])
+@pytest.mark.parametrize("blocks,ctx_f", [(1, None), (2, None), (2, 5), (4, None)])
+def test_resnet_hidden_kernel_other_activations(name, blocks, ctx_f, device):
+    """ResidualNets built with tanh / SiLU / ELU / LeakyReLU / sigmoid run in the same kernel family (uniform
+    switch); against the module in float64."""
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(len(name) + blocks)
+    net = nets.ResidualNet(12, 8, hidden_features=64, context_features=ctx_f, num_blocks=blocks,
+                           activation=_activations()[name]).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    n, d = 2048, 30
+    ids = torch.randperm(d)[:12].sort().values
+    x = torch.randn(n, d) * 1.5
+    x[::7] *= 1e-3      # small arguments: tanh / ELU cancellation regions
+    c = None if ctx_f is None else torch.randn(n, ctx_f)
+    with torch.no_grad():
+        ref = copy.deepcopy(net).double().hidden(x.double()[:, ids], None if c is None else c.double())
+        ref32 = net.hidden(x[:, ids], c)
+        net = net.to(device)
+        cd = None if c is None else c.to(device)
+        assert net.hip_hidden_supported(d, cd)
+        got = net.hidden_hip(x.to(device), ids.to(device), cd)
+    assert maxdiff(got, ref) <= 1e-5 * max(1.0, float(ref.abs().max())) + 4 * maxdiff(ref32, ref)
+
+
+def test_resnet_hidden_unknown_activation_stays_on_pytorch(device):
+    from flowconductor_amd.nn import nets
+
+    net = nets.ResidualNet(12, 8, hidden_features=64, activation=torch.nn.Softsign()).to(device).eval()
+    assert not net.hip_hidden_supported(30)
+    mixed = nets.ResidualNet(12, 8, hidden_features=64).to(device).eval()
+    mixed.blocks[1].activation = torch.nn.Tanh()
+    assert not mixed.hip_hidden_supported(30)
+
+
 @pytest.mark.parametrize("xscale", [1e-6, 1.0, 3e5])
 def test_resnet_hidden_kernel_input_scales(xscale, device):
     """Rows far outside the f16 range: the per-row power-of-two scaling keeps the split products at f32-GEMM
