@@ -330,7 +330,7 @@ def main():
                 out["roofline_hidden"] = {"bound": "hbm", "achieved": h_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": h_gbs / HBM_PEAK_GBS,
                                           "traffic": measured_traffic_per_launch("fc_resnet_hidden", rows_per_launch),
-                                          "kernel": "fc_resnet_hidden -> fc::resnet_hidden_kernel<2, 1, false>",
+                                          "kernel": "fc_resnet_hidden -> fc::resnet_hidden_kernel<2, 1, false, 0>",
                                           "launches_timed": len(hidden_ms), "avg_launch_ms": h_avg,
                                           "algorithmic_bytes_per_launch": h_bytes,
                                           "share_of_step": sum(hidden_ms) / (1e3 * elapsed / args.steps),

@@ -48,7 +48,7 @@ def per_launch(counter, key):
 
 summary = {"tag": tag,
            "source": "tools/profile_bench.sh %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of "
-                     "bench.py --steps 3 --warmup 1, per-launch means over the full-batch (2^20-row) launches; "
+                     "bench.py --steps 3 --warmup 3, per-launch means over the full-batch (2^20-row) launches; "
                      "FETCH_SIZE x2 (gfx950 wide-stream correction), KiB -> bytes" % tag}
 for entry, key in KERNELS.items():
     fetch_kib, nf = per_launch("FETCH_SIZE", key)
@@ -61,3 +61,25 @@ for entry, key in KERNELS.items():
                       "traffic_bytes_per_launch": rd + wr, "expected": EXPECTED[entry]}
 json.dump(summary, open(os.path.join(prof, "%s_hbm_traffic.json" % tag), "w"), indent=1)
 print(json.dumps(summary))
+
+# Per-step launch durations of the two hot kernels from the kernel trace (full-batch launches in launch order, 32
+# per pass through the flow).  `--stats` averages every call of a kernel -- warm-up steps and the 2 048-row parity
+# launches included -- while bench.py brackets the launches of the LAST timed step with HIP events: this table is the
+# like-for-like cross-check of `roofline.avg_launch_ms` in the bench line of the same run.
+traces = glob.glob(os.path.join(out, "trace", "*", "*kernel_trace.csv"))
+if traces:
+    rows = list(csv.DictReader(open(traces[0])))
+    per_step = {"source": "rocprofv3 --kernel-trace of the profiled bench.py run (%s_bench_n1_under_rocprof.json); "
+                          "microseconds; passes in launch order: warm-up steps, timed steps (the last one carries "
+                          "bench.py's HIP-event pairs), then the untimed FC_FUSED=0 pass (hidden kernel only)" % tag}
+    for entry in ("fc_rq_spline_fused_linear", "fc_resnet_hidden"):
+        sel = [r for r in rows if KERNELS[entry] in r["Kernel_Name"]]
+        sel.sort(key=lambda r: int(r["Start_Timestamp"]))
+        big = max(int(r["Grid_Size_X"]) for r in sel)
+        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in sel if int(r["Grid_Size_X"]) == big]
+        per_step[entry] = [{"pass": i // 32, "launches": len(dur[i:i + 32]),
+                            "avg_us": round(sum(dur[i:i + 32]) / len(dur[i:i + 32]), 1),
+                            "min_us": round(min(dur[i:i + 32]), 1), "max_us": round(max(dur[i:i + 32]), 1)}
+                           for i in range(0, len(dur), 32)]
+    json.dump(per_step, open(os.path.join(prof, "%s_per_step_launch_us.json" % tag), "w"), indent=1)
+    print(json.dumps(per_step))
