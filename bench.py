@@ -210,7 +210,9 @@ def main():
     torch.set_num_threads(host_cores())
     log("rank %d/%d on %s: %d samples/GPU, host cores %d" % (rank, world, torch.cuda.get_device_name(device),
                                                              n_local, host_cores()))
-    for _ in range(args.warmup):
+    # Steady state is the metric: the first two passes of a process run ~10 % slower (allocator growth,
+    # clock ramp -- profiles/r01h_per_step_launch_us.json), so two set-up passes precede the W warm-up steps.
+    for _ in range(2 + args.warmup):
         step()
     log("warm-up done")
     torch.cuda.synchronize(device)
