@@ -574,7 +574,7 @@ def _standard_normal_log_prob_nograd(noise, log_z, add=None):
     z = _hip.dev_f32(noise, "inputs")
     _hip.require_no_grad(noise, add)
     n = z.shape[0]
-    z2 = z.reshape(n, -1)
+    z2 = z.flatten(1) if z.dim() > 1 else z.reshape(n, 1)
     if add is not None:
         add = _hip.dev_f32(add, "logabsdet")
         if add.numel() != n:
