@@ -694,7 +694,7 @@ def batchnorm_eval(inputs, mean, std, weight, bias, inverse=False):
     lib = _hip.load()
     x = _hip.dev_f32(inputs, "inputs")
     _hip.require_no_grad(inputs)
-    n, m = x.shape[0], x[0].numel()
+    n, m = x.shape[0], int(np.prod(x.shape[1:]))
     vecs = [_hip.dev_f32(v.detach().reshape(-1), "batch-norm statistic") for v in (std, bias, mean, weight)]
     for v in vecs:
         if v.numel() != m:

@@ -145,7 +145,7 @@ class CompositeCDFTransform(CompositeTransform):
 
 def _flatten_items(inputs):
     """[N, *shape] -> [N, prod(shape)] view for the [N, D] kernels."""
-    return inputs.reshape(inputs.shape[0], -1)
+    return inputs.flatten(1) if inputs.dim() > 1 else inputs.reshape(-1, 1)
 
 
 class PiecewiseRationalQuadraticCDF(Transform):

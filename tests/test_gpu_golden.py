@@ -124,3 +124,33 @@ def test_rq_no_tails_raises_outside_domain(device):
     # the error word is cleared: a valid call afterwards succeeds
     with torch.no_grad():
         t(torch.rand(16, 6, device=device))
+
+
+@pytest.mark.parametrize("name", sorted(cases.CASES))
+def test_every_case_takes_empty_and_single_row_batches(name, device):
+    """N = 0 and N = 1 through every transform of the golden set (forward, and inverse where there is one): shapes are
+    kept, nothing launches on an empty grid, the single row equals the first row of the size-7 golden batch."""
+    g = golden(name)
+    t, spec = build_case(name, g)
+    t = t.to(device)
+    x7 = torch.from_numpy(g["x_7"]).to(device)
+    c7 = torch.from_numpy(g["ctx_7"]).to(device) if spec["context"] else None
+    for n in (0, 1):
+        x = x7[:n].contiguous()
+        ctx = None if c7 is None else c7[:n].contiguous()
+        with torch.no_grad():
+            y, lad = t(x, ctx)
+        if n == 1 and name in ("cond_orthogonal_d5", "cond_svd_d4"):
+            y = y.reshape(x.shape)      # like the reference (`outputs.squeeze()`, conditional.py:439,517) these drop
+                                        # the batch axis of a single row
+        assert y.shape == x.shape and lad.shape == (n,), (name, n)
+        if n == 1 and "batchnorm" not in name and "actnorm" not in name:
+            with torch.no_grad():
+                y_full, lad_full = t(x7, c7)
+            assert maxdiff(y, y_full[:1]) <= 1e-5 * max(1.0, float(y_full.abs().max())), name
+            assert maxdiff(lad, lad_full[:1]) <= 1e-4 * max(1.0, float(lad_full.abs().max())), name
+        if spec["inverse"]:
+            yin = torch.from_numpy(g["yin_7"]).to(device)[:n].contiguous()
+            with torch.no_grad():
+                xi, ladi = t.inverse(yin, ctx)
+            assert xi.numel() == yin.numel() and ladi.shape == (n,), (name, n)
