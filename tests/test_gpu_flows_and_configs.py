@@ -292,3 +292,33 @@ def test_empty_and_tiny_batches_through_every_fast_path(n, device):
         if n:
             assert maxdiff(lp, ref) <= 3e-5 * max(1.0, float(ref.abs().max())), name
             assert maxdiff(back, x) <= 2e-4 * max(1.0, float(x.abs().max())), name
+
+
+def test_strided_inputs_and_contexts(device):
+    """Non-contiguous views (every other column of a wider tensor, a transposed buffer, an expanded context) give
+    the results of their contiguous copies on every fast path."""
+    torch.manual_seed(9)
+    d, ctx_f, n = 16, 4, 1000
+
+    def cnet(i, o):
+        return nets.ResidualNet(i, o, hidden_features=64, context_features=ctx_f, num_blocks=2)
+
+    mask = utils.create_alternating_binary_mask(d)
+    stack = T.CompositeTransform([
+        T.PiecewiseRationalQuadraticCouplingTransform(mask, cnet, num_bins=8, tails="linear", tail_bound=3.0),
+        T.AffineCouplingTransform(mask, cnet), T.RandomPermutation(d),
+        T.MaskedAffineAutoregressiveTransform(d, 64, context_features=ctx_f)]).to(device).eval()
+    wide = torch.randn(n, 2 * d, device=device)
+    x_view = wide[:, ::2]
+    x_t = torch.randn(d, n, device=device).t()
+    c_row = torch.randn(1, ctx_f, device=device)
+    with torch.no_grad():
+        for x in (x_view, x_t):
+            assert not x.is_contiguous()
+            for c in (c_row.expand(n, ctx_f), torch.randn(n, 2 * ctx_f, device=device)[:, ::2]):
+                assert not c.is_contiguous()
+                y, lad = stack(x, c)
+                y_ref, lad_ref = stack(x.contiguous(), c.contiguous())
+                assert torch.equal(y, y_ref) and torch.equal(lad, lad_ref)
+                back, _ = stack.inverse(y[:, :], c)
+                assert maxdiff(back, x) <= 2e-4 * max(1.0, float(x.abs().max()))
