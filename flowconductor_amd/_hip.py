@@ -95,7 +95,7 @@ SIGNATURES = {
                                   ctypes.POINTER(RQConfig), _P],
     "fc_resnet_hidden": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, ctypes.c_float, _P],
     "fc_resnet_hidden_context": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32,
-                                 ctypes.c_float, _P],
+                                 _I32, ctypes.c_float, _P],
     "fc_affine": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "fc_dense_mm": [_P, _P, _P, _P, _I64, _I32, _P],
     "fc_sylvester_mm": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],

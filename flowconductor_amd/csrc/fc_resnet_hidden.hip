@@ -9,10 +9,13 @@
 //  state_dict, CPU execution); this kernel is the device fast path for its inference forward when
 //  the shapes match: hidden = 64, <= 4 blocks, ReLU, <= 64 input features.
 //
-// With a context (resnet.py:48-49, 94-97; kCtx): the initial layer sees [x_id | context] and every block gates
+// With a context (resnet.py:48-49, 94-97; kCtx = 1): the initial layer sees [x_id | context] and every block gates
 // its output,  h += (W2 relu(W1 relu(h) + b1) + b2) * sigmoid(Wc context + bc)   (F.glu of the concatenation).
 // The context row is one more B operand (<= 32 features: one k-step), split once per 16-sample block and used by
 // the gate product of every residual block (12 MFMAs each).
+// kCtx = 2 is the MADE form (made.py:100-140, 239-246): the context enters additively,
+//   h = W0 x + b0 + act(Wc0 c + bc0);   per block:  h += W2 act(W1 act(h) + b1 + Wc c + bc) + b2
+// (the same context operand, one more context product for the initial layer).
 //
 // Every product runs as three v_mfma_f32_16x16x32_f16 terms on scaled two-piece f16 splits of both
 // operands (fc_split.h): f32-GEMM accuracy at 3/16 of the f32-MFMA cycles.
@@ -62,22 +65,23 @@ struct HiddenArgs {
 __host__ __device__ constexpr int hid_feat(int t, int g, int r) { return 32 * (t >> 1) + 8 * g + 4 * (t & 1) + r; }
 
 // LDS: [layer][k-step][tile][piece][lane] f16x8 fragments, then bias [layer][g][16], unscale [layer], ids
-template <int NB, int K0S, bool kCtx>
+template <int NB, int K0S, int kCtx>
 struct HiddenLds {
   static constexpr int kMain = 1 + 2 * NB;                // initial layer + two per block
-  static constexpr int kLayers = kMain + (kCtx ? NB : 0); // + one gate layer per block
+  static constexpr int kCtxLayers = kCtx == 1 ? NB : kCtx == 2 ? NB + 1 : 0;   // context products: per block (+ initial)
+  static constexpr int kLayers = kMain + kCtxLayers;
   static constexpr int kFrag0 = K0S * 4 * 2;              // fragments of the initial layer
   static constexpr int kFragL = 2 * 4 * 2;                // fragments of a 64 x 64 layer
   static constexpr int kFragG = 1 * 4 * 2;                // fragments of a 64 x C gate layer (C <= 32)
   static constexpr int kFragsMain = kFrag0 + 2 * NB * kFragL;
-  static constexpr int kFrags = kFragsMain + (kCtx ? NB * kFragG : 0);
+  static constexpr int kFrags = kFragsMain + kCtxLayers * kFragG;
   static constexpr size_t kBytes = (size_t)kFrags * 64 * 16 + kLayers * 64 * 4 + 16 * 4 + 32 * K0S * 4 + 16 * 8 * 4;
   static_assert(kLayers <= 16, "wun holds 16 entries");
   static_assert(kBytes <= 160 * 1024, "weight fragments exceed the CU's LDS");
 };
 
 // kAct: 0 = ReLU (the north-star conditioner; nothing but a v_max), 1 = the activation named by a.act
-template <int NB, int K0S, bool kCtx, int kAct>
+template <int NB, int K0S, int kCtx, int kAct>
 __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(HiddenArgs a) {
   using L = HiddenLds<NB, K0S, kCtx>;
   extern __shared__ __attribute__((aligned(16))) unsigned char hsmem[];
@@ -93,14 +97,15 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
 
   // ---- once per workgroup: scale, split and lay out the weights -----------------------------------
   // operand column i of the initial layer: identity column of x (>= 0), context feature -2 - j, or padding (-1)
-  for (int i = tid; i < 32 * K0S; i += kHidThreads) ids[i] = i < k0 ? a.id_cols[i] : (i < k0 + C ? -2 - (i - k0) : -1);
+  const int C0 = kCtx == 1 ? C : 0;   // context features concatenated into the initial layer (ResidualNet form only)
+  for (int i = tid; i < 32 * K0S; i += kHidThreads) ids[i] = i < k0 ? a.id_cols[i] : (i < k0 + C0 ? -2 - (i - k0) : -1);
   // Two rounds of global loads for ALL layers together (maxima, then fragments) with one barrier pair between them:
   // layer by layer the dependent load latencies and barriers of 5-13 layers cost ~15 us per launch.
   auto layer_src = [&](int l, const float*& w, const float*& b, int& kin, int& nks, int& base) {
     const bool gate = l >= L::kMain;
     w = l == 0 ? a.w0 : gate ? a.wc + (size_t)(l - L::kMain) * kHid * C : a.wb + (size_t)(l - 1) * kHid * kHid;
     b = l == 0 ? a.b0 : gate ? a.bc + (size_t)(l - L::kMain) * kHid : a.bb + (size_t)(l - 1) * kHid;
-    kin = l == 0 ? k0 + C : gate ? C : kHid;
+    kin = l == 0 ? k0 + C0 : gate ? C : kHid;
     nks = l == 0 ? K0S : gate ? 1 : 2;
     base = l == 0 ? 0 : gate ? L::kFragsMain + (l - L::kMain) * L::kFragG : L::kFrag0 + (l - 1) * L::kFragL;
   };
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
         float v = 0.f;
         if (ks < K0S) {
           const int c = mycol[ks < K0S ? ks : 0][j];
-          if constexpr (kCtx)
+          if constexpr (kCtx == 1)
             v = c >= 0 ? xrow[c] : (c <= -2 ? crow[-2 - c] : 0.f);
           else
             v = c >= 0 ? xrow[c] : 0.f;
@@ -330,6 +335,17 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
     float un = make_operand(xin, bh, bl);
     layer(0, K0S, bh, bl, acc);
     finish(0, un, acc, h);
+    if constexpr (kCtx == 2) {
+      // made.py:243-244: temps = initial_layer(inputs) + activation(context_layer(context))
+      f32x4 cpre[4], cact[4];
+      layer(L::kFragsMain, 1, ch, cl, acc);
+      finish(L::kMain, unc, acc, cpre);
+      activate16(cpre, cact);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][r] += cact[t][r];
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       f32x4 act[4];
@@ -337,11 +353,21 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
       un = make_operand(act, bh, bl);
       layer(L::kFrag0 + (2 * b) * L::kFragL, 2, bh, bl, acc);
       finish(1 + 2 * b, un, acc, tmid);
+      if constexpr (kCtx == 2) {
+        // made.py:131-132: temps = linear_layers[0](...) + context_layer(context)
+        f32x4 cpre[4];
+        layer(L::kFragsMain + (1 + b) * L::kFragG, 1, ch, cl, acc);
+        finish(L::kMain + 1 + b, unc, acc, cpre);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tmid[t][r] += cpre[t][r];
+      }
       activate16(tmid, act);
       un = make_operand(act, bh, bl);
       layer(L::kFrag0 + (2 * b + 1) * L::kFragL, 2, bh, bl, acc);
       finish(2 + 2 * b, un, acc, tmid);
-      if constexpr (kCtx) {
+      if constexpr (kCtx == 1) {
         // resnet.py:48-49: temps = glu(cat(temps, context_layer(context))) = temps * sigmoid(Wc c + bc)
         f32x4 gpre[4];
         layer(L::kFragsMain + b * L::kFragG, 1, ch, cl, acc);
@@ -366,7 +392,7 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
   }
 }
 
-template <int NB, int K0S, bool kCtx, int kAct>
+template <int NB, int K0S, int kCtx, int kAct>
 hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
   using L = HiddenLds<NB, K0S, kCtx>;
   static bool attr_set = false;
@@ -381,7 +407,7 @@ hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <bool kCtx, int kAct>
+template <int kCtx, int kAct>
 hipError_t dispatch_hidden(const HiddenArgs& a, int num_blocks, hipStream_t s) {
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
@@ -389,7 +415,7 @@ hipError_t dispatch_hidden(const HiddenArgs& a, int num_blocks, hipStream_t s) {
     cus = prop.multiProcessorCount;
   // two 512-thread workgroups per CU when two weight images fit in LDS (<= 2 blocks at <= 32 inputs, no
   // context), else one
-  const bool wide = a.k0 + a.C > 32;
+  const bool wide = a.k0 + (kCtx == 1 ? a.C : 0) > 32;
   const size_t frags = (size_t)(wide ? 16 : 8) + (size_t)num_blocks * (2 * 16 + (kCtx ? 8 : 0));   // 1 KB each
   int64_t grid = (int64_t)cus * (!kCtx && frags * 1024 + 2048 <= 80 * 1024 ? 2 : 1);
   const int64_t need = (a.blocks16 + 7) / 8;
@@ -406,8 +432,8 @@ hipError_t dispatch_hidden(const HiddenArgs& a, int num_blocks, hipStream_t s) {
     default: break;
   }
   if constexpr (!kCtx) {
-    if (wide) return launch_hidden<4, 2, false, kAct>(a, grid, s);
-    return launch_hidden<4, 1, false, kAct>(a, grid, s);
+    if (wide) return launch_hidden<4, 2, 0, kAct>(a, grid, s);
+    return launch_hidden<4, 1, 0, kAct>(a, grid, s);
   }
   return hipErrorInvalidValue;
 }
@@ -427,29 +453,33 @@ extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols
   if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)wb & 15u) != 0) return hipErrorInvalidValue;
   fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, nullptr, nullptr, nullptr, 0,
                    activation, activation_param};
-  if (activation == FC_ACT_RELU) return fc::dispatch_hidden<false, 0>(a, num_blocks, static_cast<hipStream_t>(stream));
-  return fc::dispatch_hidden<false, 1>(a, num_blocks, static_cast<hipStream_t>(stream));
+  if (activation == FC_ACT_RELU) return fc::dispatch_hidden<0, 0>(a, num_blocks, static_cast<hipStream_t>(stream));
+  return fc::dispatch_hidden<0, 1>(a, num_blocks, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int fc_resnet_hidden_context(const float* x, const float* context, float* h, const int32_t* id_cols,
                                         const float* w0, const float* b0, const float* wb, const float* bb,
                                         const float* wc, const float* bc, int64_t n, int32_t d,
                                         int32_t in_features, int32_t context_features, int32_t hidden,
-                                        int32_t num_blocks, int32_t activation, float activation_param,
-                                        void* stream) {
+                                        int32_t num_blocks, int32_t context_mode, int32_t activation,
+                                        float activation_param, void* stream) {
   if (activation < FC_ACT_RELU || activation > FC_ACT_SIGMOID) return hipErrorInvalidValue;
+  if (context_mode != FC_CONTEXT_GLU && context_mode != FC_CONTEXT_ADDITIVE) return hipErrorInvalidValue;
   // 3 blocks: weight fragments of 4 blocks + 4 gate layers would need 168 KB of LDS
   if (n < 0 || d <= 0 || hidden != fc::kHid || num_blocks < 0 || num_blocks > 3) return hipErrorInvalidValue;
   if (in_features <= 0 || in_features > d || context_features <= 0 || context_features > 32 ||
-      in_features + context_features > 64)
+      in_features + (context_mode == FC_CONTEXT_GLU ? context_features : 0) > 64)
     return hipErrorInvalidValue;
   if (n % 16 != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
   if (!x || !context || !h || !id_cols || !w0 || !b0 || (num_blocks > 0 && (!wb || !bb || !wc || !bc)))
     return hipErrorInvalidValue;
+  if (context_mode == FC_CONTEXT_ADDITIVE && (!wc || !bc)) return hipErrorInvalidValue;
   if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)wb & 15u) != 0) return hipErrorInvalidValue;
   fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, context, wc, bc, context_features,
                    activation, activation_param};
-  if (activation == FC_ACT_RELU) return fc::dispatch_hidden<true, 0>(a, num_blocks, static_cast<hipStream_t>(stream));
-  return fc::dispatch_hidden<true, 1>(a, num_blocks, static_cast<hipStream_t>(stream));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (context_mode == FC_CONTEXT_GLU)
+    return activation == FC_ACT_RELU ? fc::dispatch_hidden<1, 0>(a, num_blocks, s) : fc::dispatch_hidden<1, 1>(a, num_blocks, s);
+  return activation == FC_ACT_RELU ? fc::dispatch_hidden<2, 0>(a, num_blocks, s) : fc::dispatch_hidden<2, 1>(a, num_blocks, s);
 }

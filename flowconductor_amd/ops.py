@@ -386,9 +386,15 @@ def activation_code(fn):
     return None
 
 
-def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks, context=None, activation=(ACT_RELU, 0.0)):
+CONTEXT_GLU, CONTEXT_ADDITIVE = 1, 2
+
+
+def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks, context=None, activation=(ACT_RELU, 0.0),
+                  context_mode=CONTEXT_GLU):
     """Hidden layers of the conditioner on the rows of ``inputs`` (multiple of 16 rows) -> h [N, 64].
-    ``activation``: ``activation_code`` of the blocks' activation.
+    ``activation``: ``activation_code`` of the blocks' activation.  ``context_mode``: ``CONTEXT_GLU`` (ResidualNet:
+    concatenated into the initial layer, GLU gate per block) or ``CONTEXT_ADDITIVE`` (MADE: added after the initial
+    layer through the activation and inside every block; ``packed`` then carries ``blocks + 1`` context layers).
     ``in_features`` = number of identity columns read from ``inputs``; ``context`` [N, C] (C <= 32,
     in_features + C <= 64) enters the initial layer after them and gates every block (``packed`` then carries
     the context layers)."""
@@ -409,11 +415,11 @@ def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks, context=None
     wc, bc = packed[4:6]
     c = _prep_2d(context)
     _hip.require_no_grad(context)
-    if c.shape[0] != n or w0.shape[1] != in_features + c.shape[1]:
+    if c.shape[0] != n or w0.shape[1] != in_features + (c.shape[1] if context_mode == CONTEXT_GLU else 0):
         raise ValueError("context rows / width do not match the inputs / the initial layer")
     _call("fc_resnet_hidden_context", lib.fc_resnet_hidden_context, x.device, _hip.ptr(x), _hip.ptr(c), _hip.ptr(h),
           _hip.ptr(ids), _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(wb), _hip.ptr(bb), _hip.ptr(wc), _hip.ptr(bc), n, d,
-          in_features, c.shape[1], 64, num_blocks, int(activation[0]), float(activation[1]),
+          in_features, c.shape[1], 64, num_blocks, int(context_mode), int(activation[0]), float(activation[1]),
           _hip.stream_ptr(x.device))
     return h
 

@@ -28,20 +28,20 @@ class AutoregressiveTransform(Transform):
     def _hidden(self, inputs, context):
         """Everything before the conditioner's final layer, or None when the net is not a MADE-like module with
         ``hidden`` / ``final_layer``.  A MADE whose hidden stack ``fc_resnet_hidden`` covers (hidden <= 64, residual
-        blocks, ReLU, no context) runs it there on pre-masked weights -- inference only; the result then has the
+        blocks, a known activation, optionally an additive context) runs it there on pre-masked weights -- inference only; the result then has the
         kernel's 64 columns (zeros beyond a narrower MADE's width; ``_final`` accounts for them)."""
         net = self.autoregressive_net
         if not (hasattr(net, "hidden") and hasattr(net, "final_layer")):
             return None
         n = inputs.shape[0]
-        if (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+        if (inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
                 and n >= ops.HIDDEN_ROWS and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
-                and getattr(net, "hip_hidden_supported", None) is not None and net.hip_hidden_supported()
+                and getattr(net, "hip_hidden_supported", None) is not None and net.hip_hidden_supported(context)
                 and not self._needs_grad(inputs)):
             body = n - n % ops.HIDDEN_ROWS
-            hidden = net.hidden_hip(inputs[:body].contiguous())
+            hidden = net.hidden_hip(inputs[:body].contiguous(), None if context is None else context[:body])
             if body < n:
-                tail = net.hidden(inputs[body:])
+                tail = net.hidden(inputs[body:], None if context is None else context[body:])
                 if tail.shape[1] != hidden.shape[1]:
                     tail = F.pad(tail, (0, hidden.shape[1] - tail.shape[1]))
                 hidden = torch.cat((hidden, tail))

@@ -167,31 +167,42 @@ class MADE(nn.Module):
     # With residual blocks a MADE has exactly the layer structure of the ResidualNet (made.py:205-283 vs
     # nn/nets/resnet.py:55-100); with the masks multiplied into the weights once its
     # hidden stack runs in the same kernel, fc_resnet_hidden.
-    def hip_hidden_supported(self):
+    def hip_hidden_supported(self, context=None):
+        """``fc_resnet_hidden`` covers this MADE: residual blocks, hidden <= 64, <= 4 blocks (<= 3 with a context),
+        <= 64 inputs, a known activation, no batch norm, dropout inactive; a context must be a [N, C <= 32] f32
+        device tensor matching ``context_features``."""
         from flowconductor_amd import ops
 
         def is_relu(f):   # any activation the kernel knows, the same one in every block
             code = ops.activation_code(f)
             return code is not None and code == ops.activation_code(self.activation)
 
-        if (not self.use_residual_blocks or hasattr(self, "context_layer") or len(self.blocks) > 4
+        has_ctx = hasattr(self, "context_layer")
+        if (not self.use_residual_blocks or has_ctx != (context is not None) or len(self.blocks) > (3 if has_ctx else 4)
                 or self.initial_layer.out_features > 64 or self.initial_layer.in_features > 64
                 or not is_relu(self.activation)):
             return False
+        if has_ctx:
+            c = self.context_layer.in_features
+            if (context.dim() != 2 or context.shape[1] != c or c > 32 or context.dtype != torch.float32
+                    or not context.is_cuda or context.requires_grad and torch.is_grad_enabled()):
+                return False
         for block in self.blocks:
-            if block.use_batch_norm or not is_relu(block.activation) or hasattr(block, "context_layer"):
+            if block.use_batch_norm or not is_relu(block.activation) or hasattr(block, "context_layer") != has_ctx:
                 return False
             if block.dropout.p > 0 and self.training:
                 return False
         return True
 
-    def hidden_hip(self, rows):
+    def hidden_hip(self, rows, context=None):
         """h [N, 64] of ``rows`` [N, features] (N a multiple of 16) by ``fc_resnet_hidden`` on pre-masked weights; a
-        narrower MADE runs zero-padded (columns ``hidden_features``.. of the result are zero)."""
+        narrower MADE runs zero-padded (columns ``hidden_features``.. of the result are zero).  ``context`` [N, C]:
+        the additive form of made.py:100-140, 239-246."""
         from flowconductor_amd import ops
 
         layers = [self.initial_layer] + [lin for block in self.blocks for lin in block.linear_layers]
-        key = tuple((lin.weight._version, lin.bias._version, lin.weight.data_ptr()) for lin in layers)
+        ctx_layers = ([self.context_layer] + [block.context_layer for block in self.blocks]) if context is not None else []
+        key = tuple((lin.weight._version, lin.bias._version, lin.weight.data_ptr()) for lin in layers + ctx_layers)
         if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
             hw = ops.FUSED_HIDDEN
             masked = [ops._pad_to((lin.weight * lin.mask).detach(), (hw, lin.in_features if i == 0 else hw))
@@ -199,10 +210,15 @@ class MADE(nn.Module):
             biases = [ops._pad_to(lin.bias.detach(), (hw,)) for lin in layers]
             wb = torch.stack(masked[1:]).contiguous() if len(masked) > 1 else None
             bb = torch.stack(biases[1:]).contiguous() if len(biases) > 1 else None
+            wc = bc = None
+            if ctx_layers:
+                wc = torch.stack([ops._pad_to(cl.weight.detach(), (hw, cl.in_features)) for cl in ctx_layers]).contiguous()
+                bc = torch.stack([ops._pad_to(cl.bias.detach(), (hw,)) for cl in ctx_layers]).contiguous()
             ids = torch.arange(self.initial_layer.in_features, dtype=torch.int32, device=rows.device)
-            self._hip_packed = (key, (masked[0], biases[0].contiguous(), wb, bb), ids)
+            self._hip_packed = (key, (masked[0], biases[0].contiguous(), wb, bb, wc, bc), ids)
         return ops.resnet_hidden(rows, self._hip_packed[2], self._hip_packed[1], self.initial_layer.in_features,
-                                 len(self.blocks), None, ops.activation_code(self.activation))
+                                 len(self.blocks), context, ops.activation_code(self.activation),
+                                 ops.CONTEXT_ADDITIVE)
 
     def masked_final(self, width=None):
         """(weight * mask [out, width], bias) of the final layer, cached per parameter version; ``width`` = 64 pads

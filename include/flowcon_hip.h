@@ -124,10 +124,14 @@ int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const flo
  *   h += (W2 relu(W1 relu(h) + b1) + b2) * sigmoid(Wc context + bc)      (F.glu of the concatenation),
  * wc [blocks][64][context_features] / bc [blocks][64] = blocks[i].context_layer.  context [n, context_features]
  * row-major; context_features <= 32, in_features + context_features <= 64, num_blocks <= 3. */
+#define FC_CONTEXT_GLU 1      /* ResidualNet: as above */
+#define FC_CONTEXT_ADDITIVE 2 /* MADE (transforms/made.py:100-140, 239-246): w0 [64, in_features] only;
+                                 h = W0 x + b0 + act(Wc[0] c + bc[0]); per block h += W2 act(W1 act(h) + b1 + Wc[1+i] c
+                                 + bc[1+i]) + b2;  wc [blocks + 1][64][context_features], bc [blocks + 1][64] */
 int fc_resnet_hidden_context(const float* x, const float* context, float* h, const int32_t* id_cols,
                              const float* w0, const float* b0, const float* wb, const float* bb,
                              const float* wc, const float* bc, int64_t n, int32_t d, int32_t in_features,
-                             int32_t context_features, int32_t hidden, int32_t num_blocks,
+                             int32_t context_features, int32_t hidden, int32_t num_blocks, int32_t context_mode,
                              int32_t activation, float activation_param, void* stream);
 
 /* ---- linear / quadratic / cubic splines ------------------------------------------------------ */

@@ -99,3 +99,79 @@ def test_conditional_coupling_flow(kind, n, device, monkeypatch):
     assert maxdiff(got, ref) <= tol
     assert maxdiff(got, got_torch) <= tol
     assert maxdiff(back, x) <= 2e-4 * max(1.0, float(x.abs().max()))
+
+
+@pytest.mark.parametrize("features,hidden,ctx_f,blocks,act", [(12, 64, 5, 2, "relu"), (6, 32, 1, 3, "relu"),
+                                                              (40, 50, 32, 1, "tanh"), (3, 16, 7, 0, "relu"),
+                                                              (64, 64, 8, 2, "silu")])
+def test_made_hidden_stack_with_additive_context(features, hidden, ctx_f, blocks, act, device):
+    """Conditional MADE (made.py:100-140, 239-246: context added after the initial layer through the activation and
+    inside every residual block) on fc_resnet_hidden_context in its additive mode; against the module in float64."""
+    from torch.nn import functional as F
+
+    from flowconductor_amd.transforms import made
+
+    torch.manual_seed(features + ctx_f)
+    fn = {"relu": F.relu, "tanh": torch.tanh, "silu": F.silu}[act]
+    net = made.MADE(features, hidden, context_features=ctx_f, num_blocks=blocks, output_multiplier=2,
+                    activation=fn).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    n = 2048
+    x = torch.randn(n, features)
+    c = torch.randn(n, ctx_f) * 1.5
+    with torch.no_grad():
+        ref = copy.deepcopy(net).double().hidden(x.double(), c.double())
+        ref32 = net.hidden(x, c)
+        net = net.to(device)
+        assert net.hip_hidden_supported(c.to(device))
+        assert not net.hip_hidden_supported(None)
+        with ops.KernelTimer("fc_resnet_hidden_context") as timer:
+            got = net.hidden_hip(x.to(device), c.to(device))
+        assert len(timer.pairs) == 1
+    assert got.shape == (n, 64) and float(got[:, hidden:].abs().max() if hidden < 64 else 0.0) == 0.0
+    assert maxdiff(got[:, :hidden], ref) <= 1e-5 * max(1.0, float(ref.abs().max())) + 4 * maxdiff(ref32, ref)
+
+
+@pytest.mark.parametrize("kind", ["maf", "rq_ar"])
+def test_conditional_autoregressive_flow(kind, device, monkeypatch):
+    """log_prob(x | c) and the sampling direction of a conditional MAF / RQ-AR flow: MADE hidden stacks with the
+    additive context in the kernel, against the oracle and the PyTorch conditioner."""
+    from flowconductor_amd import distributions, flows, transforms
+
+    torch.manual_seed(17)
+    d, ctx_f, n = 6, 4, 1000
+    layers = []
+    for _ in range(2):
+        if kind == "maf":
+            layers.append(transforms.MaskedAffineAutoregressiveTransform(d, 48, context_features=ctx_f))
+        else:
+            layers.append(transforms.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+                d, 64, context_features=ctx_f, num_bins=8, tails="linear", tail_bound=3.0))
+        layers.append(transforms.ReversePermutation(d))
+    flow = flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([d])).eval()
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.mul_(1.5)
+    x = torch.randn(n, d) * 1.2
+    c = torch.randn(n, ctx_f)
+    with torch.no_grad():
+        ref = O.flow_log_prob(flow, x, c)
+        # autoregressive inverses through steep splines amplify rounding: the oracle's own float32 round trip sets
+        # the scale for the round-trip check below
+        z_ref, _ = O.transform_apply(flow._transform, x.clone(), c)
+        back_ref, _ = O.transform_apply(flow._transform, z_ref, c, inverse=True)
+        floor = maxdiff(back_ref, x)
+    flow = flow.to(device)
+    with torch.no_grad():
+        with ops.KernelTimer("fc_resnet_hidden_context") as timer:
+            got = flow.log_prob(x.to(device), c.to(device))
+        assert len(timer.pairs) == 2, "the MADE hidden stacks did not run in the kernel"
+        z, _ = flow._transform(x.to(device), c.to(device))
+        back, _ = flow._transform.inverse(z, c.to(device))
+        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        got_torch = flow.log_prob(x.to(device), c.to(device))
+    tol = 3e-4 * max(1.0, float(ref.abs().max()) / 10)
+    assert maxdiff(got, ref) <= tol and maxdiff(got, got_torch) <= tol
+    assert maxdiff(back, x) <= 3e-4 * max(1.0, float(x.abs().max())) + 4 * floor
