@@ -255,10 +255,10 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
     # K = 8, linear tails (the fused kernel's), inference only.
     def _fused_forward_ok(self, inputs, context):
         net = self.autoregressive_net
-        return (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+        return (inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
                 and os.environ.get("FC_FUSED", "1") != "0" and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
                 and isinstance(net, made_module.MADE) and not hasattr(net, "hidden_features")
-                and net.final_layer.in_features <= 64 and net.hip_hidden_supported()
+                and net.final_layer.in_features <= 64 and net.hip_hidden_supported(context)
                 and inputs.shape[0] >= ops.FUSED_ROWS
                 and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], inputs.shape[1],
                                                net.final_layer.in_features, self.num_bins, self.tails)
@@ -277,9 +277,8 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
     def forward(self, inputs, context=None):
         if not self._fused_forward_ok(inputs, context):
             return super().forward(inputs, context)
-        net = self.autoregressive_net
-        hidden = self._hidden(inputs, None)
-        masked, w_pad, b_pad, cols = self._packed_final_layer(inputs.device)
+        hidden = self._hidden(inputs, context)
+        _, w_pad, b_pad, cols = self._packed_final_layer(inputs.device)
         kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                   min_bin_height=self.min_bin_height, min_derivative=self.min_derivative, wh_divisor=1.0,
                   enable_identity_init=True)

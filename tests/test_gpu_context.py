@@ -168,6 +168,10 @@ def test_conditional_autoregressive_flow(kind, device, monkeypatch):
         with ops.KernelTimer("fc_resnet_hidden_context") as timer:
             got = flow.log_prob(x.to(device), c.to(device))
         assert len(timer.pairs) == 2, "the MADE hidden stacks did not run in the kernel"
+        if kind == "rq_ar":     # K = 8, linear tails, hidden 64: the masked final Linear + spline run fused, too
+            with ops.KernelTimer("fc_rq_spline_fused_linear") as fused:
+                flow.log_prob(x.to(device), c.to(device))
+            assert len(fused.pairs) == 2
         z, _ = flow._transform(x.to(device), c.to(device))
         back, _ = flow._transform.inverse(z, c.to(device))
         monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
