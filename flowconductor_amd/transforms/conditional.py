@@ -4,6 +4,8 @@ the context instead of from the inputs (API of flowcon/transforms/conditional.py
 The conditional network is a PyTorch-ROCm module (ResidualNet / MLP); every bijector application is the
 same HIP kernel as its coupling / autoregressive sibling, fed per-sample parameter rows.
 """
+import os
+
 import numpy as np
 import torch
 from torch.nn import functional as F
@@ -49,12 +51,42 @@ class ConditionalTransform(Transform):
     def forward(self, inputs, context=None):
         if context is None:
             raise TypeError("Conditional transforms require a context.")
-        return self._forward_given_params(inputs, self.conditional_net(context))
+        return self._forward_given_params(inputs, self._conditional_params(context))
 
     def inverse(self, inputs, context=None):
         if context is None:
             raise TypeError("Conditional transforms require a context.")
-        return self._inverse_given_params(inputs, self.conditional_net(context))
+        return self._inverse_given_params(inputs, self._conditional_params(context))
+
+    # ---- the hyper-network on the matrix cores (inference) ------------------------------------------------------
+    def _hip_hidden_ok(self, context):
+        net = self.conditional_net
+        return (type(net) is ResidualNet and context.dim() == 2 and context.is_cuda
+                and context.dtype == torch.float32 and context.shape[0] >= ops.HIDDEN_ROWS
+                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0" and net.hip_hidden_supported(context.shape[1])
+                and not net._forward_hooks and not net._forward_pre_hooks
+                and not (torch.is_grad_enabled()
+                         and (context.requires_grad or any(p.requires_grad for p in net.parameters()))))
+
+    def _hidden(self, context):
+        """[N, 64] hidden activation of the conditional ResidualNet by ``fc_resnet_hidden`` (its input rows are the
+        context rows; zero-padded columns for a narrower net); the leftover < 16 rows on PyTorch."""
+        net = self.conditional_net
+        n = context.shape[0]
+        ids = getattr(self, "_ctx_cols", None)
+        if ids is None or ids.device != context.device or ids.numel() != context.shape[1]:
+            ids = self._ctx_cols = torch.arange(context.shape[1], dtype=torch.int32, device=context.device)
+        body = n - n % ops.HIDDEN_ROWS
+        hidden = net.hidden_hip(context[:body], ids)
+        if body < n:
+            hidden = torch.cat((hidden, net.hidden_padded(context[body:])))
+        return hidden
+
+    def _conditional_params(self, context):
+        """``conditional_net(context)``; a ResidualNet the hidden-layer kernel covers runs its hidden stack there."""
+        if self._hip_hidden_ok(context):
+            return self.conditional_net.final_from_padded(self._hidden(context))
+        return self.conditional_net(context)
 
     def _output_dim_multiplier(self):
         raise NotImplementedError()
@@ -328,6 +360,46 @@ class ConditionalPiecewiseRationalQuadraticTransform(ConditionalTransform):
 
     def _inverse_given_params(self, inputs, autoregressive_params):
         return self._elementwise(inputs, autoregressive_params, inverse=True)
+
+    # K = 8, linear tails, <= 32 features, ResidualNet(hidden <= 64): final Linear + spline in one kernel, both
+    # directions in one pass (the parameters depend on the context only)
+    def _fused_ok(self, inputs, context):
+        return (context is not None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and inputs.shape[0] == context.shape[0] and os.environ.get("FC_FUSED", "1") != "0"
+                and self._hip_hidden_ok(context) and not (torch.is_grad_enabled() and inputs.requires_grad)
+                and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], inputs.shape[1],
+                                               self.conditional_net.hidden_features, self.num_bins, self.tails))
+
+    def _fused(self, inputs, context, inverse):
+        net = self.conditional_net
+        lin = net.final_layer
+        key = (lin.weight._version, lin.bias._version, lin.weight.device, lin.weight.data_ptr())
+        if getattr(self, "_packed", None) is None or self._packed[0] != key:
+            w_pad, b_pad = ops.pack_final_layer(lin.weight, lin.bias, self.num_bins)
+            cols = torch.arange(self.features, dtype=torch.int32, device=lin.weight.device)
+            self._packed = (key, w_pad, b_pad, cols)
+        _, w_pad, b_pad, cols = self._packed
+        hidden = self._hidden(context)
+        kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
+                  min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
+                  wh_divisor=float(np.sqrt(net.hidden_features)), enable_identity_init=True, inverse=inverse)
+        n = inputs.shape[0]
+        body = n - n % ops.FUSED_ROWS
+        outputs, logabsdet = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_pad, b_pad, cols, **kw)
+        if body < n:
+            out_b, lad_b = self._elementwise(inputs[body:].contiguous(), net.final_from_padded(hidden[body:]), inverse)
+            outputs, logabsdet = torch.cat((outputs, out_b)), torch.cat((logabsdet, lad_b))
+        return outputs, logabsdet
+
+    def forward(self, inputs, context=None):
+        if context is not None and self._fused_ok(inputs, context):
+            return self._fused(inputs, context, False)
+        return super().forward(inputs, context)
+
+    def inverse(self, inputs, context=None):
+        if context is not None and self._fused_ok(inputs, context):
+            return self._fused(inputs, context, True)
+        return super().inverse(inputs, context)
 
 
 class ConditionalSumOfSigmoidsTransform(ConditionalTransform):

@@ -179,3 +179,48 @@ def test_conditional_autoregressive_flow(kind, device, monkeypatch):
     tol = 3e-4 * max(1.0, float(ref.abs().max()) / 10)
     assert maxdiff(got, ref) <= tol and maxdiff(got, got_torch) <= tol
     assert maxdiff(back, x) <= 3e-4 * max(1.0, float(x.abs().max())) + 4 * floor
+
+
+@pytest.mark.parametrize("kind", ["rq", "rq_k5", "sos", "lu", "shift"])
+def test_hyper_network_transforms_on_the_matrix_core_kernels(kind, device, monkeypatch):
+    """Conditional ("hyper-network") transforms (conditional.py): the ResidualNet on the context runs its hidden stack in
+    fc_resnet_hidden, and for the RQ form with K = 8 / linear tails the final Linear + spline run fused, forward and
+    inverse in one pass each.  Against the oracle and the PyTorch hyper-network."""
+    from flowconductor_amd import transforms as T
+
+    torch.manual_seed(23)
+    d, ctx_f, n = 10, 6, 1000
+    if kind == "rq":
+        t = T.ConditionalPiecewiseRationalQuadraticTransform(d, 48, ctx_f, num_bins=8, tails="linear", tail_bound=3.0)
+    elif kind == "rq_k5":
+        t = T.ConditionalPiecewiseRationalQuadraticTransform(d, 64, ctx_f, num_bins=5, tails="linear", tail_bound=3.0)
+    elif kind == "sos":
+        t = T.ConditionalSumOfSigmoidsTransform(d, 32, ctx_f, n_sigmoids=8)
+    elif kind == "lu":
+        t = T.ConditionalLUTransform(d, 64, ctx_f)
+    else:
+        t = T.ConditionalShiftTransform(d, 20, ctx_f)
+    t.eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            if p.is_floating_point():
+                p.mul_(1.3)
+    x = torch.randn(n, d) * 1.1
+    c = torch.randn(n, ctx_f)
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(t, x.clone(), c)
+    t = t.to(device)
+    with torch.no_grad():
+        with ops.KernelTimer("fc_resnet_hidden") as hid, ops.KernelTimer("fc_rq_spline_fused_linear") as fused:
+            y, lad = t(x.to(device), c.to(device))
+        assert len(hid.pairs) == 1, "the hyper-network's hidden stack did not run in fc_resnet_hidden"
+        assert len(fused.pairs) == (1 if kind == "rq" else 0)
+        back, lad_inv = t.inverse(y, c.to(device))
+        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        y_torch, lad_torch = t(x.to(device), c.to(device))
+    scale = max(1.0, float(ref_y.abs().max()))
+    lscale = max(1.0, float(ref_lad.abs().max()) / 10)
+    assert maxdiff(y, ref_y) <= 3e-5 * scale and maxdiff(lad, ref_lad) <= 3e-4 * lscale
+    assert maxdiff(y, y_torch) <= 3e-5 * scale and maxdiff(lad, lad_torch) <= 3e-4 * lscale
+    assert maxdiff(back, x) <= 3e-4 * max(1.0, float(x.abs().max()))
+    assert maxdiff(lad + lad_inv, torch.zeros_like(lad)) <= 3e-3 * lscale
