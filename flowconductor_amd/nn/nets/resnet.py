@@ -74,7 +74,30 @@ class ResidualNet(nn.Module):
         return h
 
     def forward(self, inputs, context=None):
+        if self._hip_forward_ok(inputs, context):
+            # inference on a HIP device: hidden stack in fc_resnet_hidden, the < 16 leftover rows on PyTorch
+            n = inputs.shape[0]
+            body = n - n % 16
+            ids = getattr(self, "_all_cols", None)
+            if ids is None or ids.device != inputs.device or ids.numel() != inputs.shape[1]:
+                ids = self._all_cols = torch.arange(inputs.shape[1], dtype=torch.int32, device=inputs.device)
+            hidden = self.hidden_hip(inputs[:body], ids, None if context is None else context[:body])
+            if body < n:
+                hidden = torch.cat((hidden, self.hidden_padded(inputs[body:],
+                                                               None if context is None else context[body:])))
+            return self.final_from_padded(hidden)
         return self.final_layer(self.hidden(inputs, context))
+
+    def _hip_forward_ok(self, inputs, context):
+        import os
+
+        if not (inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.shape[0] >= 16
+                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"):
+            return False
+        if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False        # training: PyTorch autograd
+        return inputs.shape[1] + (0 if context is None else self.context_features or 0) == self.initial_layer.in_features \
+            and self.hip_hidden_supported(inputs.shape[1], context)
 
     # ---- device fast path for the hidden layers (inference) ------------------------------------------
     def hip_hidden_supported(self, features_total, context=None):

@@ -224,3 +224,43 @@ def test_hyper_network_transforms_on_the_matrix_core_kernels(kind, device, monke
     assert maxdiff(y, y_torch) <= 3e-5 * scale and maxdiff(lad, lad_torch) <= 3e-4 * lscale
     assert maxdiff(back, x) <= 3e-4 * max(1.0, float(x.abs().max()))
     assert maxdiff(lad + lad_inv, torch.zeros_like(lad)) <= 3e-3 * lscale
+
+
+def test_flow_with_embedding_net_and_conditional_layers(device, monkeypatch):
+    """The layout of examples/conditional_toy_2d.py with in-scope layers: an embedding ResidualNet (hidden 32, SiLU) on
+    the raw context feeds conditional RQ / affine-coupling layers; every ResidualNet forward runs in the hidden-layer
+    kernel.  log_prob against the oracle and against the PyTorch networks."""
+    from torch.nn import functional as F
+
+    from flowconductor_amd import distributions, flows, transforms, utils
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(29)
+    d, raw_ctx, emb, n = 8, 1, 12, 1000
+
+    def cnet(i, o):
+        return nets.ResidualNet(i, o, hidden_features=64, context_features=emb, num_blocks=2)
+
+    layers = [transforms.ConditionalPiecewiseRationalQuadraticTransform(d, 64, emb, num_bins=8, tails="linear",
+                                                                        tail_bound=3.0),
+              transforms.AffineCouplingTransform(utils.create_alternating_binary_mask(d), cnet),
+              transforms.ConditionalShiftTransform(d, 32, emb)]
+    embedding = nets.ResidualNet(raw_ctx, emb, hidden_features=32, num_blocks=2, activation=F.silu)
+    flow = flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([d]),
+                      embedding_net=embedding).eval()
+    with torch.no_grad():
+        for p in flow.parameters():
+            p.mul_(1.3)
+    x = torch.randn(n, d)
+    c = torch.randn(n, raw_ctx)
+    with torch.no_grad():
+        ref = O.flow_log_prob(flow, x, c)
+    flow = flow.to(device)
+    with torch.no_grad():
+        with ops.KernelTimer("fc_resnet_hidden") as plain, ops.KernelTimer("fc_resnet_hidden_context") as withctx:
+            got = flow.log_prob(x.to(device), c.to(device))
+        assert len(plain.pairs) == 3 and len(withctx.pairs) == 1   # embedding + 2 hyper-networks; the coupling net
+        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        got_torch = flow.log_prob(x.to(device), c.to(device))
+    tol = 3e-4 * max(1.0, float(ref.abs().max()) / 10)
+    assert maxdiff(got, ref) <= tol and maxdiff(got, got_torch) <= tol
