@@ -64,6 +64,28 @@ def measured_traffic_per_launch(entry, rows_per_launch):
         return None
 
 
+def issue_bound(counters_file, launch_ms, rows_per_launch):
+    """How much of the SIMDs' instruction-issue time a compute-bound kernel uses: wave-level VALU and MFMA instruction
+    counts per launch from the committed SQ-counter passes (tools/probe/pmc_kernel.sh) priced at 4.3 / 8 issue cycles
+    (MI355X_MICROARCH.md: a 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles), against 256 CUs x 4
+    SIMDs x the 2.4 GHz peak clock over this run's launch duration.  None if the profile is absent."""
+    try:
+        if rows_per_launch != (1 << 20):
+            return None
+        vals = {}
+        for line in open(os.path.join(ROOT, counters_file)):
+            parts = line.split()
+            if len(parts) >= 3 and parts[0] in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA"):
+                vals[parts[0]] = float(parts[2])
+        cycles = 4.3 * vals["SQ_INSTS_VALU"] + 8.0 * vals["SQ_INSTS_MFMA"]
+        avail = 256 * 4 * 2.4e9 * launch_ms * 1e-3
+        return {"valu_wave_instructions": vals["SQ_INSTS_VALU"], "mfma_wave_instructions": vals["SQ_INSTS_MFMA"],
+                "issue_cycles": cycles, "simd_cycles_at_2.4GHz": avail, "frac": cycles / avail,
+                "source": counters_file}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def algorithmic_bytes_per_sample_layer():
     """B = 4*d_t*(P + 2) + 8: params + x_t + y_t + logabsdet r/w."""
     d_t = FEATURES // 2
@@ -310,6 +332,7 @@ def main():
                                "algorithmic_bytes_per_launch": f_bytes,
                                "share_of_step": sum(fused_ms) / (1e3 * elapsed / args.steps),
                                "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01h_fused_sq_counters.txt",
+                               "issue_bound": issue_bound("profiles/r01h_fused_sq_counters.txt", f_avg, rows_per_launch),
                                # BASELINE.md section 4 prices a coupling bijector at B = 4 d_t (P + 2) + 8 bytes per
                                # sample and layer (parameters read from HBM).  The fused kernel never moves them; in
                                # that accounting it delivers:
@@ -336,6 +359,8 @@ def main():
                                           "launches_timed": len(hidden_ms), "avg_launch_ms": h_avg,
                                           "algorithmic_bytes_per_launch": h_bytes,
                                           "share_of_step": sum(hidden_ms) / (1e3 * elapsed / args.steps),
+                                          "issue_bound": issue_bound("profiles/r01h_hidden_sq_counters.txt", h_avg,
+                                                                     rows_per_launch),
                                           "matrix_pipe": {"algorithmic_tflops": hflops / (h_avg * 1e-3) / 1e12,
                                                           "executed_tflops": 3.0 * hflops / (h_avg * 1e-3) / 1e12,
                                                           "peak_f16_dense_tflops": MFMA_F16_PEAK_TFLOPS}}
