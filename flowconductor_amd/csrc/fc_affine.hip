@@ -17,6 +17,10 @@
 
 namespace fc {
 
+// torch.clamp: a NaN stays a NaN (fminf / fmaxf would return the bound)
+__device__ __forceinline__ float clamp_like_torch(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+
 struct AffineOp {
   static constexpr bool kHasPrepare = false;
   __device__ void prepare(float*, int, int) const {}
@@ -34,7 +38,7 @@ struct AffineOp {
         break;
       case FC_AFFINE_SOFTPLUS_CLAMP3:
         shift = prow[j];
-        s = fminf(fmaxf(softplus1(prow[d_t + j]) + 1e-3f, 0.f), 3.f);
+        s = clamp_like_torch(softplus1(prow[d_t + j]) + 1e-3f, 0.f, 3.f);
         break;
       case FC_AFFINE_SCALE_GIVEN:
         shift = prow[j];
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void affine_backward_kernel(const float* __res
       case FC_AFFINE_SOFTPLUS_CLAMP3: {
         i_shift = j; i_scale = d_t + j;
         const float u = prow[i_scale], v = softplus1(u) + 1e-3f;
-        s = fminf(fmaxf(v, 0.f), 3.f);
+        s = clamp_like_torch(v, 0.f, 3.f);
         ds = (v >= 0.f && v <= 3.f) ? (u > 20.f ? 1.f : sigmoidf(u)) : 0.f;   // clamp passes the gradient inside [0, 3]
         break;
       }

@@ -71,7 +71,7 @@ __device__ __forceinline__ void ew_eval(const EwArgs& a, int64_t row, int64_t j,
       } else {
         if (x < 0.f || x > 1.f) err |= 1u;
         const float eps = a.p0;
-        const float xc = fminf(fmaxf(x, eps), 1.f - eps);
+        const float xc = x < eps ? eps : (x > 1.f - eps ? 1.f - eps : x);   // torch.clamp: NaN stays NaN
         y = (1.f / temp) * (logf(xc) - log1pf(-xc));
         lad = -(logf(temp) - softplus1(-temp * y) - softplus1(temp * y));
       }

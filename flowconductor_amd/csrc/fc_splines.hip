@@ -14,6 +14,11 @@
 
 namespace fc {
 
+// torch.clamp(x, 0, 1) as ATen computes it: a NaN (e.g. the square root of a discriminant that rounding pushed
+// below zero, splines/quadratic.py:139) stays a NaN instead of turning into 0 the way fminf / fmaxf would make it
+__device__ __forceinline__ float clamp01(float x) { return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); }
+
+
 struct SplineParams {
   int K;
   int tails;       // 0 none, 1 linear
@@ -96,7 +101,7 @@ struct LinearSplineOp {
       for (int i = 0; i < idx; ++i) cum += (double)pdf[i];
       const float p = pdf[idx];
       float out = (float)cum + alpha * p;
-      out = fminf(fmaxf(out, 0.f), 1.f);
+      out = clamp01(out);
       lad = logf(p) - logf(1.f / (float)K);
       y = spline_out(q, out);
     } else {
@@ -118,7 +123,7 @@ struct LinearSplineOp {
       const float slope = (knot_hi - knot_lo) / (b1 - b0);
       const float offset = knot_hi - slope * b1;
       float out = (xn - offset) / slope;
-      out = fminf(fmaxf(out, 0.f), 1.f);
+      out = clamp01(out);
       lad = -logf(slope);
       y = spline_out(q, out);
     }
@@ -200,12 +205,12 @@ struct QuadraticSplineOp {
       const float c_ = lc - xn;
       const float alpha = (-b + sqrtf(b * b - 4.f * a * c_)) / (2.f * a);
       out = alpha * wk + loc;
-      out = fminf(fmaxf(out, 0.f), 1.f);
+      out = clamp01(out);
       lad = -logf(alpha * (hr - hl) + hl);
     } else {
       const float alpha = (xn - loc) / wk;
       out = a * (alpha * alpha) + b * alpha + lc;
-      out = fminf(fmaxf(out, 0.f), 1.f);
+      out = clamp01(out);
       lad = logf(alpha * (hr - hl) + hl);
     }
     y = spline_out(q, out);
