@@ -1,0 +1,121 @@
+"""Randomised shapes for the remaining bijectors (autoregressive forms, sum-of-sigmoids, Householder / planar / Sylvester /
+LU, point-wise maps, batch-shared CDFs) against the CPU oracle, float64 oracle as the noise floor.  Not part of the test
+suite; run on the GPU box:  python tools/probe/fuzz_other_kernels.py [seed] [cases]"""
+import copy
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT]
+from flowconductor_amd import transforms as T  # noqa: E402
+from oracle import torch_oracle as O  # noqa: E402
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+g = torch.Generator().manual_seed(seed)
+dev = "cuda"
+
+
+def ri(lo, hi):
+    return int(torch.randint(lo, hi + 1, (1,), generator=g))
+
+
+def md(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max()) if a.numel() else 0.0
+
+
+KINDS = ["maf", "maf_rq", "maf_rq_box", "maf_linear", "maf_quadratic", "maf_cubic", "maf_sos", "householder", "planar",
+         "sylvester", "lu", "pointwise", "actnorm", "exp", "tanh", "logtanh", "leaky", "sigmoid", "logit", "softplus",
+         "cauchy", "rq_cdf", "linear_cdf", "quadratic_cdf", "cubic_cdf"]
+worst = {}
+for c in range(cases):
+    kind = KINDS[ri(0, len(KINDS) - 1)]
+    d = ri(1, 40) if kind.startswith("maf") else ri(1, 150)
+    if kind == "sylvester":
+        d = ri(2, 100)
+    n = ri(1, 2500)
+    k = ri(2, 12)
+    hidden = ri(4, 70)
+    torch.manual_seed(seed * 100000 + c)
+    unit, has_inverse, boost = False, True, 1.5
+    if kind == "maf":
+        t = T.MaskedAffineAutoregressiveTransform(d, hidden)
+    elif kind == "maf_rq":
+        t = T.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(d, hidden, num_bins=k, tails="linear", tail_bound=3.0)
+    elif kind == "maf_rq_box":
+        t = T.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(d, hidden, num_bins=k)
+    elif kind == "maf_linear":
+        t, unit = T.MaskedPiecewiseLinearAutoregressiveTransform(k, d, hidden), True
+    elif kind == "maf_quadratic":
+        t = T.MaskedPiecewiseQuadraticAutoregressiveTransform(k, d, hidden, tails="linear", tail_bound=3.0)
+    elif kind == "maf_cubic":
+        t, unit = T.MaskedPiecewiseCubicAutoregressiveTransform(k, d, hidden), True
+    elif kind == "maf_sos":
+        d = min(d, 12)
+        t = T.MaskedSumOfSigmoidsTransform(d, hidden, n_sigmoids=ri(2, 20))
+    elif kind == "householder":
+        t = T.HouseholderSequence(d, ri(1, 8))
+        with torch.no_grad():
+            t.q_vectors.copy_(torch.randn(t.q_vectors.shape, generator=g))
+        boost = 1.0
+    elif kind == "planar":
+        t, has_inverse = T.PlanarTransform(d), False
+    elif kind == "sylvester":
+        t, has_inverse, boost = T.SylvesterTransform(d, num_householder=ri(1, min(d, 6)), device="cpu"), False, 1.0
+    elif kind == "lu":
+        t, boost = T.LULinear(d), 1.0
+        with torch.no_grad():
+            t.lower_entries.normal_(0, 0.3, generator=g)
+            t.upper_entries.normal_(0, 0.3, generator=g)
+    elif kind == "pointwise":
+        t = T.PointwiseAffineTransform(shift=torch.randn(d, generator=g), scale=torch.rand(d, generator=g) + 0.3)
+    elif kind == "actnorm":
+        t, boost = T.ActNorm(d), 1.0
+        with torch.no_grad():
+            t.log_scale.normal_(0, 0.5, generator=g)
+            t.shift.normal_(0, 1, generator=g)
+            t.initialized.fill_(True)
+    elif kind in ("exp", "tanh", "logtanh", "leaky", "sigmoid", "logit", "softplus", "cauchy"):
+        t = {"exp": T.Exp, "tanh": T.Tanh, "logtanh": T.LogTanh, "leaky": T.LeakyReLU, "sigmoid": T.Sigmoid,
+             "logit": T.Logit, "softplus": T.Softplus, "cauchy": T.CauchyCDF}[kind]()
+        unit = kind == "logit"
+    elif kind == "rq_cdf":
+        t = T.PiecewiseRationalQuadraticCDF([d], num_bins=k, tails="linear", tail_bound=3.0)
+    elif kind == "linear_cdf":
+        t, unit = T.PiecewiseLinearCDF([d], num_bins=k), True
+    elif kind == "quadratic_cdf":
+        t = T.PiecewiseQuadraticCDF([d], num_bins=k, tails="linear", tail_bound=3.0)
+    else:
+        t, unit = T.PiecewiseCubicCDF([d], num_bins=k), True
+    t.eval()
+    if boost != 1.0:
+        with torch.no_grad():
+            for p in t.parameters():
+                if p.is_floating_point():
+                    p.mul_(boost)
+    x = torch.rand(n, d, generator=g) * 0.96 + 0.02 if unit else torch.randn(n, d, generator=g) * (0.7 if kind in ("maf_sos", "exp") else 1.3)
+    if kind == "maf_rq_box":
+        x = torch.rand(n, d, generator=g) * 2.2 - 1.1
+    with torch.no_grad():
+        ry, rl = O.transform_apply(t, x.clone())
+        ry64, rl64 = O.transform_apply(copy.deepcopy(t).double(), x.double())
+        td = copy.deepcopy(t).to(dev)
+        y, lad = td(x.to(dev))
+    fy, fl = md(ry, ry64), md(rl, rl64)
+    by = 2e-5 * max(1.0, float(ry.abs().max())) + 8 * fy
+    bl = 2e-4 * max(1.0, float(rl.abs().max()) / 10) + 8 * fl
+    ey, el = md(y, ry64), md(lad, rl64)
+    assert y.shape == x.shape and lad.shape == (n,), (kind, d, n)
+    assert ey <= by and el <= bl, (kind, d, k, n, hidden, ey, by, el, bl)
+    if has_inverse and kind != "maf_sos":
+        with torch.no_grad():
+            back, _ = td.inverse(y)
+            rb, _ = O.transform_apply(t, ry.clone(), inverse=True)
+        ok = ~(torch.isnan(rb) | torch.isnan(back.cpu()))
+        assert int((~ok).sum()) <= 2, (kind, "nan", d, k, n)
+        rt, rt_ref = md(back.cpu()[ok], x[ok]), md(rb[ok], x[ok])
+        assert rt <= 5e-4 * max(1.0, float(x.abs().max())) + 8 * rt_ref, (kind, "round trip", d, k, n, hidden, rt, rt_ref)
+    worst[kind] = max(worst.get(kind, 0.0), ey / by, el / bl)
+print("fuzz ok: seed %d, %d cases; worst error / bound per kind %s" % (seed, cases, {a: "%.2f" % b for a, b in sorted(worst.items())}))
