@@ -301,15 +301,37 @@ class _RQSplineFunction(torch.autograd.Function):
         return gx, gp, None, None
 
 
+def _inverse_through_forward(forward_fn, inverse_nograd_fn, inputs, params):
+    """Differentiable inverse of an element-wise bijector whose gradients exist for the forward direction only
+    (sampling / reverse-KL training through ``Flow.sample``, ``sample_and_log_prob``): the inverse kernel finds
+    ``y0 = f^-1(x; p)`` without a graph, then one Newton-shaped step ``y = y0 - (f(y0; p) - x) / f'(y0)`` through the
+    differentiable forward op carries the implicit-function gradients ``dy/dx = 1 / f'``, ``dy/dp = -(df/dp) / f'``
+    (its value only removes the inverse's rounding residual), and ``logabsdet = -logabsdet_f(y; p)`` is the forward op
+    evaluated at that ``y``.  Three kernel passes instead of one; ``f'`` per element comes from the backward kernel."""
+    with torch.no_grad():
+        y0, _ = inverse_nograd_fn(inputs, params)
+    y0 = y0.detach().requires_grad_(True)
+    with torch.enable_grad():
+        x_hat, _ = forward_fn(y0, params)
+        fprime, = torch.autograd.grad(x_hat.sum(), y0, retain_graph=True)
+        y = y0.detach() - (x_hat - inputs) / fprime.detach()
+        _, logabsdet = forward_fn(y, params)
+    return y, -logabsdet
+
+
 def rq_spline_autograd(inputs, params, cols=None, **kw):
-    """``rq_spline`` that records an autograd node when gradients are required (forward direction, per-sample
-    parameters); otherwise exactly ``rq_spline``."""
+    """``rq_spline`` that records an autograd node when gradients are required (per-sample parameters; the inverse
+    direction through ``_inverse_through_forward``); otherwise exactly ``rq_spline``."""
     needs = torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad)
     if not needs:
         return rq_spline(inputs, params, cols, **kw)
-    if kw.get("inverse") or kw.get("shared_params"):
-        raise RuntimeError("flowconductor_amd: gradients are implemented for the forward direction of the RQ "
-                           "spline with per-sample parameters; wrap other calls in torch.no_grad().")
+    if kw.get("shared_params"):
+        raise RuntimeError("flowconductor_amd: gradients are implemented for the RQ spline with per-sample "
+                           "parameters; wrap other calls in torch.no_grad().")
+    if kw.get("inverse"):
+        fwd_kw = dict(kw, inverse=False)
+        return _inverse_through_forward(lambda y, p: _RQSplineFunction.apply(y, p, cols, fwd_kw),
+                                        lambda x, p: rq_spline(x, p, cols, **kw), inputs, params)
     return _RQSplineFunction.apply(inputs, params, cols, kw)
 
 
@@ -500,10 +522,15 @@ def affine_coupling(inputs, params, cols=None, *, activation=AFFINE_SIGMOID_PLUS
     gradients are required (forward direction, per-sample parameters).  See ``_affine_coupling_nograd``.
     ``logabsdet_accum``: running total the kernel adds onto (no-grad calls; otherwise added here)."""
     if torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad):
-        if inverse or shared_params:
-            raise RuntimeError("flowconductor_amd: gradients are implemented for the forward direction of the "
-                               "affine bijector with per-sample parameters; wrap other calls in torch.no_grad().")
-        outputs, logabsdet = _AffineFunction.apply(inputs, params, cols, activation)
+        if shared_params:
+            raise RuntimeError("flowconductor_amd: gradients are implemented for the affine bijector with "
+                               "per-sample parameters; wrap other calls in torch.no_grad().")
+        if inverse:
+            outputs, logabsdet = _inverse_through_forward(
+                lambda y, p: _AffineFunction.apply(y, p, cols, activation),
+                lambda x, p: _affine_coupling_nograd(x, p, cols, activation=activation, inverse=True), inputs, params)
+        else:
+            outputs, logabsdet = _AffineFunction.apply(inputs, params, cols, activation)
         if logabsdet_accum is not None:
             logabsdet_accum += logabsdet
             logabsdet = logabsdet_accum
