@@ -722,6 +722,74 @@ def pointwise_affine(inputs, scale, shift, inverse=False):
     return y
 
 
+class _PointwiseAffineFunction(torch.autograd.Function):
+    """``pointwise_affine`` with gradients: the HIP kernel forward, broadcasting reductions backward
+    (y = x s + b: dx = gy s, ds = sum gy x, db = sum gy; inverse y = (x - b) / s: dx = gy / s, ds = -sum gy y / s,
+    db = -sum gy / s) -- ActNorm / point-wise affine layers of a flow that is being trained."""
+
+    @staticmethod
+    def forward(ctx, inputs, scale, shift, inverse):
+        with torch.no_grad():
+            outputs = pointwise_affine(inputs, scale, shift, inverse=inverse)
+        ctx.save_for_backward(outputs if inverse else inputs, scale, shift)
+        ctx.inverse = inverse
+        return outputs
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved, scale, shift = ctx.saved_tensors
+        s = scale.to(gy.dtype)
+        if ctx.inverse:
+            gx = gy / s
+            gs = -(gx * saved).sum(0)
+            gb = -gx.sum(0)
+        else:
+            gx = gy * s
+            gs = (gy * saved).sum(0)
+            gb = gy.sum(0)
+        return gx, gs.sum_to_size(scale.shape), gb.sum_to_size(shift.shape), None
+
+
+def pointwise_affine_autograd(inputs, scale, shift, inverse=False):
+    """``pointwise_affine``; records an autograd node when gradients are required.  ``scale`` / ``shift`` broadcast
+    against one batch item."""
+    scale, shift = torch.as_tensor(scale, device=inputs.device), torch.as_tensor(shift, device=inputs.device)
+    if torch.is_grad_enabled() and (inputs.requires_grad or scale.requires_grad or shift.requires_grad):
+        return _PointwiseAffineFunction.apply(inputs, scale, shift, inverse)
+    return pointwise_affine(inputs, scale, shift, inverse=inverse)
+
+
+class _LULinearFunction(torch.autograd.Function):
+    """``y = L (U x) + b`` / ``y = U^-1 L^-1 (x - b)`` by the HIP kernel; gradients by library GEMMs and triangular
+    solves on the device (lu.py:56-91 under autograd)."""
+
+    @staticmethod
+    def forward(ctx, inputs, lower, upper, bias, inverse):
+        with torch.no_grad():
+            outputs = linear(inputs, upper, lower, bias, mode=LINEAR_LU_INVERSE if inverse else LINEAR_LU_FORWARD)
+        ctx.save_for_backward(inputs, lower, upper, outputs)
+        ctx.inverse = inverse
+        return outputs
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, lower, upper, y = ctx.saved_tensors
+        if not ctx.inverse:
+            ux = x @ upper.T
+            g_ux = gy @ lower
+            return g_ux @ upper, gy.T @ ux, g_ux.T @ x, gy.sum(0), None
+        # y = W^-1 (x - b), W = L U:  gz = W^-T gy;  dW = -gz^T y;  dL = dW U^T, dU = L^T dW
+        t = torch.linalg.solve_triangular(upper.T, gy.T, upper=False)
+        gz = torch.linalg.solve_triangular(lower.T, t, upper=True, unitriangular=True).T
+        gw = -(gz.T @ y)
+        return gz, gw @ upper.T, lower.T @ gw, -gz.sum(0), None
+
+
+def lu_linear_autograd(inputs, lower, upper, bias, inverse=False):
+    """LU-parameterised linear map with an autograd node (training / differentiable sampling)."""
+    return _LULinearFunction.apply(_prep_2d(inputs), lower, upper, bias, inverse)
+
+
 def batchnorm_eval(inputs, mean, std, weight, bias, inverse=False):
     """Eval-mode BatchNorm map and its inverse (reference normalization.py:98-141)."""
     lib = _hip.load()

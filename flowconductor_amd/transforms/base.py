@@ -11,8 +11,47 @@ from flowconductor_amd import ops
 from flowconductor_amd.ops import InputOutsideDomain, InverseNotAvailable  # noqa: F401 (re-export)
 
 
+def _guard_missing_backward(fn):
+    """forward / inverse of a transform whose kernels have no backward: called with autograd on and trainable own
+    parameters, its outputs would carry no gradient and those parameters would silently never train -- fail loudly."""
+    import functools
+
+    @functools.wraps(fn)
+    def guarded(self, *args, **kwargs):
+        self._check_autograd()
+        return fn(self, *args, **kwargs)
+
+    guarded._guarded = True
+    return guarded
+
+
+def own_autograd_check(fn):
+    """Marks a forward / inverse that calls ``self._check_autograd()`` itself (after checks of its own)."""
+    fn._guarded = True
+    return fn
+
+
 class Transform(nn.Module):
     """Base class for all transform objects."""
+
+    # True for transforms whose HIP kernels sit behind torch.autograd (or that only delegate to children); every
+    # other subclass with trainable parameters of its own refuses to run with autograd on (see the guard above)
+    _HIP_AUTOGRAD = False
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        for name in ("forward", "inverse"):
+            fn = cls.__dict__.get(name)
+            if fn is not None and not getattr(fn, "_guarded", False):
+                setattr(cls, name, _guard_missing_backward(fn))
+
+    def _check_autograd(self):
+        if (not self._HIP_AUTOGRAD and torch.is_grad_enabled()
+                and any(p.requires_grad for p in self.parameters(recurse=False))):
+            raise RuntimeError(
+                "flowconductor_amd: %s has no backward kernel; with autograd on its parameters would silently not "
+                "train.  Wrap the call in torch.no_grad() (inference) or freeze the layer with requires_grad_(False)."
+                % type(self).__name__)
 
     def forward(self, inputs, context=None):
         raise NotImplementedError()

@@ -37,8 +37,11 @@ class Linear(Transform):
         self.using_cache = using_cache
         self.cache = LinearCache()
 
+    def _grad_needed(self, inputs):
+        return torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def forward(self, inputs, context=None):
-        if not self.training and self.using_cache:
+        if not self.training and self.using_cache and not self._grad_needed(inputs):
             self._check_forward_cache()
             outputs = ops.linear(inputs, self.cache.weight, bias=self.bias, mode=ops.LINEAR_DENSE)
             return outputs, self.cache.logabsdet * outputs.new_ones(outputs.shape[0])
@@ -53,7 +56,7 @@ class Linear(Transform):
             self.cache.logabsdet = self.logabsdet()
 
     def inverse(self, inputs, context=None):
-        if not self.training and self.using_cache:
+        if not self.training and self.using_cache and not self._grad_needed(inputs):
             self._check_inverse_cache()
             # F.linear(inputs - bias, W^-1) == W^-1 inputs + (-(W^-1 bias)); the [D] constant is host-side
             shift = -(self.cache.inverse.detach() @ self.bias.detach())

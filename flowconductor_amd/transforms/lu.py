@@ -15,6 +15,8 @@ class LULinear(Linear):
     Parameters ``lower_entries``, ``upper_entries`` (strict triangles, row-major), ``unconstrained_upper_diag``
     and ``bias`` keep the reference's names and shapes."""
 
+    _HIP_AUTOGRAD = True
+
     def __init__(self, features, using_cache=False, identity_init=True, eps=1e-3):
         super().__init__(features, using_cache)
         self.eps = eps
@@ -48,8 +50,15 @@ class LULinear(Linear):
         upper[self.diag_indices[0], self.diag_indices[1]] = self.upper_diag
         return lower, upper
 
+    def _needs_grad(self, inputs):
+        return torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
+
     def forward_no_cache(self, inputs):
         """outputs = L (U x) + bias in one kernel; logabsdet = sum log diag(U)."""
+        if self._needs_grad(inputs):    # training: same kernel behind an autograd node, L / U built differentiably
+            lower, upper = self._create_lower_upper()
+            outputs = ops.lu_linear_autograd(inputs, lower, upper, self.bias)
+            return outputs, self.logabsdet() * inputs.new_ones(outputs.shape[0])
         with torch.no_grad():
             lower, upper = self._create_lower_upper()
             n = inputs.shape[0]
@@ -65,6 +74,10 @@ class LULinear(Linear):
 
     def inverse_no_cache(self, inputs):
         """outputs = U^-1 L^-1 (x - bias) by forward/back substitution in one kernel."""
+        if self._needs_grad(inputs):
+            lower, upper = self._create_lower_upper()
+            outputs = ops.lu_linear_autograd(inputs, lower, upper, self.bias, inverse=True)
+            return outputs, -self.logabsdet() * inputs.new_ones(outputs.shape[0])
         with torch.no_grad():
             lower, upper = self._create_lower_upper()
             outputs = ops.linear(inputs, upper, lower, self.bias, mode=ops.LINEAR_LU_INVERSE)

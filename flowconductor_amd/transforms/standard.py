@@ -39,7 +39,7 @@ class PointwiseAffineTransform(Transform):
 
     def _map(self, inputs, inverse):
         batch_size, *batch_shape = inputs.size()
-        outputs = ops.pointwise_affine(inputs, self._scale, self._shift, inverse=inverse)
+        outputs = ops.pointwise_affine_autograd(inputs, self._scale, self._shift, inverse=inverse)
         logabsdet = self._batch_logabsdet(batch_shape).to(torch.float32).expand(batch_size)
         return outputs, (-logabsdet if inverse else logabsdet)
 
