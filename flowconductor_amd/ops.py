@@ -821,6 +821,10 @@ def _rows(inputs, name="inputs"):
 
 
 def _param(t, device, name):
+    """A parameter operand (module-owned or produced per sample by a hyper-network) as a device f32 tensor.  These
+    kernels have no backward: a parameter that still carries a graph is refused rather than silently detached."""
+    if isinstance(t, torch.Tensor):
+        _hip.require_no_grad(t)
     return _hip.dev_f32(torch.as_tensor(t).detach().to(device), name)
 
 
