@@ -40,6 +40,8 @@ class Transform(nn.Module):
 
     def __init_subclass__(cls, **kwargs):
         super().__init_subclass__(**kwargs)
+        if not cls.__module__.startswith("flowconductor_amd."):
+            return      # a user's own Transform (plain torch ops, differentiable as it is) is none of our business
         for name in ("forward", "inverse"):
             fn = cls.__dict__.get(name)
             if fn is not None and not getattr(fn, "_guarded", False):

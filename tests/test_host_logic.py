@@ -244,3 +244,24 @@ def test_graphed_call_rejects_cpu_tensors():
 
     with pytest.raises(ValueError):
         GraphedCall(lambda t: t, torch.zeros(4, 2))
+
+
+def test_user_defined_transforms_are_left_alone():
+    """The boundary is duck-typed: a user's Transform subclass with trainable parameters and plain torch ops
+    composes with the package's layers and trains; the missing-backward guard only wraps the package's own classes."""
+    class Scale(T.Transform):
+        def __init__(self):
+            super().__init__()
+            self.log_s = torch.nn.Parameter(torch.zeros(3))
+
+        def forward(self, inputs, context=None):
+            return inputs * torch.exp(self.log_s), self.log_s.sum().expand(inputs.shape[0])
+
+    t = Scale()
+    assert not getattr(Scale.forward, "_guarded", False)
+    y, lad = t(torch.ones(4, 3))
+    (y.sum() + lad.sum()).backward()
+    assert t.log_s.grad is not None
+    assert getattr(T.HouseholderSequence.forward, "_guarded", False)
+    with pytest.raises(RuntimeError, match="no backward kernel"):
+        T.HouseholderSequence(3, 2)(torch.ones(4, 3))
