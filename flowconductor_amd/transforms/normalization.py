@@ -38,8 +38,26 @@ class BatchNorm(Transform):
         if inputs.dim() != 2:
             raise ValueError("Expected 2-dim inputs, got inputs of shape: {}".format(inputs.shape))
 
+    def _grad_needed(self, inputs):
+        return torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
+
+    @own_autograd_check
     def forward(self, inputs, context=None):
         self._check(inputs)
+        if self._grad_needed(inputs):
+            # Under autograd (training is a cross-batch reduction, SURVEY 8e: not a row-wise kernel) the map is the
+            # reference's torch expression on the device, differentiable through the batch statistics
+            # (normalization.py:98-119)
+            if self.training:
+                mean, var = inputs.mean(0), inputs.var(0)
+                with torch.no_grad():
+                    self.running_mean.mul_(1 - self.momentum).add_(mean.detach() * self.momentum)
+                    self.running_var.mul_(1 - self.momentum).add_(var.detach() * self.momentum)
+            else:
+                mean, var = self.running_mean, self.running_var
+            outputs = self.weight * ((inputs - mean) / torch.sqrt(var + self.eps)) + self.bias
+            logabsdet_ = torch.log(self.weight) - 0.5 * torch.log(var + self.eps)
+            return outputs, torch.sum(logabsdet_) * inputs.new_ones(inputs.shape[0])
         if self.training:
             with torch.no_grad():
                 mean, var = inputs.mean(0), inputs.var(0)
@@ -57,8 +75,11 @@ class BatchNorm(Transform):
         if self.training:
             raise InverseNotAvailable(
                 "Batch norm inverse is only available in eval mode, not in training mode.")
-        self._check_autograd()
         self._check(inputs)
+        if self._grad_needed(inputs):   # normalization.py:121-141 in torch ops (see forward)
+            outputs = torch.sqrt(self.running_var + self.eps) * ((inputs - self.bias) / self.weight) + self.running_mean
+            logabsdet_ = -torch.log(self.weight) + 0.5 * torch.log(self.running_var + self.eps)
+            return outputs, torch.sum(logabsdet_) * inputs.new_ones(inputs.shape[0])
         weight = self.weight.detach()
         outputs = ops.batchnorm_eval(inputs, self.running_mean, torch.sqrt(self.running_var + self.eps),
                                      weight, self.bias.detach(), inverse=True)

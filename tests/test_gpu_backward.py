@@ -331,7 +331,7 @@ def test_transforms_without_backward_refuse_to_run_under_autograd(device):
 
     x = torch.randn(64, 8, device=device)
     for t in (T.HouseholderSequence(8, 3), T.SylvesterTransform(8, num_householder=2, device="cpu"), T.PlanarTransform(8),
-              T.PiecewiseRationalQuadraticCDF([8], num_bins=4, tails="linear", tail_bound=3.0), T.BatchNorm(8).eval()):
+              T.PiecewiseRationalQuadraticCDF([8], num_bins=4, tails="linear", tail_bound=3.0)):
         t = t.to(device)
         with pytest.raises(RuntimeError, match="no backward kernel"):
             t(x)
@@ -343,3 +343,53 @@ def test_transforms_without_backward_refuse_to_run_under_autograd(device):
             m.requires_grad_(False)
         y2, _ = t(x)
         assert torch.equal(y, y2)
+
+
+def test_realnvp_with_batch_norm_trains(device):
+    """SimpleRealNVP-style stack with BatchNorm between the coupling layers in training mode: the batch-norm layer is
+    the reference's torch expression under autograd (cross-batch statistics), everything else the HIP path; loss and
+    parameter gradients against the same stack evaluated with torch ops in float64."""
+    from flowconductor_amd import transforms, utils
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(53)
+    d, n = 6, 400
+    layers = []
+    for i in range(2):
+        layers += [transforms.AffineCouplingTransform(utils.create_alternating_binary_mask(d, even=(i % 2 == 0)),
+                                                      lambda a, b: nets.ResidualNet(a, b, hidden_features=16, num_blocks=1)),
+                   transforms.BatchNorm(d)]
+    stack = transforms.CompositeTransform(layers)
+    ref = copy.deepcopy(stack).double().train()
+    gpu = copy.deepcopy(stack).to(device).train()
+    x = torch.randn(n, d) * 1.3 + 0.4
+
+    v, total = x.double(), torch.zeros(n, dtype=torch.float64)
+    for t in ref._transforms:
+        if isinstance(t, transforms.BatchNorm):
+            mean, var = v.mean(0), v.var(0)
+            v, lad = t.weight * ((v - mean) / torch.sqrt(var + t.eps)) + t.bias, (torch.log(t.weight) - 0.5 * torch.log(var + t.eps)).sum().expand(n)
+        else:
+            v, lad = O.transform_apply(t, v)
+        total = total + lad
+    loss_ref = (v ** 2).sum(1).mean() - total.mean()
+    loss_ref.backward()
+
+    y, lad = gpu(x.to(device))
+    loss = (y ** 2).sum(1).mean() - lad.mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4 * max(1.0, abs(float(loss_ref.detach())))
+    for (name, p_ref), (_, p) in zip(ref.named_parameters(), gpu.named_parameters()):
+        if p_ref.grad is None:
+            continue
+        scale = max(1e-5, float(p_ref.grad.abs().max()))
+        # (some gradients are exactly zero in exact arithmetic, e.g. of a bias that the next layer's mean
+        # subtraction removes: absolute floor at the float32 noise of the loss)
+        assert p.grad is not None and maxdiff(p.grad.cpu().double(), p_ref.grad) <= 1e-3 * scale + 1e-6, name
+    bn = [t for t in gpu._transforms if isinstance(t, transforms.BatchNorm)][0]
+    assert float(bn.running_var.abs().sum()) > 0      # running statistics were updated
+    with torch.no_grad():
+        gpu.eval()
+        y_eval, _ = gpu(x.to(device))                 # eval mode, no autograd: the HIP kernel with running statistics
+        back, _ = gpu.inverse(y_eval)
+    assert maxdiff(back, x) <= 1e-4 * max(1.0, float(x.abs().max()))
