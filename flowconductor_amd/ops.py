@@ -1038,6 +1038,77 @@ def elementwise(inputs, kind, inverse=False, aux=None, p=(0.0, 0.0, 0.0, 0.0), r
 
 # ---- sum of sigmoids ------------------------------------------------------------------------------
 
+class _TorchGradFunction(torch.autograd.Function):
+    """Forward by a HIP kernel, gradients by torch.autograd walking the same map written in torch ops on the device
+    (for bijectors without a backward kernel; both evaluate f at the same point, so the gradient is f's)."""
+
+    @staticmethod
+    def forward(ctx, hip_fn, expr_fn, *tensors):
+        with torch.no_grad():
+            outputs, logabsdet = hip_fn(*tensors)
+        ctx.expr_fn = expr_fn
+        ctx.save_for_backward(*tensors)
+        return outputs, logabsdet
+
+    @staticmethod
+    def backward(ctx, grad_outputs, grad_logabsdet):
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(True) for t in ctx.saved_tensors]
+            outputs, logabsdet = ctx.expr_fn(*ins)
+            if grad_outputs is None:
+                grad_outputs = torch.zeros_like(outputs)
+            if grad_logabsdet is None:
+                grad_logabsdet = torch.zeros_like(logabsdet)
+            grads = torch.autograd.grad((outputs, logabsdet), ins, (grad_outputs, grad_logabsdet), allow_unused=True)
+        return (None, None) + tuple(grads)
+
+
+def _sos_expression(n_sigmoids, offset, log_scale_postact=0.0, eps=1e-6):
+    """Sum of sigmoids + extended softplus in torch ops (adaptive_sigmoids.py:108-142, nonlinearities.py:519-552) on
+    ``x [N, D]`` and raw parameters ``[N or 1, D, 3S+1]`` = [shift | log-scale | softmax logits | softplus shift]."""
+    from torch.nn import functional as F
+
+    def expr(x, raw):
+        raw = raw.reshape(-1, x.shape[1], 3 * n_sigmoids + 1)
+        shift_pre, log_scale_pre, raw_softmax, esp_raw = torch.split(raw, [n_sigmoids] * 3 + [1], dim=-1)
+        soft_max = F.softmax(raw_softmax, dim=-1) + eps
+        soft_max = soft_max / soft_max.sum(-1, keepdim=True)
+        post = math.exp(log_scale_postact) * soft_max
+        scale = torch.sigmoid(log_scale_pre) * (10.0 - 0.1) + 0.1
+        pre = scale * (x.unsqueeze(-1) - torch.tanh(shift_pre) * 10)
+        y_sos = (post * torch.sigmoid(pre)).sum(-1) / post.sum(-1)
+        lj_sos = torch.logsumexp(torch.log(post) + torch.log(scale) + (pre - 2 * F.softplus(pre)), -1)
+        s = F.softplus(esp_raw[..., 0]) + 1e-1
+        y_esp = F.softplus(x - s) - F.softplus(-(x + s))
+        lj_esp = torch.logaddexp(x - torch.logaddexp(s, x), -F.softplus(s + x))
+        return y_sos + y_esp - offset, torch.logaddexp(lj_sos, lj_esp).sum(-1)
+
+    return expr
+
+
+def sum_of_sigmoids_autograd(inputs, raw_params, n_sigmoids, inverse=False, offset=0.0, iterations=50, lim=120.0,
+                             shared_params=False):
+    """``sum_of_sigmoids``; with autograd on, the kernel's forward sits behind a node whose gradients come from the
+    same map in torch ops, and the inverse goes through ``_inverse_through_forward``."""
+    if not (torch.is_grad_enabled() and (inputs.requires_grad or raw_params.requires_grad)):
+        return sum_of_sigmoids(inputs, raw_params, n_sigmoids, inverse=inverse, offset=offset, iterations=iterations,
+                               lim=lim, shared_params=shared_params)
+    expr = _sos_expression(n_sigmoids, offset)
+
+    def hip_forward(x, raw):
+        return sum_of_sigmoids(x, raw, n_sigmoids, offset=offset, shared_params=shared_params)
+
+    def forward_fn(x, raw):
+        return _TorchGradFunction.apply(hip_forward, expr, x, raw)
+
+    if not inverse:
+        return forward_fn(_prep_2d(inputs), raw_params)
+    return _inverse_through_forward(
+        forward_fn, lambda x, raw: sum_of_sigmoids(x, raw, n_sigmoids, inverse=True, offset=offset,
+                                                   iterations=iterations, lim=lim, shared_params=shared_params),
+        _prep_2d(inputs), raw_params)
+
+
 def sum_of_sigmoids(inputs, raw_params, n_sigmoids, inverse=False, offset=0.0, iterations=50, lim=120.0,
                     log_scale_postact=0.0, shared_params=False):
     """Sum-of-sigmoids bijector (reference adaptive_sigmoids.py:108-142; inverse base.py:23-83).

@@ -15,6 +15,8 @@ class SumOfSigmoids(MonotonicTransform):
     (``[1, F, S]``), ``extended_softplus.shift`` (``[1, F]``), ``log_scale_postact`` (``[1]``, frozen).
     With ``raw_params`` (``[N, F, 3S+1]``) the same tensors are per-sample views of it."""
 
+    _HIP_AUTOGRAD = True    # forward kernel behind an autograd node (gradients from the same map in torch ops)
+
     PREACT_SCALE_MIN = .1
     PREACT_SCALE_MAX = 10.
     PREACT_SHIFT_MAX = 10
@@ -51,12 +53,12 @@ class SumOfSigmoids(MonotonicTransform):
         self._raw = raw_params
 
     def _kernel(self, inputs, inverse, offset=0.0):
-        raw = self._raw if self._raw is not None else self.get_raw_params().detach()
+        raw = self._raw if self._raw is not None else self.get_raw_params()
         shared = raw.shape[0] == 1
         if not shared and raw.shape[0] != inputs.shape[0]:
             raise ValueError("raw_params batch %d != inputs batch %d" % (raw.shape[0], inputs.shape[0]))
-        return ops.sum_of_sigmoids(inputs, raw, self.n_sigmoids, inverse=inverse, offset=offset,
-                                   iterations=self.num_iterations, lim=self.lim, shared_params=shared)
+        return ops.sum_of_sigmoids_autograd(inputs, raw, self.n_sigmoids, inverse=inverse, offset=offset,
+                                            iterations=self.num_iterations, lim=self.lim, shared_params=shared)
 
     def forward(self, inputs, context=None):
         return self._kernel(inputs, inverse=False)

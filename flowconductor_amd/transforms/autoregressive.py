@@ -308,10 +308,10 @@ class MaskedSumOfSigmoidsTransform(AutoregressiveTransform):
         return 3 * self.n_sigmoids + 1
 
     def _elementwise_forward(self, inputs, autoregressive_params):
-        return ops.sum_of_sigmoids(inputs, autoregressive_params, self.n_sigmoids, inverse=False, offset=0.5)
+        return ops.sum_of_sigmoids_autograd(inputs, autoregressive_params, self.n_sigmoids, inverse=False, offset=0.5)
 
     def _elementwise_inverse(self, inputs, autoregressive_params):
-        return ops.sum_of_sigmoids(inputs, autoregressive_params, self.n_sigmoids, inverse=True, offset=0.5)
+        return ops.sum_of_sigmoids_autograd(inputs, autoregressive_params, self.n_sigmoids, inverse=True, offset=0.5)
 
 
 def _ar_divisor(net):

@@ -416,10 +416,10 @@ class ConditionalSumOfSigmoidsTransform(ConditionalTransform):
         return 3 * self.n_sigmoids + 1
 
     def _forward_given_params(self, inputs, autoregressive_params):
-        return ops.sum_of_sigmoids(inputs, autoregressive_params, self.n_sigmoids, inverse=False)
+        return ops.sum_of_sigmoids_autograd(inputs, autoregressive_params, self.n_sigmoids, inverse=False)
 
     def _inverse_given_params(self, inputs, autoregressive_params):
-        return ops.sum_of_sigmoids(inputs, autoregressive_params, self.n_sigmoids, inverse=True)
+        return ops.sum_of_sigmoids_autograd(inputs, autoregressive_params, self.n_sigmoids, inverse=True)
 
 
 class ConditionalPlanarTransform(ConditionalTransform):
