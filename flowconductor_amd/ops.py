@@ -908,6 +908,55 @@ def linear(inputs, a, b=None, bias=None, mode=LINEAR_DENSE):
     return y
 
 
+def _householder_expression(reverse):
+    """orthogonal.py:144-194 in torch ops: out -= (out . q_i) (2 / |q_i|^2) q_i, shared ``q [K, D]``."""
+    def expr(x, q):
+        out = x
+        order = range(q.shape[0] - 1, -1, -1) if reverse else range(q.shape[0])
+        for i in order:
+            qi = q[i]
+            out = out - (out @ qi).unsqueeze(-1) * (2.0 / (qi @ qi)) * qi
+        return out, x.new_zeros(x.shape[0])
+    return expr
+
+
+def householder_autograd(inputs, q_vectors, reverse=False):
+    """``householder`` (shared q-vectors) -> (outputs, zeros); under autograd the kernel sits behind a node whose
+    gradients come from the reflections in torch ops."""
+    if torch.is_grad_enabled() and (inputs.requires_grad or q_vectors.requires_grad) and q_vectors.dim() == 2:
+        return _TorchGradFunction.apply(lambda x, q: (householder(x, q, reverse=reverse), x.new_zeros(x.shape[0])),
+                                        _householder_expression(reverse), _prep_2d(inputs), q_vectors)
+    return householder(inputs, q_vectors, reverse=reverse), inputs.new_zeros(inputs.shape[0])
+
+
+def planar_autograd(inputs, w, u_hat, b):
+    """Shared-parameter planar flow (no_analytic_inv/planar.py:30-49) with an autograd node when needed."""
+    def expr(x, w_, u_, b_):
+        a = x @ w_.T + b_
+        t = torch.tanh(a)
+        lad = torch.log(1e-7 + (1 + (u_ @ ((1 - t ** 2) * w_).T)).abs())
+        return x + u_ * t, lad.reshape(-1)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (inputs, w, u_hat, b)):
+        return _TorchGradFunction.apply(lambda x, w_, u_, b_: planar(x, w_, u_, b_), expr, _prep_2d(inputs), w, u_hat, b)
+    return planar(inputs, w, u_hat, b)
+
+
+def sylvester_autograd(inputs, q_vectors, r1, r2, bias):
+    """Shared-parameter Sylvester flow (no_analytic_inv/planar.py:144-166) with an autograd node when needed."""
+    refl_inv, refl_fwd = _householder_expression(True), _householder_expression(False)
+
+    def expr(x, q, r1_, r2_, b_):
+        qtz, _ = refl_inv(x, q)
+        pre = qtz @ r1_.T + b_
+        act = torch.tanh(pre)
+        out, _ = refl_fwd(act @ r2_.T, q)
+        diag = 1 + (1 - act ** 2) * (torch.diag(r1_) * torch.diag(r2_))
+        return x + out, torch.log(diag).sum(-1)
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (inputs, q_vectors, r1, r2, bias)):
+        return _TorchGradFunction.apply(lambda *a: sylvester(*a), expr, _prep_2d(inputs), q_vectors, r1, r2, bias)
+    return sylvester(inputs, q_vectors, r1, r2, bias)
+
+
 def sylvester(inputs, q_vectors, r1, r2, bias):
     """Sylvester flow forward + logabsdet (reference no_analytic_inv/planar.py:144-166).
 
@@ -1059,7 +1108,8 @@ class _TorchGradFunction(torch.autograd.Function):
                 grad_outputs = torch.zeros_like(outputs)
             if grad_logabsdet is None:
                 grad_logabsdet = torch.zeros_like(logabsdet)
-            grads = torch.autograd.grad((outputs, logabsdet), ins, (grad_outputs, grad_logabsdet), allow_unused=True)
+            pairs = [(o, g) for o, g in ((outputs, grad_outputs), (logabsdet, grad_logabsdet)) if o.requires_grad]
+            grads = torch.autograd.grad([o for o, _ in pairs], ins, [g for _, g in pairs], allow_unused=True)
         return (None, None) + tuple(grads)
 
 

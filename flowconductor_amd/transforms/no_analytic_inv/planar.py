@@ -23,10 +23,10 @@ class PlanarTransform(Transform):
         self.b = nn.Parameter(torch.randn(1).normal_(0, 0.1))
         self.u = nn.Parameter(torch.randn(1, features).normal_(0, 0.1))
 
+    _HIP_AUTOGRAD = True
+
     def forward(self, inputs, context=None):
-        with torch.no_grad():
-            u_hat = self.get_constrained_u()
-        return ops.planar(inputs, self.w, u_hat, self.b)
+        return ops.planar_autograd(inputs, self.w, self.get_constrained_u(), self.b)
 
     def forward_logabsdet(self, inputs, context=None):
         return self.forward(inputs, context)[1].unsqueeze(-1)
@@ -99,7 +99,11 @@ class SylvesterTransform(Transform):
             self._mm_cache = (key, ops.pack_sylvester(self.Q_orth.q_vectors, self._create_R1(), self._create_R2()))
         return self._mm_cache[1]
 
+    _HIP_AUTOGRAD = True
+
     def forward(self, inputs, context=None):
+        if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return ops.sylvester_autograd(inputs, self.Q_orth.q_vectors, self._create_R1(), self._create_R2(), self.bias)
         with torch.no_grad():
             n = inputs.shape[0]
             if (inputs.dim() == 2 and inputs.is_cuda and ops.sylvester_mm_supported(n, self.features)

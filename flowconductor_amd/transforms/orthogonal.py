@@ -22,12 +22,13 @@ def _paired_unit_vectors(num_transforms, features):
 
 
 def _apply(inputs, q_vectors, reverse):
-    outputs = ops.householder(inputs, q_vectors, reverse=reverse)
-    return outputs, inputs.new_zeros(inputs.shape[0])
+    return ops.householder_autograd(inputs, q_vectors, reverse=reverse)
 
 
 class HouseholderSequence(Transform):
     """A sequence of Householder transforms with a learnable ``q_vectors [K, D]`` parameter."""
+
+    _HIP_AUTOGRAD = True
 
     def __init__(self, features, num_transforms):
         if not check.is_positive_int(features):

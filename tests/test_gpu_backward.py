@@ -325,13 +325,13 @@ def test_nsf_style_stack_trains_through_actnorm_and_lu(device):
 
 
 def test_transforms_without_backward_refuse_to_run_under_autograd(device):
-    """Layers whose kernels have no backward (Householder, Sylvester, planar, batch-shared CDFs, batch norm) raise with
-    autograd on instead of returning detached outputs -- and run under no_grad or when frozen."""
+    """Layers whose kernels have no backward (the batch-shared CDFs) raise with autograd on instead of returning
+    detached outputs -- and run under no_grad or when frozen."""
     from flowconductor_amd import transforms as T
 
-    x = torch.randn(64, 8, device=device)
-    for t in (T.HouseholderSequence(8, 3), T.SylvesterTransform(8, num_householder=2, device="cpu"), T.PlanarTransform(8),
-              T.PiecewiseRationalQuadraticCDF([8], num_bins=4, tails="linear", tail_bound=3.0)):
+    x = torch.rand(64, 8, device=device) * 0.9 + 0.05
+    for t in (T.PiecewiseRationalQuadraticCDF([8], num_bins=4, tails="linear", tail_bound=3.0),
+              T.PiecewiseLinearCDF([8], num_bins=4)):
         t = t.to(device)
         with pytest.raises(RuntimeError, match="no backward kernel"):
             t(x)
@@ -439,3 +439,45 @@ def test_sum_of_sigmoids_gradients(device):
     xi, ladi = tg.inverse(z)
     (xi.sum() + ladi.sum()).backward()
     assert z.grad is not None and torch.isfinite(z.grad).all() and tg.shift_preact.grad is not None
+
+
+@pytest.mark.parametrize("kind", ["householder", "planar", "sylvester"])
+def test_orthogonal_and_planar_family_gradients_by_finite_differences(kind, device):
+    """Householder / planar / Sylvester layers under autograd (kernel forward, gradients from the same map in torch ops)
+    against central finite differences of the ORACLE's float64 forward -- an independent check of those expressions."""
+    from flowconductor_amd import transforms as T
+
+    torch.manual_seed(61)
+    d, n = 6, 200
+    t = {"householder": lambda: T.HouseholderSequence(d, 3), "planar": lambda: T.PlanarTransform(d),
+         "sylvester": lambda: T.SylvesterTransform(d, num_householder=2, device="cpu")}[kind]()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.add_(torch.randn_like(p) * 0.3)
+    x = torch.randn(n, d)
+    gy, gl = torch.randn(n, d).double(), torch.randn(n).double()
+
+    def loss64(module):
+        with torch.no_grad():
+            y, lad = O.transform_apply(module, x.double())
+        return float((y * gy).sum() + (lad * gl).sum())
+
+    tg = copy.deepcopy(t).to(device).train()
+    xg = x.to(device).requires_grad_(True)
+    y, lad = tg(xg)
+    ((y * gy.float().to(device)).sum() + (lad * gl.float().to(device)).sum()).backward()
+    t64 = copy.deepcopy(t).double()
+    g = torch.Generator().manual_seed(1)
+    for (name, p64), (_, pg) in zip(t64.named_parameters(), tg.named_parameters()):
+        assert pg.grad is not None, name
+        flat, gflat = p64.data.view(-1), pg.grad.cpu().double().view(-1)
+        for idx in torch.randperm(flat.numel(), generator=g)[:4].tolist():
+            old, h = float(flat[idx]), 1e-5
+            flat[idx] = old + h
+            up = loss64(t64)
+            flat[idx] = old - h
+            down = loss64(t64)
+            flat[idx] = old
+            fd = (up - down) / (2 * h)
+            assert abs(float(gflat[idx]) - fd) <= 2e-3 * max(1.0, abs(fd)) + 1e-3, (name, idx, float(gflat[idx]), fd)
+    assert xg.grad is not None and torch.isfinite(xg.grad).all()

@@ -262,6 +262,6 @@ def test_user_defined_transforms_are_left_alone():
     y, lad = t(torch.ones(4, 3))
     (y.sum() + lad.sum()).backward()
     assert t.log_s.grad is not None
-    assert getattr(T.HouseholderSequence.forward, "_guarded", False)
+    assert getattr(T.PiecewiseLinearCDF.forward, "_guarded", False)
     with pytest.raises(RuntimeError, match="no backward kernel"):
-        T.HouseholderSequence(3, 2)(torch.ones(4, 3))
+        T.PiecewiseLinearCDF([3], num_bins=4)(torch.ones(4, 3) * 0.5)
