@@ -179,10 +179,22 @@ class PiecewiseRationalQuadraticCDF(Transform):
             self.unnormalized_heights = nn.Parameter(torch.rand(*shape, num_bins))
             self.unnormalized_derivatives = nn.Parameter(torch.rand(*shape, num_derivatives))
 
+    _HIP_AUTOGRAD = True
+
     def _spline(self, inputs, inverse=False):
+        flat = _flatten_items(inputs)
+        if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training: the shared row expanded to per-sample rows (the backward kernel's layout); autograd sums the
+            # row gradients back through the expand
+            rows = torch.cat((self.unnormalized_widths, self.unnormalized_heights, self.unnormalized_derivatives),
+                             dim=-1).reshape(1, -1).expand(flat.shape[0], -1).contiguous()
+            outputs, logabsdet = ops.rq_spline_autograd(
+                flat, rows, None, num_bins=self.num_bins, tails=self.tails, tail_bound=self.tail_bound,
+                min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                min_derivative=self.min_derivative, inverse=inverse)
+            return outputs.reshape(inputs.shape), logabsdet
         rows = torch.cat((self.unnormalized_widths.detach(), self.unnormalized_heights.detach(),
                           self.unnormalized_derivatives.detach()), dim=-1).reshape(-1)
-        flat = _flatten_items(inputs)
         outputs, logabsdet = ops.rq_spline(
             flat, rows, None, num_bins=self.num_bins, tails=self.tails, tail_bound=self.tail_bound,
             min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,

@@ -330,8 +330,7 @@ def test_transforms_without_backward_refuse_to_run_under_autograd(device):
     from flowconductor_amd import transforms as T
 
     x = torch.rand(64, 8, device=device) * 0.9 + 0.05
-    for t in (T.PiecewiseRationalQuadraticCDF([8], num_bins=4, tails="linear", tail_bound=3.0),
-              T.PiecewiseLinearCDF([8], num_bins=4)):
+    for t in (T.PiecewiseQuadraticCDF([8], num_bins=4), T.PiecewiseLinearCDF([8], num_bins=4)):
         t = t.to(device)
         with pytest.raises(RuntimeError, match="no backward kernel"):
             t(x)
@@ -481,3 +480,27 @@ def test_orthogonal_and_planar_family_gradients_by_finite_differences(kind, devi
             fd = (up - down) / (2 * h)
             assert abs(float(gflat[idx]) - fd) <= 2e-3 * max(1.0, abs(fd)) + 1e-3, (name, idx, float(gflat[idx]), fd)
     assert xg.grad is not None and torch.isfinite(xg.grad).all()
+
+
+def test_rq_cdf_trains(device):
+    """Batch-shared RQ-spline CDF under autograd: gradients of the shared parameters against torch.autograd on the
+    oracle's spline with the row expanded, float64."""
+    from flowconductor_amd import transforms as T
+
+    torch.manual_seed(67)
+    d, k, n = 5, 6, 300
+    t = T.PiecewiseRationalQuadraticCDF([d], num_bins=k, tails="linear", tail_bound=3.0)
+    x = torch.randn(n, d) * 1.3
+    gy, gl = torch.randn(n, d), torch.randn(n)
+    leaves = [p.detach().double().clone().requires_grad_(True)
+              for p in (t.unnormalized_widths, t.unnormalized_heights, t.unnormalized_derivatives)]
+    rows = torch.cat(leaves, dim=-1).reshape(1, d, -1).expand(n, d, 3 * k - 1) * 1.0
+    out, lad_e = O.rq_from_rows(x.double(), rows, k, "linear", 3.0, False)
+    ((out * gy.double()).sum() + (lad_e.sum(dim=1) * gl.double()).sum()).backward()
+    tg = copy.deepcopy(t).to(device).train()
+    y, lad = tg(x.to(device))
+    ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
+    assert maxdiff(y.detach(), out.detach()) <= 2e-5 * max(1.0, float(out.detach().abs().max()))
+    for got, ref in zip((tg.unnormalized_widths, tg.unnormalized_heights, tg.unnormalized_derivatives), leaves):
+        scale = max(1e-5, float(ref.grad.abs().max()))
+        assert got.grad is not None and maxdiff(got.grad.cpu().double(), ref.grad) <= 1e-3 * scale + 1e-6
