@@ -1197,6 +1197,108 @@ def spline_multiplier(kind, num_bins, tails):
     return num_bins * 2 + 2
 
 
+def _piecewise_expression(cols, *, kind, num_bins, tails=None, tail_bound=1.0, left=0.0, right=1.0, bottom=0.0,
+                          top=1.0, min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
+                          width_divisor=1.0, height_divisor=1.0):
+    """Forward direction of the linear / quadratic / cubic splines in torch ops (splines/linear.py:38-105,
+    quadratic.py:55-159, cubic.py:63-150 with their ``unconstrained_*`` wrappers) on ``x [N, D]`` and per-sample rows
+    ``[N, d_t * P]``: the gradient source for ``fc_piecewise_spline`` under autograd."""
+    from torch.nn import functional as F
+
+    k = num_bins
+    if tails == "linear":
+        left, right, bottom, top = -tail_bound, tail_bound, -tail_bound, tail_bound
+
+    def bin_index(edges, v):
+        edges = edges.clone()
+        edges[..., -1] += 1e-6                    # utils/torchutils.py:147-149
+        return (torch.sum(v[..., None] >= edges, dim=-1) - 1).clamp(0, k - 1)[..., None]
+
+    def cum(v):
+        c = torch.cumsum(v, dim=-1)
+        c = torch.cat((c[..., :-1], torch.ones_like(c[..., -1:])), dim=-1)
+        return F.pad(c, pad=(1, 0), mode="constant", value=0.0)
+
+    def spline(u, rows):
+        if kind == SPLINE_LINEAR:
+            pdf = F.softmax(rows, dim=-1)
+            cdf = cum(pdf)
+            pos = u * k
+            idx = torch.floor(pos).long().clamp(0, k - 1)[..., None]
+            pdf_k = pdf.gather(-1, idx)[..., 0]
+            out = cdf.gather(-1, idx)[..., 0] + (pos - idx[..., 0].to(u.dtype)) * pdf_k
+            return out.clamp(0, 1), torch.log(pdf_k) - math.log(1.0 / k)
+        widths = min_bin_width + (1 - min_bin_width * k) * F.softmax(rows[..., :k] / width_divisor, dim=-1)
+        if kind == SPLINE_QUADRATIC:
+            uh = F.softplus(rows[..., k:] / height_divisor) + 1e-3
+            if uh.shape[-1] == k - 1:
+                fw, lw = 0.5 * widths[..., 0], 0.5 * widths[..., -1]
+                num = (0.5 * fw * uh[..., 0] + 0.5 * lw * uh[..., -1]
+                       + torch.sum(((uh[..., :-1] + uh[..., 1:]) / 2) * widths[..., 1:-1], dim=-1))
+                const = (num / (1 - 0.5 * fw - 0.5 * lw))[..., None]
+                uh = torch.cat([const, uh, const], dim=-1)
+            area = torch.sum(((uh[..., :-1] + uh[..., 1:]) / 2) * widths, dim=-1)[..., None]
+            heights = min_bin_height + (1 - min_bin_height) * (uh / area)
+            left_cdf = cum(((heights[..., :-1] + heights[..., 1:]) / 2) * widths)
+            locations = cum(widths)
+            idx = bin_index(locations, u)
+            w_k = widths.gather(-1, idx)[..., 0]
+            hl, hr = heights.gather(-1, idx)[..., 0], heights.gather(-1, idx + 1)[..., 0]
+            alpha = (u - locations.gather(-1, idx)[..., 0]) / w_k
+            out = 0.5 * (hr - hl) * w_k * alpha ** 2 + hl * w_k * alpha + left_cdf.gather(-1, idx)[..., 0]
+            return out.clamp(0, 1), torch.log(alpha * (hr - hl) + hl)
+        heights = min_bin_height + (1 - min_bin_height * k) * F.softmax(rows[..., k:2 * k] / height_divisor, dim=-1)
+        cumwidths, cumheights = cum(widths), cum(heights)
+        slopes = heights / widths
+        m1 = torch.min(slopes[..., :-1].abs(), slopes[..., 1:].abs())
+        m2 = 0.5 * (widths[..., 1:] * slopes[..., :-1] + widths[..., :-1] * slopes[..., 1:]) / (
+            widths[..., :-1] + widths[..., 1:])
+        d_left = torch.sigmoid(rows[..., 2 * k:2 * k + 1]) * 3 * slopes[..., :1]
+        d_right = torch.sigmoid(rows[..., 2 * k + 1:2 * k + 2]) * 3 * slopes[..., -1:]
+        derivs = torch.cat([d_left, torch.min(m1, m2) * (torch.sign(slopes[..., :-1]) + torch.sign(slopes[..., 1:])),
+                            d_right], dim=-1)
+        a = (derivs[..., :-1] + derivs[..., 1:] - 2 * slopes) / widths ** 2
+        b = (3 * slopes - 2 * derivs[..., :-1] - derivs[..., 1:]) / widths
+        idx = bin_index(cumwidths, u)
+        ia, ib, ic, id_ = (t.gather(-1, idx)[..., 0] for t in (a, b, derivs[..., :-1], cumheights[..., :-1]))
+        sft = u - cumwidths.gather(-1, idx)[..., 0]
+        return ia * sft ** 3 + ib * sft ** 2 + ic * sft + id_, torch.log(3 * ia * sft ** 2 + 2 * ib * sft + ic)
+
+    def expr(x, params):
+        xt = x if cols is None else x[:, cols.long()]
+        rows = params.reshape(xt.shape[0], xt.shape[1], -1)
+        inside = (xt >= left) & (xt <= right) if tails == "linear" else torch.ones_like(xt, dtype=torch.bool)
+        u = ((xt.clamp(left, right) if tails == "linear" else xt) - left) / (right - left)
+        out, lad = spline(u, rows)
+        out = out * (top - bottom) + bottom
+        out = torch.where(inside, out, xt)
+        lad = torch.where(inside, lad, torch.zeros_like(lad))
+        if cols is None:
+            return out, lad.sum(-1)
+        y = x.clone()
+        y[:, cols.long()] = out
+        return y, lad.sum(-1)
+
+    return expr
+
+
+def piecewise_spline_autograd(inputs, params, cols=None, *, inverse=False, shared_params=False, **kw):
+    """``piecewise_spline``; under autograd (per-sample parameters) the kernel's forward sits behind a node whose
+    gradients come from the same spline in torch ops, the inverse goes through ``_inverse_through_forward``."""
+    if not (torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad)) or shared_params:
+        return piecewise_spline(inputs, params, cols, inverse=inverse, shared_params=shared_params, **kw)
+    x = _prep_2d(inputs)
+    cols_dev = _as_cols(cols, x.device)
+    expr = _piecewise_expression(cols_dev, **kw)
+
+    def forward_fn(v, p):
+        return _TorchGradFunction.apply(lambda a, b: piecewise_spline(a, b, cols, **kw), expr, v, p)
+
+    if not inverse:
+        return forward_fn(x, params)
+    return _inverse_through_forward(forward_fn, lambda a, b: piecewise_spline(a, b, cols, inverse=True, **kw), x, params)
+
+
 def piecewise_spline(inputs, params, cols=None, *, kind, num_bins, tails=None, tail_bound=1.0,
                      left=0.0, right=1.0, bottom=0.0, top=1.0, min_bin_width=DEFAULT_MIN_BIN_WIDTH,
                      min_bin_height=DEFAULT_MIN_BIN_HEIGHT, width_divisor=1.0, height_divisor=1.0,

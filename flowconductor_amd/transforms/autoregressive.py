@@ -334,7 +334,7 @@ class MaskedPiecewiseLinearAutoregressiveTransform(AutoregressiveTransform):
         return self.num_bins
 
     def _elementwise(self, inputs, autoregressive_params, inverse=False):
-        return ops.piecewise_spline(inputs, autoregressive_params, None, kind=ops.SPLINE_LINEAR,
+        return ops.piecewise_spline_autograd(inputs, autoregressive_params, None, kind=ops.SPLINE_LINEAR,
                                     num_bins=self.num_bins, inverse=inverse)
 
     def _elementwise_forward(self, inputs, autoregressive_params):
@@ -371,7 +371,7 @@ class MaskedPiecewiseQuadraticAutoregressiveTransform(AutoregressiveTransform):
     def _elementwise(self, inputs, autoregressive_params, inverse=False):
         if self.tails not in (None, "linear"):
             raise ValueError
-        return ops.piecewise_spline(inputs, autoregressive_params, None, kind=ops.SPLINE_QUADRATIC,
+        return ops.piecewise_spline_autograd(inputs, autoregressive_params, None, kind=ops.SPLINE_QUADRATIC,
                                     num_bins=self.num_bins, tails=self.tails, tail_bound=self.tail_bound,
                                     min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                                     width_divisor=_ar_divisor(self.autoregressive_net), inverse=inverse)
@@ -400,7 +400,7 @@ class MaskedPiecewiseCubicAutoregressiveTransform(AutoregressiveTransform):
 
     def _elementwise(self, inputs, autoregressive_params, inverse=False):
         div = _ar_divisor(self.autoregressive_net)
-        return ops.piecewise_spline(inputs, autoregressive_params, None, kind=ops.SPLINE_CUBIC,
+        return ops.piecewise_spline_autograd(inputs, autoregressive_params, None, kind=ops.SPLINE_CUBIC,
                                     num_bins=self.num_bins, width_divisor=div, height_divisor=div,
                                     inverse=inverse)
 

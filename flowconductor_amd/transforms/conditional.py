@@ -309,7 +309,7 @@ class PiecewiseLinearConditionalTransform(ConditionalTransform):
         return self.num_bins
 
     def _elementwise(self, inputs, autoregressive_params, inverse=False):
-        return ops.piecewise_spline(inputs, autoregressive_params, None, kind=ops.SPLINE_LINEAR,
+        return ops.piecewise_spline_autograd(inputs, autoregressive_params, None, kind=ops.SPLINE_LINEAR,
                                     num_bins=self.num_bins, left=-4.0, right=4.0, bottom=-4.0, top=4.0,
                                     inverse=inverse)
 

@@ -419,7 +419,7 @@ class PiecewiseLinearCouplingTransform(PiecewiseCouplingTransform):
         return self.num_bins
 
     def _coupling_kernel(self, inputs, transform_params, inverse):
-        return ops.piecewise_spline(inputs, transform_params, self._cols(inputs.device), kind=ops.SPLINE_LINEAR,
+        return ops.piecewise_spline_autograd(inputs, transform_params, self._cols(inputs.device), kind=ops.SPLINE_LINEAR,
                                     num_bins=self.num_bins, tails=self.tails, tail_bound=self.tail_bound,
                                     inverse=inverse)
 
@@ -451,7 +451,7 @@ class PiecewiseQuadraticCouplingTransform(PiecewiseCouplingTransform):
 
     def _coupling_kernel(self, inputs, transform_params, inverse):
         div = _divisor_if_hidden_features(self.transform_net)
-        return ops.piecewise_spline(inputs, transform_params, self._cols(inputs.device),
+        return ops.piecewise_spline_autograd(inputs, transform_params, self._cols(inputs.device),
                                     kind=ops.SPLINE_QUADRATIC, num_bins=self.num_bins, tails=self.tails,
                                     tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                                     min_bin_height=self.min_bin_height, width_divisor=div, height_divisor=div,
@@ -485,7 +485,7 @@ class PiecewiseCubicCouplingTransform(PiecewiseCouplingTransform):
 
     def _coupling_kernel(self, inputs, transform_params, inverse):
         div = _divisor_if_hidden_features(self.transform_net)
-        return ops.piecewise_spline(inputs, transform_params, self._cols(inputs.device), kind=ops.SPLINE_CUBIC,
+        return ops.piecewise_spline_autograd(inputs, transform_params, self._cols(inputs.device), kind=ops.SPLINE_CUBIC,
                                     num_bins=self.num_bins, tails=self.tails, tail_bound=self.tail_bound,
                                     min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
                                     width_divisor=div, height_divisor=div, inverse=inverse)

@@ -213,13 +213,22 @@ class _SharedSplineCDF(Transform):
     one ``[prod(shape), multiplier]`` row set and run the spline kernel with ``shared_params``."""
 
     _kind = None
+    _HIP_AUTOGRAD = True
 
-    def _rows(self):
+    def _rows(self, detach=True):
         raise NotImplementedError()
 
     def _spline(self, inputs, inverse=False):
         flat = _flatten_items(inputs)
-        outputs, logabsdet = ops.piecewise_spline(
+        kw = dict(kind=self._kind, num_bins=self.num_bins, tails=self.tails, tail_bound=self.tail_bound,
+                  min_bin_width=getattr(self, "min_bin_width", ops.DEFAULT_MIN_BIN_WIDTH),
+                  min_bin_height=getattr(self, "min_bin_height", ops.DEFAULT_MIN_BIN_HEIGHT))
+        if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())):
+            # training: the shared row set expanded to per-sample rows; autograd sums their gradients back
+            rows = self._rows(detach=False).reshape(1, -1).expand(flat.shape[0], -1).contiguous()
+            outputs, logabsdet = ops.piecewise_spline_autograd(flat, rows, None, inverse=inverse, **kw)
+            return outputs.reshape(inputs.shape), logabsdet
+        outputs, logabsdet = ops.piecewise_spline_autograd(
             flat, self._rows(), None, kind=self._kind, num_bins=self.num_bins, tails=self.tails,
             tail_bound=self.tail_bound, min_bin_width=getattr(self, "min_bin_width", ops.DEFAULT_MIN_BIN_WIDTH),
             min_bin_height=getattr(self, "min_bin_height", ops.DEFAULT_MIN_BIN_HEIGHT), inverse=inverse,
@@ -245,8 +254,8 @@ class PiecewiseLinearCDF(_SharedSplineCDF):
         self.num_bins = num_bins
         self.unnormalized_pdf = nn.Parameter(torch.randn(*shape, num_bins))
 
-    def _rows(self):
-        return self.unnormalized_pdf.detach().reshape(-1)
+    def _rows(self, detach=True):
+        return (self.unnormalized_pdf.detach() if detach else self.unnormalized_pdf).reshape(-1)
 
 
 class PiecewiseQuadraticCDF(_SharedSplineCDF):
@@ -266,8 +275,9 @@ class PiecewiseQuadraticCDF(_SharedSplineCDF):
         n_heights = num_bins + 1 if tails is None else num_bins - 1
         self.unnormalized_heights = nn.Parameter(torch.randn(*shape, n_heights))
 
-    def _rows(self):
-        return torch.cat((self.unnormalized_widths.detach(), self.unnormalized_heights.detach()), dim=-1).reshape(-1)
+    def _rows(self, detach=True):
+        rows = torch.cat((self.unnormalized_widths, self.unnormalized_heights), dim=-1).reshape(-1)
+        return rows.detach() if detach else rows
 
 
 class PiecewiseCubicCDF(_SharedSplineCDF):
@@ -288,10 +298,10 @@ class PiecewiseCubicCDF(_SharedSplineCDF):
         self.unnorm_derivatives_left = nn.Parameter(torch.randn(*shape, 1))
         self.unnorm_derivatives_right = nn.Parameter(torch.randn(*shape, 1))
 
-    def _rows(self):
-        return torch.cat((self.unnormalized_widths.detach(), self.unnormalized_heights.detach(),
-                          self.unnorm_derivatives_left.detach(), self.unnorm_derivatives_right.detach()),
-                         dim=-1).reshape(-1)
+    def _rows(self, detach=True):
+        rows = torch.cat((self.unnormalized_widths, self.unnormalized_heights, self.unnorm_derivatives_left,
+                          self.unnorm_derivatives_right), dim=-1).reshape(-1)
+        return rows.detach() if detach else rows
 
 
 class ExtendedSoftplus(torch.nn.Module):

@@ -324,24 +324,39 @@ def test_nsf_style_stack_trains_through_actnorm_and_lu(device):
     (s.sum() + lq.sum()).backward()
 
 
-def test_transforms_without_backward_refuse_to_run_under_autograd(device):
-    """Layers whose kernels have no backward (the batch-shared CDFs) raise with autograd on instead of returning
-    detached outputs -- and run under no_grad or when frozen."""
+def test_batch_shared_cdfs_train(device):
+    """Batch-shared linear / quadratic / cubic CDFs under autograd (expanded rows through the spline node): gradients of
+    the shared parameters against central finite differences of the oracle's float64 forward."""
     from flowconductor_amd import transforms as T
 
-    x = torch.rand(64, 8, device=device) * 0.9 + 0.05
-    for t in (T.PiecewiseQuadraticCDF([8], num_bins=4), T.PiecewiseLinearCDF([8], num_bins=4)):
-        t = t.to(device)
-        with pytest.raises(RuntimeError, match="no backward kernel"):
-            t(x)
-        with torch.no_grad():
-            y, lad = t(x)
-        assert y.shape == x.shape and lad.shape == (64,)
-        t.requires_grad_(False)
-        for m in t.modules():
-            m.requires_grad_(False)
-        y2, _ = t(x)
-        assert torch.equal(y, y2)
+    torch.manual_seed(73)
+    d, n = 5, 200
+    x = torch.rand(n, d) * 0.9 + 0.05
+    gy, gl = torch.randn(n, d).double(), torch.randn(n).double()
+    for t in (T.PiecewiseLinearCDF([d], num_bins=4), T.PiecewiseQuadraticCDF([d], num_bins=4),
+              T.PiecewiseCubicCDF([d], num_bins=4)):
+        def loss64(module):
+            with torch.no_grad():
+                y, lad = O.transform_apply(module, x.double())
+            return float((y * gy).sum() + (lad * gl).sum())
+
+        tg = copy.deepcopy(t).to(device).train()
+        y, lad = tg(x.to(device))
+        ((y * gy.float().to(device)).sum() + (lad * gl.float().to(device)).sum()).backward()
+        t64 = copy.deepcopy(t).double()
+        g = torch.Generator().manual_seed(2)
+        for (name, p64), (_, pg) in zip(t64.named_parameters(), tg.named_parameters()):
+            assert pg.grad is not None, (type(t).__name__, name)
+            flat, gflat = p64.data.view(-1), pg.grad.cpu().double().view(-1)
+            for idx in torch.randperm(flat.numel(), generator=g)[:3].tolist():
+                old, h = float(flat[idx]), 1e-5
+                flat[idx] = old + h
+                up = loss64(t64)
+                flat[idx] = old - h
+                down = loss64(t64)
+                flat[idx] = old
+                fd = (up - down) / (2 * h)
+                assert abs(float(gflat[idx]) - fd) <= 3e-3 * max(1.0, abs(fd)) + 2e-3, (type(t).__name__, name, float(gflat[idx]), fd)
 
 
 def test_realnvp_with_batch_norm_trains(device):
@@ -504,3 +519,52 @@ def test_rq_cdf_trains(device):
     for got, ref in zip((tg.unnormalized_widths, tg.unnormalized_heights, tg.unnormalized_derivatives), leaves):
         scale = max(1e-5, float(ref.grad.abs().max()))
         assert got.grad is not None and maxdiff(got.grad.cpu().double(), ref.grad) <= 1e-3 * scale + 1e-6
+
+
+@pytest.mark.parametrize("kind", ["linear", "quadratic", "quadratic_tails", "cubic", "maf_quadratic", "maf_cubic"])
+def test_sibling_spline_layers_train(kind, device):
+    """Linear / quadratic / cubic spline layers under autograd: kernel forward behind a node whose gradients come from
+    the same spline in torch ops; parameter and input gradients against torch.autograd through the oracle in float64;
+    the inverse direction carries gradients too."""
+    from flowconductor_amd import transforms as T, utils
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(71)
+    d, n, k = 6, 300, 5
+    mask = utils.create_alternating_binary_mask(d)
+
+    def net(i, o):
+        return nets.ResidualNet(i, o, hidden_features=16, num_blocks=1)
+
+    unit = kind in ("linear", "quadratic", "cubic", "maf_cubic")
+    t = {"linear": lambda: T.PiecewiseLinearCouplingTransform(mask, net, num_bins=k),
+         "quadratic": lambda: T.PiecewiseQuadraticCouplingTransform(mask, net, num_bins=k),
+         "quadratic_tails": lambda: T.PiecewiseQuadraticCouplingTransform(mask, net, num_bins=k, tails="linear", tail_bound=2.0),
+         "cubic": lambda: T.PiecewiseCubicCouplingTransform(mask, net, num_bins=k),
+         "maf_quadratic": lambda: T.MaskedPiecewiseQuadraticAutoregressiveTransform(k, d, 16, num_blocks=1, tails="linear", tail_bound=3.0),
+         "maf_cubic": lambda: T.MaskedPiecewiseCubicAutoregressiveTransform(k, d, 16, num_blocks=1)}[kind]()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    x = torch.rand(n, d) * 0.9 + 0.05 if unit else torch.randn(n, d) * 1.3
+    gy, gl = torch.randn(n, d), torch.randn(n)
+    ref = copy.deepcopy(t).double().train()
+    x_ref = x.double().requires_grad_(True)
+    y_ref, lad_ref = O.transform_apply(ref, x_ref)
+    ((y_ref * gy.double()).sum() + (lad_ref * gl.double()).sum()).backward()
+    gpu = copy.deepcopy(t).to(device).train()
+    x_gpu = x.to(device).requires_grad_(True)
+    y, lad = gpu(x_gpu)
+    ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
+    assert maxdiff(y.detach(), y_ref.detach()) <= 3e-5 * max(1.0, float(y_ref.detach().abs().max()))
+    assert maxdiff(x_gpu.grad, x_ref.grad) <= 1e-3 * max(1.0, float(x_ref.grad.abs().max()))
+    for (name, p_ref), (_, p) in zip(ref.named_parameters(), gpu.named_parameters()):
+        if p_ref.grad is None:
+            continue
+        scale = max(1e-5, float(p_ref.grad.abs().max()))
+        assert p.grad is not None and maxdiff(p.grad.cpu().double(), p_ref.grad) <= 2e-3 * scale + 1e-6, name
+    z = y.detach().clone().requires_grad_(True)
+    back, lad_inv = gpu.inverse(z)
+    (back.sum() + lad_inv.sum()).backward()
+    assert z.grad is not None and torch.isfinite(z.grad).all()
+    assert maxdiff(back.detach(), x) <= 1e-3 * max(1.0, float(x.abs().max()))
