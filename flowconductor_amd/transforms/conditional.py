@@ -349,11 +349,11 @@ class ConditionalPiecewiseRationalQuadraticTransform(ConditionalTransform):
         divisor = 1.0
         if hasattr(self.conditional_net, "hidden_features"):
             divisor = float(np.sqrt(self.conditional_net.hidden_features))
-        return ops.rq_spline(inputs, autoregressive_params, None, num_bins=self.num_bins, tails=self.tails,
-                             tail_bound=self.tail_bound, left=-1.2, right=1.2, bottom=-1.2, top=1.2,
-                             min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
-                             min_derivative=self.min_derivative, enable_identity_init=True, wh_divisor=divisor,
-                             inverse=inverse)
+        return ops.rq_spline_autograd(inputs, autoregressive_params, None, num_bins=self.num_bins, tails=self.tails,
+                                      tail_bound=self.tail_bound, left=-1.2, right=1.2, bottom=-1.2, top=1.2,
+                                      min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                                      min_derivative=self.min_derivative, enable_identity_init=True,
+                                      wh_divisor=divisor, inverse=inverse)
 
     def _forward_given_params(self, inputs, autoregressive_params):
         return self._elementwise(inputs, autoregressive_params)

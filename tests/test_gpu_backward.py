@@ -568,3 +568,36 @@ def test_sibling_spline_layers_train(kind, device):
     (back.sum() + lad_inv.sum()).backward()
     assert z.grad is not None and torch.isfinite(z.grad).all()
     assert maxdiff(back.detach(), x) <= 1e-3 * max(1.0, float(x.abs().max()))
+
+
+@pytest.mark.parametrize("kind", ["rq", "sos", "linear_spline", "shift", "scale"])
+def test_hyper_network_transforms_train(kind, device):
+    """Conditional (hyper-network) transforms under autograd: gradients of the hyper-network's parameters against
+    torch.autograd through the oracle in float64."""
+    from flowconductor_amd import transforms as T
+
+    torch.manual_seed(79)
+    d, ctx_f, n = 5, 4, 300
+    t = {"rq": lambda: T.ConditionalPiecewiseRationalQuadraticTransform(d, 16, ctx_f, num_bins=6, tails="linear", tail_bound=3.0),
+         "sos": lambda: T.ConditionalSumOfSigmoidsTransform(d, 16, ctx_f, n_sigmoids=5),
+         "linear_spline": lambda: T.PiecewiseLinearConditionalTransform(5, d, 16, ctx_f),
+         "shift": lambda: T.ConditionalShiftTransform(d, 16, ctx_f),
+         "scale": lambda: T.ConditionalScaleTransform(d, 16, ctx_f)}[kind]()
+    x = (torch.randn(n, d) * 1.2).clamp(-3.5, 3.5)       # (the conditional linear spline lives on the box [-4, 4])
+    c = torch.randn(n, ctx_f)
+    gy, gl = torch.randn(n, d), torch.randn(n)
+    ref = copy.deepcopy(t).double().train()
+    y_ref, lad_ref = O.transform_apply(ref, x.double(), c.double())
+    ((y_ref * gy.double()).sum() + (lad_ref * gl.double()).sum()).backward()
+    gpu = copy.deepcopy(t).to(device).train()
+    y, lad = gpu(x.to(device), c.to(device))
+    ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
+    assert maxdiff(y.detach(), y_ref.detach()) <= 3e-5 * max(1.0, float(y_ref.detach().abs().max()))
+    checked = 0
+    for (name, p_ref), (_, p) in zip(ref.named_parameters(), gpu.named_parameters()):
+        if p_ref.grad is None:
+            continue
+        scale = max(1e-5, float(p_ref.grad.abs().max()))
+        assert p.grad is not None and maxdiff(p.grad.cpu().double(), p_ref.grad) <= 2e-3 * scale + 1e-6, name
+        checked += 1
+    assert checked > 0
