@@ -105,6 +105,29 @@ __device__ __forceinline__ void matvec(Row<E>& y, const Row<E>& x, const float* 
   }
 }
 
+// y_i = sum_{j >= i} R[i][j] x_j for a per-sample upper-triangular R stored row-major as the hyper-network emits it:
+// row i is one coalesced read of its columns j >= i only (the strictly lower part is never fetched), one multiply
+// per lane and a wave reduction.
+template <int E>
+__device__ __forceinline__ void matvec_rows_upper(Row<E>& y, const Row<E>& x, const float* __restrict__ r, int d,
+                                                  int lane) {
+#pragma unroll
+  for (int e = 0; e < E; ++e) y.v[e] = 0.f;
+  for (int i = 0; i < d; ++i) {
+    const float* row = r + (int64_t)i * d;
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = lane + 64 * e;
+      if (j >= i && j < d) s += row[j] * x.v[e];
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (lane + 64 * e == i) y.v[e] = s;
+  }
+}
+
 // ---- kernels ----------------------------------------------------------------------------
 
 template <int E>
@@ -239,7 +262,8 @@ __global__ __launch_bounds__(256) void sylvester_kernel(const float* __restrict_
     const float* rd = per_sample ? rdiag + row * (int64_t)d : rdiag;
     t = z;
     householder<E>(t, qr, m, d, lane, true);          // Q^T z
-    matvec<E>(a, t, r1, d, lane, 1);                   // R1 Q^T z
+    if (per_sample) matvec_rows_upper<E>(a, t, r1, d, lane);   // R1 Q^T z (row-major per-sample R, upper part only)
+    else matvec<E>(a, t, r1, d, lane, 1);
     float ld = 0.f;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -253,7 +277,8 @@ __global__ __launch_bounds__(256) void sylvester_kernel(const float* __restrict_
       }
     }
     ld = wave_sum(ld);
-    matvec<E>(t, a, r2, d, lane, 1);                   // R2 act
+    if (per_sample) matvec_rows_upper<E>(t, a, r2, d, lane);   // R2 act
+    else matvec<E>(t, a, r2, d, lane, 1);
     householder<E>(t, qr, m, d, lane, false);          // Q R2 act
 #pragma unroll
     for (int e = 0; e < E; ++e) z.v[e] = z.v[e] + t.v[e];

@@ -974,8 +974,13 @@ def sylvester(inputs, q_vectors, r1, r2, bias):
     if per_sample != (q.dim() == 3) or per_sample != (bv.dim() == 2):
         raise ValueError("q, R1, R2 and bias must all be shared or all be per-sample")
     rdiag = (torch.diagonal(r1, dim1=-2, dim2=-1) * torch.diagonal(r2, dim1=-2, dim2=-1)).contiguous()
-    r1t = r1.transpose(-1, -2).contiguous()
-    r2t = r2.transpose(-1, -2).contiguous()
+    if per_sample:
+        # [N, D, D] row-major exactly as the hyper-network emits them: the kernel reads each row's upper part once
+        # (a transposed copy would cost two more passes over 2 x N x D x D floats)
+        r1t, r2t = r1.contiguous(), r2.contiguous()
+    else:
+        r1t = r1.transpose(-1, -2).contiguous()
+        r2t = r2.transpose(-1, -2).contiguous()
     y = torch.empty_like(x)
     lad = torch.empty(n, dtype=torch.float32, device=x.device)
     _call("fc_sylvester", lib.fc_sylvester, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(lad), _hip.ptr(q),

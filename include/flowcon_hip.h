@@ -275,8 +275,9 @@ int fc_linear_per_sample(const float* x, float* y, float* logabsdet, const float
 
 /* Sylvester flow, fused: y = z + Q R2 tanh(R1 Q^T z + bias), Q = num_householder reflections q,
  * logabsdet = sum_j log(1 + (1 - tanh^2(.)_j) * r_diag_prod_j), r_diag_prod = diag(R1)*diag(R2).
- * r1_t / r2_t are the upper-triangular matrices TRANSPOSED.  per_sample != 0: q [n, M, d],
- * r1_t/r2_t [n, d, d], bias/r_diag_prod [n, d] (the D-general conditional form, conditional.py:936-953).
+ * Shared parameters: r1_t / r2_t are the upper-triangular matrices TRANSPOSED.  per_sample != 0: q [n, M, d],
+ * r1_t / r2_t [n, d, d] ROW-MAJOR AND UNTRANSPOSED, as a hyper-network emits them (only the upper triangle of every
+ * row is read: half the bytes), bias / r_diag_prod [n, d] (the D-general conditional form, conditional.py:936-953).
  * Replaces SylvesterTransform.forward (no_analytic_inv/planar.py:144-166). */
 int fc_sylvester(const float* x, float* y, float* logabsdet, const float* q, const float* r1_t,
                  const float* r2_t, const float* bias, const float* r_diag_prod, int64_t n, int32_t d,

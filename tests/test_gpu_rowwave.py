@@ -227,3 +227,37 @@ def test_householder_and_lu_dense_matrix_core_path(d, k, n, device):
         scale = max(1.0, float(ref_y.abs().max()))
         assert maxdiff(y.cpu().double(), ref_y) <= 1e-5 * scale + 4 * maxdiff(f32_y.double(), ref_y)
         assert maxdiff(lad.cpu().double(), ref_lad) <= 1e-5 * max(1.0, float(ref_lad.abs().max()))
+
+
+@pytest.mark.parametrize("d,m,n", [(12, 5, 300), (128, 32, 512), (70, 3, 65)])
+def test_per_sample_sylvester_row_major_upper_triangles(d, m, n, device):
+    """The conditional (per-sample) Sylvester form: q [N, M, D], R1 / R2 [N, D, D] row-major as a hyper-network emits
+    them, only their upper triangles are read (garbage below the diagonal must not matter); against the formula of
+    conditional.py:936-953 in float64."""
+    torch.manual_seed(d + m)
+    x = torch.randn(n, d)
+    q = torch.randn(n, m, d)
+    r1 = torch.triu(torch.randn(n, d, d) / d ** 0.5)
+    r2 = torch.triu(torch.randn(n, d, d) / d ** 0.5)
+    r1.diagonal(dim1=1, dim2=2).tanh_()
+    r2.diagonal(dim1=1, dim2=2).tanh_()
+    bias = torch.randn(n, d) * 0.1
+    xd, qd, b64 = x.double(), q.double(), bias.double()
+
+    def reflect(v, reverse):
+        order = range(m - 1, -1, -1) if reverse else range(m)
+        for i in order:
+            qi = qd[:, i]
+            v = v - (v * qi).sum(-1, keepdim=True) * (2.0 / (qi * qi).sum(-1, keepdim=True)) * qi
+        return v
+
+    pre = torch.einsum("nij,nj->ni", r1.double(), reflect(xd, True)) + b64
+    act = torch.tanh(pre)
+    ref_y = xd + reflect(torch.einsum("nij,nj->ni", r2.double(), act), False)
+    ref_lad = torch.log(1 + (1 - act ** 2) * (r1.double().diagonal(dim1=1, dim2=2) * r2.double().diagonal(dim1=1, dim2=2))).sum(-1)
+    junk = torch.tril(torch.randn(n, d, d) * 100, -1)       # below the diagonal: never read
+    with torch.no_grad():
+        y, lad = ops.sylvester(x.to(device), q.to(device), (r1 + junk).to(device), (r2 + junk).to(device),
+                               bias.to(device))
+    assert maxdiff(y, ref_y) <= 2e-5 * max(1.0, float(ref_y.abs().max()))
+    assert maxdiff(lad, ref_lad) <= 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10)

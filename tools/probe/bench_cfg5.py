@@ -43,3 +43,29 @@ with torch.no_grad():
     torch.cuda.synchronize()
 ms = sorted(tm.durations_ms())
 print("fc_sylvester_mm (SylvesterTransform.forward) N=2^18 D=128 M=32: median %.3f ms" % ms[len(ms) // 2])
+
+# conditional variant: per-sample q [N, 32, 128], R1 / R2 [N, 128, 128], bias [N, 128] -- 148 480 B per
+# sample, HBM-bound by construction
+for log2n in (16, 18):
+    nn_ = 1 << log2n
+    xs = torch.randn(nn_, d, device=dev)
+    qs = torch.randn(nn_, m, d, device=dev)
+    r1s = torch.triu(torch.randn(nn_, d, d, device=dev) / d ** 0.5)
+    r2s = torch.triu(torch.randn(nn_, d, d, device=dev) / d ** 0.5)
+    r1s.diagonal(dim1=1, dim2=2).tanh_()
+    r2s.diagonal(dim1=1, dim2=2).tanh_()
+    bs = torch.randn(nn_, d, device=dev) * 0.1
+    with torch.no_grad():
+        for _ in range(2):
+            ops.sylvester(xs, qs, r1s, r2s, bs)
+        with ops.KernelTimer("fc_sylvester") as t:
+            for _ in range(5):
+                ops.sylvester(xs, qs, r1s, r2s, bs)
+        torch.cuda.synchronize()
+    ms = sorted(t.durations_ms())
+    med = ms[len(ms) // 2]
+    byts = nn_ * (4 * (2 * d * d + 2 * d + m * d) + 4 * d + 4)
+    print("fc_sylvester per-sample parameters N=2^%d D=128 M=32: median %.3f ms = %.2f TB/s of %d B/sample (%.2f of 8 TB/s)"
+          % (log2n, med, byts / med / 1e9, byts // nn_, byts / med / 1e9 / 8.0))
+    del xs, qs, r1s, r2s, bs
+    torch.cuda.empty_cache()
