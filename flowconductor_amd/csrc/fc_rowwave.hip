@@ -113,18 +113,31 @@ __device__ __forceinline__ void matvec_rows_upper(Row<E>& y, const Row<E>& x, co
                                                   int lane) {
 #pragma unroll
   for (int e = 0; e < E; ++e) y.v[e] = 0.f;
-  for (int i = 0; i < d; ++i) {
-    const float* row = r + (int64_t)i * d;
-    float s = 0.f;
+  // eight rows per step: their loads are issued together (one row at a time the loop waits a full memory latency per
+  // row), then eight independent reductions
+  constexpr int kRows = 8;
+  for (int i0 = 0; i0 < d; i0 += kRows) {
+    float w[kRows][E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int j = lane + 64 * e;
-      if (j >= i && j < d) s += row[j] * x.v[e];
+    for (int k = 0; k < kRows; ++k) {
+      const int i = i0 + k;
+      const float* row = r + (int64_t)(i < d ? i : d - 1) * d;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = lane + 64 * e;
+        w[k][e] = (j >= i && j < d && i < d) ? row[j] : 0.f;
+      }
     }
-    s = wave_sum(s);
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-      if (lane + 64 * e == i) y.v[e] = s;
+    for (int k = 0; k < kRows; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s += w[k][e] * x.v[e];
+      s = wave_sum(s);
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (lane + 64 * e == i0 + k) y.v[e] = s;
+    }
   }
 }
 
