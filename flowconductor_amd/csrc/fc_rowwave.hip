@@ -315,80 +315,115 @@ __global__ __launch_bounds__(256) void linear_per_sample_kernel(const float* __r
 #pragma unroll
     for (int e = 0; e < E; ++e) out.v[e] = 0.f;
     float ld = 0.f;
-    if (mode == 0) {  // y_i = sum_j M_ij x_j
-      for (int i = 0; i < d; ++i) {
-        Row<E> mi;
-        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
-        const float s = dot_rows<E>(mi, v);
+    // Rows are taken kRows at a time: their loads are issued together (row by row the loop waits a full memory
+    // latency per row) and every matrix element is read exactly once in all four modes.
+    constexpr int kRows = 8;
+    auto load_rows = [&](int i0, Row<E> (&mi)[kRows]) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] = s;
+      for (int k = 0; k < kRows; ++k) load_row<E>(mi[k], mr + (int64_t)(i0 + k < d ? i0 + k : d - 1) * d, d, lane);
+    };
+    // softplus(diag M) + eps of the LU forms: lane j loads M[j][j] once per sample (one strided load per register)
+    Row<E> diag;
+    if (mode >= 2) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int j = lane + 64 * e;
+        diag.v[e] = j < d ? softplus1(mr[(int64_t)j * d + j]) + eps : 1.f;
+        ld += j < d ? logf(diag.v[e]) : 0.f;
+      }
+      ld = wave_sum(ld);
+      if (mode == 3) ld = -ld;
+    }
+    if (mode == 0) {  // y_i = sum_j M_ij x_j
+      for (int i0 = 0; i0 < d; i0 += kRows) {
+        Row<E> mi[kRows];
+        load_rows(i0, mi);
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) {
+          const float sres = dot_rows<E>(mi[k], v);
+#pragma unroll
+          for (int e = 0; e < E; ++e) if (lane + 64 * e == i0 + k) out.v[e] = sres;
+        }
       }
     } else if (mode == 1) {  // y_j = sum_i M_ij x_i: row i scaled by the broadcast x_i
-      for (int i = 0; i < d; ++i) {
-        Row<E> mi;
-        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
-        const float xi = bcast<E>(v, i);
+      for (int i0 = 0; i0 < d; i0 += kRows) {
+        Row<E> mi[kRows];
+        load_rows(i0, mi);
 #pragma unroll
-        for (int e = 0; e < E; ++e) out.v[e] += mi.v[e] * xi;
+        for (int k = 0; k < kRows; ++k) {
+          const float xi = i0 + k < d ? bcast<E>(v, i0 + k) : 0.f;
+#pragma unroll
+          for (int e = 0; e < E; ++e) out.v[e] += mi[k].v[e] * xi;
+        }
       }
-    } else if (mode == 2) {  // t = U x, y = L t
+    } else if (mode == 2) {  // t = U x, y = L t in ONE pass over the rows: y_i = sum_{j<i} L_ij t_j + t_i only needs
+                             // the t_j of earlier rows
       Row<E> t;
 #pragma unroll
       for (int e = 0; e < E; ++e) t.v[e] = 0.f;
-      for (int i = 0; i < d; ++i) {
-        Row<E> mi, ui;
-        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
+      for (int i0 = 0; i0 < d; i0 += kRows) {
+        Row<E> mi[kRows];
+        load_rows(i0, mi);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const int j = lane + 64 * e;
-          const float dg = softplus1(mi.v[e]) + eps;
-          ui.v[e] = j > i ? sp * mi.v[e] : (j == i ? dg : 0.f);
-          if (j == i) ld += logf(dg);
+        for (int k = 0; k < kRows; ++k) {       // t_i = dg_i x_i + sp sum_{j>i} M_ij x_j
+          const int i = i0 + k;
+          float part = 0.f;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int j = lane + 64 * e;
+            part += (j > i && j < d) ? sp * mi[k].v[e] * v.v[e] : (j == i ? diag.v[e] * v.v[e] : 0.f);
+          }
+          part = wave_sum(part);
+#pragma unroll
+          for (int e = 0; e < E; ++e) if (lane + 64 * e == i) t.v[e] = part;
         }
-        const float s = dot_rows<E>(ui, v);
 #pragma unroll
-        for (int e = 0; e < E; ++e) if (lane + 64 * e == i) t.v[e] = s;
-      }
-      for (int i = 0; i < d; ++i) {
-        Row<E> mi, li;
-        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
+        for (int k = 0; k < kRows; ++k) {       // y_i = t_i + sp sum_{j<i} M_ij t_j
+          const int i = i0 + k;
+          float part = 0.f;
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const int j = lane + 64 * e;
-          li.v[e] = j < i ? sp * mi.v[e] : (j == i ? 1.f : 0.f);
+          for (int e = 0; e < E; ++e) {
+            const int j = lane + 64 * e;
+            part += j < i ? sp * mi[k].v[e] * t.v[e] : (j == i ? t.v[e] : 0.f);
+          }
+          part = wave_sum(part);
+#pragma unroll
+          for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] = part;
         }
-        const float s = dot_rows<E>(li, t);
-#pragma unroll
-        for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] = s;
       }
-      ld = wave_sum(ld);
     } else {  // forward substitution with unit-lower L, then back substitution with U (no pivoting)
       out = v;
-      for (int i = 0; i < d; ++i) {
-        Row<E> mi;
-        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
-        float part = 0.f;
+      for (int i0 = 0; i0 < d; i0 += kRows) {
+        Row<E> mi[kRows];
+        load_rows(i0, mi);
 #pragma unroll
-        for (int e = 0; e < E; ++e) if (lane + 64 * e < i) part += sp * mi.v[e] * out.v[e];
-        part = wave_sum(part);
+        for (int k = 0; k < kRows; ++k) {
+          const int i = i0 + k;
+          float part = 0.f;
 #pragma unroll
-        for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] -= part;
-      }
-      for (int i = d - 1; i >= 0; --i) {
-        Row<E> mi;
-        load_row<E>(mi, mr + (int64_t)i * d, d, lane);
-        float part = 0.f, dg = 0.f;
+          for (int e = 0; e < E; ++e) if (lane + 64 * e < i) part += sp * mi[k].v[e] * out.v[e];
+          part = wave_sum(part);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const int j = lane + 64 * e;
-          if (j > i && j < d) part += sp * mi.v[e] * out.v[e];
-          if (j == i) dg = softplus1(mi.v[e]) + eps;
+          for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] -= part;
         }
-        part = wave_sum(part);
-        dg = wave_sum(dg);
-        ld -= logf(dg);
+      }
+      for (int i0 = ((d - 1) / kRows) * kRows; i0 >= 0; i0 -= kRows) {
+        Row<E> mi[kRows];
+        load_rows(i0, mi);
 #pragma unroll
-        for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] = (out.v[e] - part) / dg;
+        for (int k = kRows - 1; k >= 0; --k) {
+          const int i = i0 + k;
+          if (i >= d) continue;
+          float part = 0.f;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int j = lane + 64 * e;
+            if (j > i && j < d) part += sp * mi[k].v[e] * out.v[e];
+          }
+          part = wave_sum(part);
+#pragma unroll
+          for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] = (out.v[e] - part) / diag.v[e];
+        }
       }
     }
     store_row<E>(out, y + row * d, d, lane);
