@@ -261,3 +261,36 @@ def test_per_sample_sylvester_row_major_upper_triangles(d, m, n, device):
                                bias.to(device))
     assert maxdiff(y, ref_y) <= 2e-5 * max(1.0, float(ref_y.abs().max()))
     assert maxdiff(lad, ref_lad) <= 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10)
+
+
+@pytest.mark.parametrize("d", [1, 2, 7, 8, 9, 33, 64, 65, 100, 128, 200, 257, 512])
+def test_per_sample_linear_modes_over_widths(d, device):
+    """fc_linear_per_sample (rows taken eight at a time, LU forward in one pass) over widths that are not multiples of
+    the row batch / the wave: M x, M^T x, L (U x) and its inverse against float64 torch."""
+    torch.manual_seed(d)
+    n = 37
+    x = torch.randn(n, d)
+    m = torch.randn(n, d, d) / max(1.0, d ** 0.5)
+    sp, eps = 0.3, 1e-3
+    xd, md = x.double(), m.double()
+    lower = sp * torch.tril(md, -1) + torch.eye(d, dtype=torch.float64)
+    diag = torch.nn.functional.softplus(md.diagonal(dim1=1, dim2=2)) + eps
+    upper = sp * torch.triu(md, 1) + torch.diag_embed(diag)
+    refs = {ops.PER_SAMPLE_DENSE: (torch.einsum("nij,nj->ni", md, xd), None),
+            ops.PER_SAMPLE_DENSE_T: (torch.einsum("nij,ni->nj", md, xd), None),
+            ops.PER_SAMPLE_LU_FORWARD: (torch.einsum("nij,nj->ni", lower, torch.einsum("nij,nj->ni", upper, xd)),
+                                        torch.log(diag).sum(-1))}
+    with torch.no_grad():
+        for mode, (ref, ref_lad) in refs.items():
+            out = ops.linear_per_sample(x.to(device), m.to(device), mode=mode, offdiag_scale=sp, eps=eps,
+                                        want_logabsdet=ref_lad is not None)
+            y, lad = out if isinstance(out, tuple) else (out, None)
+            assert maxdiff(y, ref) <= 2e-5 * max(1.0, float(ref.abs().max())), (mode, d)
+            if ref_lad is not None:
+                assert maxdiff(lad, ref_lad) <= 2e-4 * max(1.0, float(ref_lad.abs().max())), (mode, d)
+        y_fwd = refs[ops.PER_SAMPLE_LU_FORWARD][0].float()
+        back, lad_inv = ops.linear_per_sample(y_fwd.to(device), m.to(device), mode=ops.PER_SAMPLE_LU_INVERSE,
+                                              offdiag_scale=sp, eps=eps, want_logabsdet=True)
+    cond = float(torch.linalg.cond(lower @ upper).max())
+    assert maxdiff(back, x) <= 1e-5 * max(1.0, cond) * max(1.0, float(x.abs().max())), (d, cond)
+    assert maxdiff(lad_inv, -refs[ops.PER_SAMPLE_LU_FORWARD][1]) <= 2e-4 * max(1.0, float(refs[ops.PER_SAMPLE_LU_FORWARD][1].abs().max()))
