@@ -16,6 +16,17 @@ __device__ __forceinline__ float row16_allmax(float m) {
   return m;
 }
 
+// sum over the 16 lanes of a DPP row; every lane of the row gets the result
+__device__ __forceinline__ float row16_allsum(float v) {
+#define FC_ROR(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + (n), 0xf, 0xf, false))
+  v += FC_ROR(8);
+  v += FC_ROR(4);
+  v += FC_ROR(2);
+  v += FC_ROR(1);
+#undef FC_ROR
+  return v;
+}
+
 // value of lane ^ 32 / lane ^ 16
 __device__ __forceinline__ float lane_xor32(float v, int lane) {
   const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
@@ -31,6 +42,10 @@ __device__ __forceinline__ float rows4_allsum(float v, int lane) {
   v += lane_xor32(v, lane);
   return v + lane_xor16(v, lane);
 }
+// sum over all 64 lanes, every lane gets it: four DPP row rotations + two permlane swaps, all on the VALU (a
+// __shfl_xor butterfly is six dependent ds_bpermute round trips through the LDS pipe)
+__device__ __forceinline__ float wave64_allsum(float v, int lane) { return rows4_allsum(row16_allsum(v), lane); }
+
 __device__ __forceinline__ float rows4_allmax(float v, int lane) {
   v = fmaxf(v, lane_xor32(v, lane));
   return fmaxf(v, lane_xor16(v, lane));

@@ -15,13 +15,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fc_math.h"
+#include "fc_lane.h"
 #include "../../include/flowcon_hip.h"
 
 namespace fc {
 
 constexpr int kWavesPerBlock = 4;
 
-__device__ __forceinline__ float wave_sum(float v) {
+__device__ __forceinline__ float wave_sum(float v) { return wave64_allsum(v, threadIdx.x & 63); }
+// the ds_bpermute butterfly: slower per reduction, but the shared-parameter Sylvester kernel runs faster with it
+// (3.4 vs 5.4 ms at D = 128, M = 32, N = 2^18 -- its reductions overlap the column reads of the mat-vecs)
+__device__ __forceinline__ float wave_sum_lds(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -50,12 +54,12 @@ __device__ __forceinline__ void store_row(const Row<E>& r, float* __restrict__ p
   }
 }
 
-template <int E>
+template <int E, bool kLds = false>
 __device__ __forceinline__ float dot_rows(const Row<E>& a, const Row<E>& b) {
   float s = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) s += a.v[e] * b.v[e];
-  return wave_sum(s);
+  return kLds ? wave_sum_lds(s) : wave_sum(s);
 }
 
 // x_j for a wave-uniform j: element j lives in register j/64 of lane j%64
@@ -73,15 +77,15 @@ __device__ __forceinline__ float bcast(const Row<E>& r, int j) {
 
 // out -= (out . q) * (2 / |q|^2) * q, K times (orthogonal.py:144-171).
 // q: [K, d] shared, or this row's [K, d] block when per-sample.  order: 0..K-1 or reversed.
-template <int E>
+template <int E, bool kLds = false>
 __device__ __forceinline__ void householder(Row<E>& x, const float* __restrict__ q, int k_count, int d,
                                             int lane, bool reverse) {
   for (int t = 0; t < k_count; ++t) {
     const int k = reverse ? k_count - 1 - t : t;
     Row<E> qv;
     load_row<E>(qv, q + (int64_t)k * d, d, lane);
-    const float sq = dot_rows<E>(qv, qv);
-    const float ip = dot_rows<E>(x, qv);
+    const float sq = dot_rows<E, kLds>(qv, qv);
+    const float ip = dot_rows<E, kLds>(x, qv);
     const float c = 2.f / sq;
 #pragma unroll
     for (int e = 0; e < E; ++e) x.v[e] = x.v[e] - ip * (c * qv.v[e]);
@@ -257,12 +261,15 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 // Sylvester flow, fused (planar.py:144-166):
 //   Qtz = Householder^-1(z); pre = R1 Qtz + b; act = tanh(pre); out = z + Householder(R2 act)
 //   logdet = sum_j log(1 + (1 - act_j^2) * diag(R1)_j * diag(R2)_j)
-template <int E>
+// kPS: per-sample parameters (row-major upper-triangular R from HBM, VALU cross-lane sums); the shared-parameter
+// kernel keeps the transposed-R column reads and the ds_bpermute sums it is fastest with
+template <int E, bool kPS>
 __global__ __launch_bounds__(256) void sylvester_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         float* __restrict__ lad, const float* __restrict__ q,
                                                         const float* __restrict__ r1t, const float* __restrict__ r2t,
                                                         const float* __restrict__ bias, const float* __restrict__ rdiag,
-                                                        int64_t n, int d, int m, int per_sample) {
+                                                        int64_t n, int d, int m) {
+  constexpr bool per_sample = kPS;
   const int lane = threadIdx.x & 63;
   const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
   for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < n; row += stride) {
@@ -274,8 +281,8 @@ __global__ __launch_bounds__(256) void sylvester_kernel(const float* __restrict_
     const float* bb = per_sample ? bias + row * (int64_t)d : bias;
     const float* rd = per_sample ? rdiag + row * (int64_t)d : rdiag;
     t = z;
-    householder<E>(t, qr, m, d, lane, true);          // Q^T z
-    if (per_sample) matvec_rows_upper<E>(a, t, r1, d, lane);   // R1 Q^T z (row-major per-sample R, upper part only)
+    householder<E, !kPS>(t, qr, m, d, lane, true);          // Q^T z
+    if constexpr (kPS) matvec_rows_upper<E>(a, t, r1, d, lane);   // R1 Q^T z (row-major per-sample R, upper part only)
     else matvec<E>(a, t, r1, d, lane, 1);
     float ld = 0.f;
 #pragma unroll
@@ -289,10 +296,10 @@ __global__ __launch_bounds__(256) void sylvester_kernel(const float* __restrict_
         a.v[e] = 0.f;
       }
     }
-    ld = wave_sum(ld);
-    if (per_sample) matvec_rows_upper<E>(t, a, r2, d, lane);   // R2 act
+    ld = per_sample ? wave_sum(ld) : wave_sum_lds(ld);
+    if constexpr (kPS) matvec_rows_upper<E>(t, a, r2, d, lane);   // R2 act
     else matvec<E>(t, a, r2, d, lane, 1);
-    householder<E>(t, qr, m, d, lane, false);          // Q R2 act
+    householder<E, !kPS>(t, qr, m, d, lane, false);         // Q R2 act
 #pragma unroll
     for (int e = 0; e < E; ++e) z.v[e] = z.v[e] + t.v[e];
     store_row<E>(z, y + row * d, d, lane);
@@ -502,8 +509,12 @@ extern "C" int fc_sylvester(const float* x, float* y, float* logabsdet, const fl
   if (!x || !y || !r1_t || !r2_t || !bias || !r_diag_prod || (!q && num_householder > 0))
     return hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::sylvester_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x, y,
-                                        logabsdet, q, r1_t, r2_t, bias, r_diag_prod, n, d, num_householder,
-                                        per_sample));
+  if (per_sample) {
+    FC_ROW_DISPATCH(d, hipLaunchKernelGGL((fc::sylvester_kernel<E, true>), dim3(fc::row_grid(n)), dim3(256), 0, s, x,
+                                          y, logabsdet, q, r1_t, r2_t, bias, r_diag_prod, n, d, num_householder));
+  } else {
+    FC_ROW_DISPATCH(d, hipLaunchKernelGGL((fc::sylvester_kernel<E, false>), dim3(fc::row_grid(n)), dim3(256), 0, s, x,
+                                          y, logabsdet, q, r1_t, r2_t, bias, r_diag_prod, n, d, num_householder));
+  }
   return hipGetLastError();
 }
