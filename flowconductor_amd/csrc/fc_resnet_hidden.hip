@@ -37,6 +37,10 @@
 #include "fc_math.h"
 #include "../../include/flowcon_hip.h"
 
+#ifndef FC_HIDDEN_PREFETCH_X
+#define FC_HIDDEN_PREFETCH_X 1
+#endif
+
 namespace fc {
 
 constexpr int kHid = 64;
@@ -84,6 +88,7 @@ struct HiddenLds {
 template <int NB, int K0S, int kCtx, int kAct>
 __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(HiddenArgs a) {
   using L = HiddenLds<NB, K0S, kCtx>;
+  constexpr bool kPrefetchX = FC_HIDDEN_PREFETCH_X && K0S == 1;   // (16 more live registers spill in the 64-input kernels)
   extern __shared__ __attribute__((aligned(16))) unsigned char hsmem[];
   f16x8* wfrag = reinterpret_cast<f16x8*>(hsmem);
   float* bias = reinterpret_cast<float*>(hsmem + (size_t)L::kFrags * 64 * 16);   // [layer][g][16]
@@ -281,14 +286,10 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
     for (int j = 0; j < 8; ++j) mycol[ks][j] = ids[32 * ks + 8 * g + j];
 
   const int64_t nwaves = (int64_t)gridDim.x * (kHidThreads / 64);
-  for (int64_t blk = (int64_t)blockIdx.x * (kHidThreads / 64) + wave; blk < a.blocks16; blk += nwaves) {
-    // the weight fragments are loop-invariant LDS loads: without this fence the compiler hoists all of them
-    // out of the loop and spills
-    asm volatile("" ::: "memory");
+  // identity (and concatenated context) features of sample s for this lane, laid out like an activation tile
+  auto gather = [&](int64_t blk, f32x4 (&xv)[4]) {
     const float* xrow = a.x + (blk * 16 + s16) * D;
-    const float* crow = kCtx ? a.ctx + (blk * 16 + s16) * C : nullptr;
-    // x operand: 8 (16) identity features of sample s per lane, laid out like an activation tile
-    f32x4 xin[4];
+    const float* crow_ = kCtx ? a.ctx + (blk * 16 + s16) * C : nullptr;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -298,12 +299,24 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
         if (ks < K0S) {
           const int c = mycol[ks < K0S ? ks : 0][j];
           if constexpr (kCtx == 1)
-            v = c >= 0 ? xrow[c] : (c <= -2 ? crow[-2 - c] : 0.f);
+            v = c >= 0 ? xrow[c] : (c <= -2 ? crow_[-2 - c] : 0.f);
           else
             v = c >= 0 ? xrow[c] : 0.f;
         }
-        xin[t][r] = v;
+        xv[t][r] = v;
       }
+  };
+  const int64_t blk0 = (int64_t)blockIdx.x * (kHidThreads / 64) + wave;
+  f32x4 xin[4];
+  if (blk0 < a.blocks16) gather(blk0, xin);
+  for (int64_t blk = blk0; blk < a.blocks16; blk += nwaves) {
+    // the weight fragments are loop-invariant LDS loads: without this fence the compiler hoists all of them
+    // out of the loop and spills
+    asm volatile("" ::: "memory");
+    const float* crow = kCtx ? a.ctx + (blk * 16 + s16) * C : nullptr;
+    if constexpr (!kPrefetchX) {
+      if (blk != blk0) gather(blk, xin);
+    }
     f16x8 bh[2], bl[2];
     f32x4 acc[4], h[4], tmid[4];
     // context row as the B operand of the gate products: lane (s, g) supplies features 8g..8g+7 of sample s; split
@@ -333,6 +346,12 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
       }
     }
     float un = make_operand(xin, bh, bl);
+    // the next block's rows are requested now and consumed an iteration later (a wave otherwise starts every block
+    // with an exposed memory latency)
+    if constexpr (kPrefetchX) {
+      const int64_t nxt = blk + nwaves < a.blocks16 ? blk + nwaves : blk;
+      gather(nxt, xin);
+    }
     layer(0, K0S, bh, bl, acc);
     finish(0, un, acc, h);
     if constexpr (kCtx == 2) {
