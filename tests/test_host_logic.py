@@ -277,3 +277,22 @@ def test_user_defined_transforms_are_left_alone():
         internal()(torch.ones(4, 3))
     with torch.no_grad():
         internal()(torch.ones(4, 3))
+
+
+def test_activation_codes_and_made_predicates():
+    from torch.nn import functional as F
+
+    assert ops.activation_code(F.relu) == (ops.ACT_RELU, 0.0) and ops.activation_code(torch.nn.ReLU()) == (ops.ACT_RELU, 0.0)
+    assert ops.activation_code(torch.tanh)[0] == ops.ACT_TANH and ops.activation_code(F.silu)[0] == ops.ACT_SILU
+    assert ops.activation_code(torch.nn.ELU(0.7)) == (ops.ACT_ELU, 0.7) and ops.activation_code(F.elu) == (ops.ACT_ELU, 1.0)
+    assert ops.activation_code(torch.nn.LeakyReLU(0.2)) == (ops.ACT_LEAKY_RELU, 0.2)
+    assert ops.activation_code(torch.nn.Softsign()) is None and ops.activation_code(lambda v: v) is None
+    made = T.made.MADE(features=5, hidden_features=20, num_blocks=2, output_multiplier=2)
+    assert made.hip_hidden_supported() and not made.hip_hidden_supported(torch.zeros(4, 3))
+    cmade = T.made.MADE(features=5, hidden_features=20, context_features=3, num_blocks=2, output_multiplier=2)
+    assert not cmade.hip_hidden_supported()                    # needs its context
+    assert not cmade.hip_hidden_supported(torch.zeros(4, 3))   # ... on the device
+    assert not T.made.MADE(features=5, hidden_features=80, output_multiplier=2).hip_hidden_supported()
+    w, b = made.masked_final(64)
+    assert w.shape == (10, 64) and float(w[:, 20:].abs().max()) == 0.0
+    assert torch.equal(w[:, :20], made.final_layer.weight.detach() * made.final_layer.mask)
