@@ -88,7 +88,7 @@ struct HiddenLds {
 template <int NB, int K0S, int kCtx, int kAct>
 __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(HiddenArgs a) {
   using L = HiddenLds<NB, K0S, kCtx>;
-  constexpr bool kPrefetchX = FC_HIDDEN_PREFETCH_X && K0S == 1;   // (16 more live registers spill in the 64-input kernels)
+  constexpr bool kPrefetchX = FC_HIDDEN_PREFETCH_X && (K0S == 1 || kCtx != 0);   // (16 more live registers spill in the 64-input kernels without a context: 128-register budget)
   extern __shared__ __attribute__((aligned(16))) unsigned char hsmem[];
   f16x8* wfrag = reinterpret_cast<f16x8*>(hsmem);
   float* bias = reinterpret_cast<float*>(hsmem + (size_t)L::kFrags * 64 * 16);   // [layer][g][16]
@@ -307,15 +307,21 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
       }
   };
   const int64_t blk0 = (int64_t)blockIdx.x * (kHidThreads / 64) + wave;
-  f32x4 xin[4];
-  if (blk0 < a.blocks16) gather(blk0, xin);
+  f32x4 xpre[kPrefetchX ? 4 : 1];       // the next block's rows, one iteration ahead
+  if constexpr (kPrefetchX) {
+    if (blk0 < a.blocks16) gather(blk0, xpre);
+  }
   for (int64_t blk = blk0; blk < a.blocks16; blk += nwaves) {
     // the weight fragments are loop-invariant LDS loads: without this fence the compiler hoists all of them
     // out of the loop and spills
     asm volatile("" ::: "memory");
     const float* crow = kCtx ? a.ctx + (blk * 16 + s16) * C : nullptr;
-    if constexpr (!kPrefetchX) {
-      if (blk != blk0) gather(blk, xin);
+    f32x4 xin[4];
+    if constexpr (kPrefetchX) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xin[t] = xpre[t];
+    } else {
+      gather(blk, xin);
     }
     f16x8 bh[2], bl[2];
     f32x4 acc[4], h[4], tmid[4];
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
     // with an exposed memory latency)
     if constexpr (kPrefetchX) {
       const int64_t nxt = blk + nwaves < a.blocks16 ? blk + nwaves : blk;
-      gather(nxt, xin);
+      gather(nxt, xpre);
     }
     layer(0, K0S, bh, bl, acc);
     finish(0, un, acc, h);
