@@ -162,6 +162,36 @@ __global__ __launch_bounds__(256) void householder_kernel(const float* __restric
   }
 }
 
+// Rows of <= 16 features (the low-dimensional conditional flows): four samples per wave, one per 16-lane DPP row, so
+// all 64 lanes work and a dot product is four DPP row rotations (no cross-row step at all).
+__global__ __launch_bounds__(256) void householder_narrow_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 const float* __restrict__ q, int64_t n, int d,
+                                                                 int k_count, int per_sample, int reverse) {
+  const int lane = threadIdx.x & 63, j = lane & 15;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * 4;
+  for (int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 4; base < n; base += stride) {
+    const int64_t row = base + (lane >> 4);
+    const bool live = row < n && j < d;
+    const int64_t rr = row < n ? row : n - 1;
+    float v = live ? x[rr * d + j] : 0.f;
+    const float* qr = per_sample ? q + rr * (int64_t)k_count * d : q;
+    // the q rows of a sample do not depend on v: four in flight at a time
+    for (int t0 = 0; t0 < k_count; t0 += 4) {
+      float qv[4], c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u < k_count ? t0 + u : k_count - 1;
+        qv[u] = j < d ? qr[(int64_t)(reverse ? k_count - 1 - t : t) * d + j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c[u] = t0 + u < k_count ? 2.f / row16_allsum(qv[u] * qv[u]) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v -= row16_allsum(v * qv[u]) * (c[u] * qv[u]);
+    }
+    if (live) y[row * d + j] = v;
+  }
+}
+
 template <int E>
 __global__ __launch_bounds__(256) void planar_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                      float* __restrict__ lad, const float* __restrict__ w,
@@ -463,6 +493,11 @@ extern "C" int fc_householder(const float* x, float* y, const float* q, int64_t 
   if (n == 0) return hipSuccess;
   if (!x || !y || (!q && num_transforms > 0)) return hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d <= 16) {
+    hipLaunchKernelGGL(fc::householder_narrow_kernel, dim3(fc::row_grid((n + 3) / 4)), dim3(256), 0, s, x, y, q, n, d,
+                       num_transforms, per_sample, reverse);
+    return hipGetLastError();
+  }
   FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::householder_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x, y,
                                         q, n, d, num_transforms, per_sample, reverse));
   return hipGetLastError();

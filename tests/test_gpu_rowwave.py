@@ -294,3 +294,24 @@ def test_per_sample_linear_modes_over_widths(d, device):
     cond = float(torch.linalg.cond(lower @ upper).max())
     assert maxdiff(back, x) <= 1e-5 * max(1.0, cond) * max(1.0, float(x.abs().max())), (d, cond)
     assert maxdiff(lad_inv, -refs[ops.PER_SAMPLE_LU_FORWARD][1]) <= 2e-4 * max(1.0, float(refs[ops.PER_SAMPLE_LU_FORWARD][1].abs().max()))
+
+
+@pytest.mark.parametrize("d,k,n,per_sample", [(1, 1, 5, True), (2, 3, 1000, True), (5, 7, 333, True), (16, 16, 4099, True),
+                                              (16, 5, 64, False), (3, 2, 7, False), (15, 9, 250, True)])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_narrow_householder_rows(d, k, n, per_sample, reverse, device):
+    """Rows of <= 16 features run four samples per wave (one per DPP row); shared and per-sample q, both orders, batch
+    sizes that are not multiples of four; against the reflections in float64."""
+    torch.manual_seed(10 * d + k)
+    x = torch.randn(n, d)
+    q = torch.randn(n, k, d) if per_sample else torch.randn(k, d)
+    v = x.double()
+    qd = q.double()
+    order = range(k - 1, -1, -1) if reverse else range(k)
+    for i in order:
+        qi = qd[:, i] if per_sample else qd[i].expand(n, d)
+        v = v - (v * qi).sum(-1, keepdim=True) * (2.0 / (qi * qi).sum(-1, keepdim=True)) * qi
+    with torch.no_grad():
+        y = ops.householder(x.to(device), q.to(device), reverse=reverse)
+    assert y.shape == (n, d)
+    assert maxdiff(y, v) <= 2e-5 * max(1.0, float(v.abs().max()))
