@@ -468,6 +468,69 @@ __global__ __launch_bounds__(256) void linear_per_sample_kernel(const float* __r
   }
 }
 
+// The same four modes for matrices of <= 16 x 16 (low-dimensional conditional flows): four samples per wave, one per
+// 16-lane DPP row; lane j of a row holds x_j and column j of every matrix row, a dot product is four DPP rotations.
+__global__ __launch_bounds__(256) void linear_per_sample_narrow_kernel(const float* __restrict__ x,
+                                                                       float* __restrict__ y, float* __restrict__ lad,
+                                                                       const float* __restrict__ m, int64_t n, int d,
+                                                                       int mode, float sp, float eps) {
+  const int lane = threadIdx.x & 63, j = lane & 15, rowbase = lane & 48;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * 4;
+  for (int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * 4; base < n; base += stride) {
+    const int64_t row = base + (lane >> 4);
+    const int64_t rr = row < n ? row : n - 1;
+    const bool live = row < n && j < d;
+    const float* mr = m + rr * (int64_t)d * d;
+    float mi[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) mi[i] = (i < d && j < d) ? mr[i * d + j] : 0.f;
+    const float xj = j < d ? x[rr * d + j] : 0.f;
+    float out = 0.f, ld = 0.f, dg = 1.f;
+    if (mode >= 2) {
+      dg = j < d ? softplus1(mr[j * d + j]) + eps : 1.f;
+      ld = row16_allsum(j < d ? logf(dg) : 0.f);
+      if (mode == 3) ld = -ld;
+    }
+    auto pick = [&](float v, int i) { return __shfl(v, rowbase | i, 64); };   // lane i of this sample's row
+    if (mode == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float sres = row16_allsum(mi[i] * xj);
+        if (j == i) out = sres;
+      }
+    } else if (mode == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) out += mi[i] * pick(xj, i);
+    } else if (mode == 2) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float part = row16_allsum(j > i ? sp * mi[i] * xj : (j == i ? dg * xj : 0.f));
+        if (j == i) t = part;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float part = row16_allsum(j < i ? sp * mi[i] * t : (j == i ? t : 0.f));
+        if (j == i) out = part;
+      }
+    } else {
+      out = xj;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float part = row16_allsum(j < i ? sp * mi[i] * out : 0.f);
+        if (j == i) out -= part;
+      }
+#pragma unroll
+      for (int i = 15; i >= 0; --i) {
+        const float part = row16_allsum(j > i ? sp * mi[i] * out : 0.f);
+        if (j == i) out = (out - part) / dg;
+      }
+    }
+    if (live) y[row * d + j] = out;
+    if (lad && row < n && j == 0) lad[row] = ld;
+  }
+}
+
 inline unsigned row_grid(int64_t n) {
   int64_t g = (n + kWavesPerBlock - 1) / kWavesPerBlock;
   const int64_t cap = 256 * 8;
@@ -531,6 +594,11 @@ extern "C" int fc_linear_per_sample(const float* x, float* y, float* logabsdet, 
   if (n == 0) return hipSuccess;
   if (!x || !y || !m) return hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d <= 16) {
+    hipLaunchKernelGGL(fc::linear_per_sample_narrow_kernel, dim3(fc::row_grid((n + 3) / 4)), dim3(256), 0, s, x, y,
+                       logabsdet, m, n, d, mode, offdiag_scale, eps);
+    return hipGetLastError();
+  }
   FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::linear_per_sample_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x,
                                         y, logabsdet, m, n, d, mode, offdiag_scale, eps));
   return hipGetLastError();

@@ -263,7 +263,7 @@ def test_per_sample_sylvester_row_major_upper_triangles(d, m, n, device):
     assert maxdiff(lad, ref_lad) <= 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10)
 
 
-@pytest.mark.parametrize("d", [1, 2, 7, 8, 9, 33, 64, 65, 100, 128, 200, 257, 512])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 7, 8, 9, 15, 16, 17, 33, 64, 65, 100, 128, 200, 257, 512])
 def test_per_sample_linear_modes_over_widths(d, device):
     """fc_linear_per_sample (rows taken eight at a time, LU forward in one pass) over widths that are not multiples of
     the row batch / the wave: M x, M^T x, L (U x) and its inverse against float64 torch."""
