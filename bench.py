@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import flowconductor_amd  # noqa: E402,F401
-from flowconductor_amd import distributions, flows, ops, transforms, utils  # noqa: E402
+from flowconductor_amd import distributions, flows, ops, options, transforms, utils  # noqa: E402
 from flowconductor_amd.nn import nets  # noqa: E402
 
 FEATURES, LAYERS, BINS, HIDDEN, BLOCKS, TAIL_BOUND = 64, 32, 8, 64, 2, 3.0
@@ -274,11 +274,9 @@ def main():
         if fused_path:
             # the stand-alone spline kernel does not run in the fused flow: time it in one extra, untimed
             # pass with the fusion switched off (same flow, same inputs) for the HBM-roofline entry
-            os.environ["FC_FUSED"] = "0"
-            with ops.KernelTimer("fc_rq_spline") as extra, torch.no_grad():
+            with options.override(fused_final_layer=False), ops.KernelTimer("fc_rq_spline") as extra, torch.no_grad():
                 parallel.local_log_prob(flow.log_prob, x, chunk=chunk)  # rank-local: no collective here
             torch.cuda.synchronize(device)
-            os.environ.pop("FC_FUSED")
             kernel_ms = extra.durations_ms()
         else:
             kernel_ms = timer.durations_ms()

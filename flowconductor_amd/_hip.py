@@ -10,8 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FLOWCON_HIP_LIB points profiling tools at an ablation build of the same ABI (tools/ only)
-LIB_PATH = os.environ.get("FLOWCON_HIP_LIB") or os.path.join(_HERE, "csrc", "libflowcon_hip.so")
+# The product library, built in-tree.  Nothing in the environment redirects it: profiling tools that want an ablation
+# build of the same ABI call ``use_library(path)`` explicitly before the first kernel call (tools/ only).
+LIB_PATH = os.path.join(_HERE, "csrc", "libflowcon_hip.so")
 
 ABI_VERSION = 1
 
@@ -103,6 +104,25 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+def use_library(path):
+    """tools/ only: bind an ablation build of the same ABI instead of the product library.  Must be called before
+    the first kernel call; refuses to swap a library that is already loaded."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("flowconductor_amd: %s is already loaded" % LIB_PATH)
+    LIB_PATH = os.path.abspath(path)
+
+
+def library_info():
+    """``{"path", "sha256", "bytes"}`` of the library the kernels come from (bench.py records it)."""
+    import hashlib
+
+    with open(LIB_PATH, "rb") as f:
+        blob = f.read()
+    return {"path": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)), "sha256": hashlib.sha256(blob).hexdigest(),
+            "bytes": len(blob)}
 
 
 def load():

@@ -6,6 +6,7 @@
 // once.  HBM-bound: reads [N, D] once, writes [N].
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "fc_device.h"
 #include "../../include/flowcon_hip.h"
 
 namespace fc {
@@ -79,10 +80,7 @@ extern "C" int fc_standard_normal_log_prob(const float* z, const float* add, flo
   int t = 1;
   while (t < items && t < 64) t <<= 1;
   const int rows_per_block = 256 / t;
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-    cus = prop.multiProcessorCount;
+  const int cus = fc::device_cu_count();
   int64_t grid = (n + rows_per_block - 1) / rows_per_block;
   if (grid > (int64_t)cus * 16) grid = (int64_t)cus * 16;   // grid-stride: 16 blocks of 256 threads per CU
   dim3 g((unsigned)grid);

@@ -35,6 +35,7 @@
 #include "fc_split.h"
 #include "fc_lane.h"
 #include "fc_math.h"
+#include "fc_device.h"
 #include "../../include/flowcon_hip.h"
 
 #ifndef FC_HIDDEN_PREFETCH_X
@@ -420,13 +421,10 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
 template <int NB, int K0S, int kCtx, int kAct>
 hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
   using L = HiddenLds<NB, K0S, kCtx>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx, kAct>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce attr;
+  const hipError_t ea = ensure_max_dynamic_lds(
+      attr, reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx, kAct>), 160 * 1024);
+  if (ea != hipSuccess) return ea;
   hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S, kCtx, kAct>), dim3((unsigned)grid), dim3(kHidThreads), L::kBytes,
                      s, a);
   return hipGetLastError();
@@ -434,10 +432,7 @@ hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
 
 template <int kCtx, int kAct>
 hipError_t dispatch_hidden(const HiddenArgs& a, int num_blocks, hipStream_t s) {
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-    cus = prop.multiProcessorCount;
+  const int cus = device_cu_count();
   // two 512-thread workgroups per CU when two weight images fit in LDS (<= 2 blocks at <= 32 inputs, no
   // context), else one
   const bool wide = a.k0 + (kCtx == 1 ? a.C : 0) > 32;

@@ -410,13 +410,10 @@ template <bool kInv, int R, int XV, bool kFull, bool kPadX>
 static hipError_t launch_cfg(const RQOp<kK>& op, const FusedArgs& a, unsigned grid, hipStream_t stream) {
   const size_t lds = Fused3Lds<R>::bytes(a.D);
   if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rq_fused_linear_kernel3<kInv, R, XV, kFull, kPadX>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce attr;
+  const hipError_t ea = ensure_max_dynamic_lds(
+      attr, reinterpret_cast<const void*>(&rq_fused_linear_kernel3<kInv, R, XV, kFull, kPadX>), 160 * 1024);
+  if (ea != hipSuccess) return ea;
   hipLaunchKernelGGL((rq_fused_linear_kernel3<kInv, R, XV, kFull, kPadX>), dim3(grid), dim3(512), lds, stream, op, a);
   return hipGetLastError();
 }

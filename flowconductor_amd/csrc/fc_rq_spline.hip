@@ -7,7 +7,6 @@
 //            (utils/torchutils.py:147-149), forward rational-quadratic / inverse quadratic root.
 // One thread evaluates one (sample, dim); the K unnormalised widths/heights sit in LDS and
 // are walked with static offsets so no runtime-indexed register array (-> scratch) exists.
-#include <stdlib.h>
 #include "fc_tile.h"
 #include "fc_math.h"
 #include "fc_rq_op.h"
@@ -93,16 +92,16 @@ __global__ __launch_bounds__(256) void rq_wave_kernel(RQOp<KS> op, TileArgs a, i
 }
 
 template <int KS>
-static hipError_t launch_rq(const RQParams& q, TileArgs a, hipStream_t stream) {
+static hipError_t launch_rq(const RQParams& q, TileArgs a, int flags, hipStream_t stream) {
   RQOp<KS> op;
   op.q = q;
   op.inv_div = 1.f / q.wh_div;
   op.inv_beta = 1.f / q.beta;
   const bool pow2 = (a.d_t & (a.d_t - 1)) == 0 && a.d_t <= 64;
-  const char* force = getenv("FC_RQ_PATH");  // "tile" / "wave": pin one structure (A/B measurements)
+  const bool force_tile = (flags & FC_RQ_FORCE_TILE) != 0;   // pin the LDS-tile structure (A/B measurements)
   if constexpr (KS > 0 && KS <= 10)
   if (pow2 && !a.shared_params && a.N > 0 && a.lad_mode != 1 && a.lad_mode != 3 &&
-      !(force && force[0] == 't')) {
+      !force_tile) {
     const int G = 64 / a.d_t;
     const int64_t groups = a.N / G;
     const bool al = ((G * a.D) % 4 != 0) || (aligned16(a.x) && aligned16(a.y));
@@ -160,11 +159,11 @@ extern "C" int fc_rq_spline(const float* x, float* y, const float* params, const
   a.lad_mode = lad_mode;
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (q.K) {
-    case 4: return fc::launch_rq<4>(q, a, s);
-    case 5: return fc::launch_rq<5>(q, a, s);
-    case 8: return fc::launch_rq<8>(q, a, s);
-    case 10: return fc::launch_rq<10>(q, a, s);
-    case 16: return fc::launch_rq<16>(q, a, s);
-    default: return fc::launch_rq<0>(q, a, s);
+    case 4: return fc::launch_rq<4>(q, a, cfg->flags, s);
+    case 5: return fc::launch_rq<5>(q, a, cfg->flags, s);
+    case 8: return fc::launch_rq<8>(q, a, cfg->flags, s);
+    case 10: return fc::launch_rq<10>(q, a, cfg->flags, s);
+    case 16: return fc::launch_rq<16>(q, a, cfg->flags, s);
+    default: return fc::launch_rq<0>(q, a, cfg->flags, s);
   }
 }

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fc_split.h"
+#include "fc_device.h"
 #include "fc_lane.h"
 #include "../../include/flowcon_hip.h"
 
@@ -196,13 +197,10 @@ template <int KS, bool kDense>
 static hipError_t launch_syl(const SylArgs& a, int cus, hipStream_t s) {
   constexpr int NT = 2 * KS;
   const size_t lds = (size_t)2 * KS * NT * 2 * 64 * 16 + (2 * 4 * NT * 4 + 16) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sylvester_mm_kernel<KS, kDense>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static PerDeviceOnce attr;
+  const hipError_t ea = ensure_max_dynamic_lds(attr, reinterpret_cast<const void*>(&sylvester_mm_kernel<KS, kDense>),
+                                               160 * 1024);
+  if (ea != hipSuccess) return ea;
   int64_t grid = cus;
   const int64_t need = (a.blocks16 + 7) / 8;
   if (grid > need) grid = need;
@@ -219,10 +217,7 @@ extern "C" int fc_sylvester_mm(const float* x, float* y, float* logabsdet, const
   if (!x || !y || !logabsdet || !w1 || !w2 || !bias || !r_diag_prod) return hipErrorInvalidValue;
   if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return hipErrorInvalidValue;
   fc::SylArgs a{x, y, logabsdet, w1, w2, bias, r_diag_prod, n / 16};
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-    cus = prop.multiProcessorCount;
+  const int cus = fc::device_cu_count();
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (d / 32) {
     case 1: return fc::launch_syl<1, false>(a, cus * 2, s);
@@ -239,10 +234,7 @@ extern "C" int fc_dense_mm(const float* x, float* y, const float* w, const float
   if (!x || !y || !w) return hipErrorInvalidValue;
   if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return hipErrorInvalidValue;
   fc::SylArgs a{x, y, nullptr, w, nullptr, bias, nullptr, n / 16};
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-    cus = prop.multiProcessorCount;
+  const int cus = fc::device_cu_count();
   hipStream_t s = static_cast<hipStream_t>(stream);
   switch (d / 32) {
     case 1: return fc::launch_syl<1, true>(a, cus * 2, s);

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "fc_device.h"
 
 namespace fc {
 
@@ -349,18 +350,6 @@ inline bool plan_tile(const TileArgs& a, TilePlan* plan) {
   plan->vec_ok = strides_ok && aligned16(a.x) && aligned16(a.y) && aligned16(a.params);
   plan->grid = (a.N + S - 1) / S;
   return true;
-}
-
-inline int device_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
-  }
-  return cus;
 }
 
 template <class Op, int NVP, int NVX>

@@ -89,15 +89,24 @@ class ResidualNet(nn.Module):
         return self.final_layer(self.hidden(inputs, context))
 
     def _hip_forward_ok(self, inputs, context):
-        import os
+        from flowconductor_amd import options
+
+        from flowconductor_amd import ops
 
         if not (inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32 and inputs.shape[0] >= 16
-                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"):
+                and options.get("fused_hidden") and not ops.has_hooks(self)):
             return False
         if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False        # training: PyTorch autograd
         return inputs.shape[1] + (0 if context is None else self.context_features or 0) == self.initial_layer.in_features \
             and self.hip_hidden_supported(inputs.shape[1], context)
+
+    def train(self, mode=True):
+        """Switching into or out of training mode drops the packed-weight caches (``ops.invalidate_hip_caches``)."""
+        from flowconductor_amd import ops
+
+        ops.invalidate_hip_caches()
+        return super().train(mode)
 
     # ---- device fast path for the hidden layers (inference) ------------------------------------------
     def hip_hidden_supported(self, features_total, context=None):
@@ -143,10 +152,12 @@ class ResidualNet(nn.Module):
 
     def final_from_padded(self, hidden64):
         """``final_layer`` applied to a [N, 64] zero-padded hidden activation."""
+        from flowconductor_amd import ops
+
         lin = self.final_layer
         if lin.in_features == 64:
             return lin(hidden64)
-        key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device)
+        key = ops.cache_key(lin.weight)
         if getattr(self, "_final_padded", None) is None or self._final_padded[0] != key:
             self._final_padded = (key, F.pad(lin.weight.detach(), (0, 64 - lin.in_features)))
         return F.linear(hidden64, self._final_padded[1], lin.bias)
@@ -156,7 +167,7 @@ class ResidualNet(nn.Module):
         narrower net columns ``hidden_features``.. are zero."""
         from flowconductor_amd import ops
 
-        key = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        key = ops.cache_key(*self.parameters())
         if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
             self._hip_packed = (key, ops.pack_resnet_hidden(self))
         in_features = self.initial_layer.in_features - (self.context_features or 0)

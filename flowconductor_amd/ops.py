@@ -11,7 +11,7 @@ import threading
 import numpy as np
 import torch
 
-from flowconductor_amd import _hip
+from flowconductor_amd import _hip, options
 
 
 class InverseNotAvailable(Exception):
@@ -136,11 +136,45 @@ def _as_cols(cols, device):
     return cols
 
 
-def _prep_2d(inputs, name="inputs"):
+def _prep_2d(inputs, name="inputs", align16=False):
     x = _hip.dev_f32(inputs, name)
     if x.dim() != 2:
         raise ValueError("%s must be [batch, features], got shape %s" % (name, tuple(x.shape)))
-    return x
+    return _aligned16(x) if align16 else x
+
+
+def _aligned16(t):
+    """The matrix-core kernels move rows as 16-byte pieces: a contiguous view that starts off a 16-byte boundary
+    (``data[1:]`` with a feature count that is not a multiple of 4) is copied to a fresh allocation first."""
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
+# ---- packed-weight caches ---------------------------------------------------------------------------------------
+#
+# Layers cache kernel-layout copies of their weights (pre-masked, zero-padded, folded matrices), keyed on the
+# parameters' version counters and storage pointers.  In-place writes THROUGH ``.data`` (``p.data.copy_(ema)``,
+# ``p.data.clamp_()``, some checkpoint loaders) change neither; ``invalidate_hip_caches()`` bumps an epoch that is
+# part of every key.  ``nn.Module.train()`` of this package's modules calls it, so a cache never survives a switch
+# into or out of training mode; after ``.data`` surgery on an eval-mode model call it yourself.
+
+_cache_epoch = 0
+
+
+def invalidate_hip_caches():
+    """Drop every packed-weight cache of this package (re-packed on the next call that needs them)."""
+    global _cache_epoch
+    _cache_epoch += 1
+
+
+def cache_key(*tensors, extra=()):
+    """Key of a packed copy of ``tensors``: version counter, storage pointer and device of each + the epoch."""
+    return tuple((t._version, t.data_ptr(), t.device) for t in tensors) + (_cache_epoch,) + tuple(extra)
+
+
+def has_hooks(module):
+    """True when ``module`` or a sub-module carries forward (pre-)hooks (old-style weight_norm refreshes ``weight``
+    in one): the fast paths read the weights directly and never go through ``__call__``, so they step aside."""
+    return any(m._forward_hooks or m._forward_pre_hooks for m in module.modules())
 
 
 LAD_STORE, LAD_ACCUMULATE, LAD_STORE_NEG, LAD_ACCUMULATE_NEG = 0, 1, 2, 3
@@ -171,6 +205,10 @@ class KernelTimer:
 
 def _call(name, fn, device, *args):
     """Launch C-ABI entry ``fn`` (asynchronous), bracketing it with events for active timers."""
+    if device.index is not None and device.index != torch.cuda.current_device():
+        # the launchers size grids and set kernel attributes for the CURRENT device: make it the tensors' device
+        with torch.cuda.device(device):
+            return _call(name, fn, device, *args)
     timers = [t for t in KernelTimer._active if t.name == name]
     if timers:
         start = torch.cuda.Event(enable_timing=True)
@@ -246,6 +284,8 @@ def rq_spline(inputs, params, cols=None, *, num_bins, tails=None, tail_bound=1.0
     cfg = _rq_config(num_bins, tails, tail_bound, (left, right, bottom, top), min_bin_width, min_bin_height,
                      min_derivative, enable_identity_init, wh_divisor, inverse)
 
+    if options.get("rq_force_tile"):
+        cfg.flags |= 2  # FC_RQ_FORCE_TILE
     y = torch.empty_like(x) if out is None else out
     lad = torch.empty(n, dtype=torch.float32, device=x.device)
     err = _err_word(x.device, True)
@@ -473,8 +513,8 @@ def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, t
     tensor is returned.  ``enable_identity_init``: the autoregressive form's softplus beta
     (autoregressive.py:612)."""
     lib = _hip.load()
-    x = _prep_2d(inputs)
-    h = _hip.dev_f32(hidden, "hidden")
+    x = _prep_2d(inputs, align16=True)
+    h = _aligned16(_hip.dev_f32(hidden, "hidden"))
     _hip.require_no_grad(inputs, hidden)
     n, d = x.shape
     cols = _as_cols(cols, x.device)
@@ -812,8 +852,8 @@ def batchnorm_eval(inputs, mean, std, weight, bias, inverse=False):
 MAX_ROW_FEATURES = 512
 
 
-def _rows(inputs, name="inputs"):
-    x = _prep_2d(inputs, name)
+def _rows(inputs, name="inputs", align16=False):
+    x = _prep_2d(inputs, name, align16)
     if x.shape[1] > MAX_ROW_FEATURES:
         raise ValueError("flowconductor_amd: %d features exceed the %d supported by the row kernels"
                          % (x.shape[1], MAX_ROW_FEATURES))
@@ -1026,7 +1066,7 @@ def dense_mm(inputs, weight, bias=None):
     """``inputs @ weight.T + bias`` for a batch-independent [D, D] ``weight`` on the matrix cores (rows a multiple
     of 16, D % 32 == 0, D <= 128): f32-GEMM accuracy by split-f16 products."""
     lib = _hip.load()
-    x = _rows(inputs)
+    x = _rows(inputs, align16=True)
     _hip.require_no_grad(inputs)
     n, d = x.shape
     if n % SYLVESTER_MM_ROWS != 0 or not sylvester_mm_supported(n, d):
@@ -1044,7 +1084,7 @@ def dense_mm(inputs, weight, bias=None):
 def sylvester_mm(inputs, w1, w2, bias, rdiag):
     """Sylvester flow forward + logabsdet with shared parameters as two matrix-core products (rows a multiple of 16)."""
     lib = _hip.load()
-    x = _rows(inputs)
+    x = _rows(inputs, align16=True)
     _hip.require_no_grad(inputs)
     n, d = x.shape
     if n % SYLVESTER_MM_ROWS != 0 or not sylvester_mm_supported(n, d):

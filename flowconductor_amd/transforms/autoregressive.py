@@ -4,13 +4,12 @@
 (reference autoregressive.py:39-53), each of which here only computes what it fixes: the
 hidden stack, the final-layer rows of dim d and the element-wise inverse of column d.
 """
-import os
 
 import numpy as np
 import torch
 from torch.nn import functional as F
 
-from flowconductor_amd import ops
+from flowconductor_amd import ops, options
 from flowconductor_amd.transforms import made as made_module
 from flowconductor_amd.transforms.base import Transform
 
@@ -35,9 +34,9 @@ class AutoregressiveTransform(Transform):
             return None
         n = inputs.shape[0]
         if (inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
-                and n >= ops.HIDDEN_ROWS and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
+                and n >= ops.HIDDEN_ROWS and options.get("fused_hidden")
                 and getattr(net, "hip_hidden_supported", None) is not None and net.hip_hidden_supported(context)
-                and not self._needs_grad(inputs)):
+                and not ops.has_hooks(net) and not self._needs_grad(inputs)):
             body = n - n % ops.HIDDEN_ROWS
             hidden = net.hidden_hip(inputs[:body].contiguous(), None if context is None else context[:body])
             if body < n:
@@ -101,8 +100,8 @@ class AutoregressiveTransform(Transform):
         net = self.autoregressive_net
         return (isinstance(net, made_module.MADE) and inputs.dim() == 2 and inputs.shape[1] > 1
                 and ((net.final_layer.out_features >= 8 * inputs.shape[1] and inputs.shape[0] >= 8192)
-                     or os.environ.get("FC_AR_INCREMENTAL") == "force")
-                and os.environ.get("FC_AR_INCREMENTAL", "1") != "0" and not self._needs_grad(inputs)
+                     or options.get("ar_incremental") == "force")
+                and options.get("ar_incremental") != "off" and not self._needs_grad(inputs)
                 and not net._forward_hooks and not net._forward_pre_hooks)
 
     def _inverse_incremental(self, inputs, context):
@@ -256,17 +255,17 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
     def _fused_forward_ok(self, inputs, context):
         net = self.autoregressive_net
         return (inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
-                and os.environ.get("FC_FUSED", "1") != "0" and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
+                and options.get("fused_final_layer") and options.get("fused_hidden")
                 and isinstance(net, made_module.MADE) and not hasattr(net, "hidden_features")
                 and net.final_layer.in_features <= 64 and net.hip_hidden_supported(context)
                 and inputs.shape[0] >= ops.FUSED_ROWS
                 and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], inputs.shape[1],
                                                net.final_layer.in_features, self.num_bins, self.tails)
-                and not net._forward_hooks and not net._forward_pre_hooks and not self._needs_grad(inputs))
+                and not ops.has_hooks(net) and not self._needs_grad(inputs))
 
     def _packed_final_layer(self, device):
         lin = self.autoregressive_net.final_layer
-        key = (lin.weight._version, lin.bias._version, lin.weight.device, lin.weight.data_ptr())
+        key = ops.cache_key(lin.weight, lin.bias)
         if getattr(self, "_packed", None) is None or self._packed[0] != key:
             masked = (lin.weight * lin.mask).detach()
             w_pad, b_pad = ops.pack_final_layer(masked, lin.bias, self.num_bins)

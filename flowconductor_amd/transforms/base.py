@@ -61,6 +61,12 @@ class Transform(nn.Module):
     def inverse(self, inputs, context=None):
         raise InverseNotAvailable()
 
+    def train(self, mode=True):
+        """Packed-weight caches (kernel-layout copies of parameters) never survive a switch of the training mode:
+        see ``ops.invalidate_hip_caches``."""
+        ops.invalidate_hip_caches()
+        return super().train(mode)
+
 
 class CompositeTransform(Transform):
     """Composes several transforms into one, in the order they are given."""

@@ -4,14 +4,14 @@ the context instead of from the inputs (API of flowcon/transforms/conditional.py
 The conditional network is a PyTorch-ROCm module (ResidualNet / MLP); every bijector application is the
 same HIP kernel as its coupling / autoregressive sibling, fed per-sample parameter rows.
 """
-import os
 
 import numpy as np
 import torch
 from torch.nn import functional as F
 
-from flowconductor_amd import ops
+from flowconductor_amd import ops, options
 from flowconductor_amd.nn.nets import MLP, ResidualNet
+from flowconductor_amd.transforms.coupling import _is_plain_resnet
 from flowconductor_amd.transforms.base import Transform
 from flowconductor_amd.transforms.orthogonal import ParametrizedHouseHolder
 
@@ -61,10 +61,10 @@ class ConditionalTransform(Transform):
     # ---- the hyper-network on the matrix cores (inference) ------------------------------------------------------
     def _hip_hidden_ok(self, context):
         net = self.conditional_net
-        return (type(net) is ResidualNet and context.dim() == 2 and context.is_cuda
+        return (_is_plain_resnet(net) and context.dim() == 2 and context.is_cuda
                 and context.dtype == torch.float32 and context.shape[0] >= ops.HIDDEN_ROWS
-                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0" and net.hip_hidden_supported(context.shape[1])
-                and not net._forward_hooks and not net._forward_pre_hooks
+                and options.get("fused_hidden") and net.hip_hidden_supported(context.shape[1])
+                and not ops.has_hooks(net)
                 and not (torch.is_grad_enabled()
                          and (context.requires_grad or any(p.requires_grad for p in net.parameters()))))
 
@@ -161,7 +161,7 @@ class ConditionalLUTransform(ConditionalTransform):
 
     def _offdiag_scale(self):
         # softplus of a 0-dim parameter: read back once per value (it only changes when trained)
-        key = self.scale_non_diag._version
+        key = ops.cache_key(self.scale_non_diag)
         if self._sp_cache is None or self._sp_cache[0] != key:
             self._sp_cache = (key, float(F.softplus(self.scale_non_diag.detach())))
         return self._sp_cache[1]
@@ -365,7 +365,7 @@ class ConditionalPiecewiseRationalQuadraticTransform(ConditionalTransform):
     # directions in one pass (the parameters depend on the context only)
     def _fused_ok(self, inputs, context):
         return (context is not None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
-                and inputs.shape[0] == context.shape[0] and os.environ.get("FC_FUSED", "1") != "0"
+                and inputs.shape[0] == context.shape[0] and options.get("fused_final_layer")
                 and self._hip_hidden_ok(context) and not (torch.is_grad_enabled() and inputs.requires_grad)
                 and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], inputs.shape[1],
                                                self.conditional_net.hidden_features, self.num_bins, self.tails))
@@ -373,7 +373,7 @@ class ConditionalPiecewiseRationalQuadraticTransform(ConditionalTransform):
     def _fused(self, inputs, context, inverse):
         net = self.conditional_net
         lin = net.final_layer
-        key = (lin.weight._version, lin.bias._version, lin.weight.device, lin.weight.data_ptr())
+        key = ops.cache_key(lin.weight, lin.bias)
         if getattr(self, "_packed", None) is None or self._packed[0] != key:
             w_pad, b_pad = ops.pack_final_layer(lin.weight, lin.bias, self.num_bins)
             cols = torch.arange(self.features, dtype=torch.int32, device=lin.weight.device)

@@ -7,14 +7,22 @@ reduction are ONE HIP kernel launch per layer: the kernel reads the full ``[N, D
 the conditioner's ``[N, d_t * multiplier]`` output once, writes the full output once
 (identity columns copied through LDS) and the ``[N]`` logabsdet once.
 """
-import os
 import warnings
 
 import numpy as np
 import torch
 
-from flowconductor_amd import ops
+from flowconductor_amd import ops, options
 from flowconductor_amd.transforms.base import Transform
+
+
+def _is_plain_resnet(net):
+    """This package's ResidualNet, or a subclass that keeps its ``forward`` / ``hidden`` (a subclass that overrides
+    either computes something the kernels do not know about and takes the generic path)."""
+    from flowconductor_amd.nn.nets.resnet import ResidualNet
+
+    return (isinstance(net, ResidualNet) and type(net).forward is ResidualNet.forward
+            and type(net).hidden is ResidualNet.hidden)
 
 
 def _rows_from_nchw(t):
@@ -123,13 +131,11 @@ class CouplingTransform(Transform):
         layers run in that one kernel,
         straight from the full input rows, and only the final Linear stays a library GEMM -- for every coupling
         bijector (affine, additive, all splines), inference only."""
-        from flowconductor_amd.nn.nets.resnet import ResidualNet
-
         net = self.transform_net
         n = inputs.shape[0]
-        if (type(net) is ResidualNet and self.unconditional_transform is None
+        if (_is_plain_resnet(net) and not ops.has_hooks(net) and self.unconditional_transform is None
                 and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32 and n >= ops.HIDDEN_ROWS
-                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
+                and options.get("fused_hidden")
                 and net.hip_hidden_supported(inputs.shape[1], context)
                 and not (torch.is_grad_enabled()
                          and (inputs.requires_grad or any(p.requires_grad for p in net.parameters())))):
@@ -298,12 +304,11 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
     # Any other conditioner / shape takes the generic path; FC_FUSED=0 disables it.
 
     def _fused_ok(self, inputs):
-        from flowconductor_amd.nn.nets.resnet import ResidualNet
-
         net = self.transform_net
         if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in net.parameters())):
             return False   # training: conditioner on PyTorch autograd + the spline's own backward kernel
-        return (os.environ.get("FC_FUSED", "1") != "0" and type(net) is ResidualNet and inputs.dim() == 2
+        return (options.get("fused_final_layer") and _is_plain_resnet(net) and not ops.has_hooks(net)
+                and inputs.dim() == 2
                 and inputs.is_cuda and inputs.dtype == torch.float32
                 and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1],
                                                min(self.num_transform_features, ops.FUSED_DT),
@@ -313,7 +318,7 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         """[(w_pad, bias_pad, cols)] per group of <= 32 transformed dims: the final Linear's rows of those dims in
         the kernel's layout + their column indices."""
         lin = self.transform_net.final_layer
-        key = (lin.weight._version, lin.bias._version, lin.weight.device, lin.weight.data_ptr())
+        key = ops.cache_key(lin.weight, lin.bias)
         if getattr(self, "_packed", None) is None or self._packed[0] != key:
             per_dim = 3 * self.num_bins - 1
             cols = self._cols(device)
@@ -344,7 +349,7 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         body16 = n - n % ops.HIDDEN_ROWS
         identity_split = logabsdet_identity = None
         if (self.unconditional_transform is None and body16 > 0
-                and os.environ.get("FC_FUSED_HIDDEN", "1") != "0"
+                and options.get("fused_hidden")
                 and net.hip_hidden_supported(inputs.shape[1], context)):
             # hidden layers of the conditioner in one matrix-core kernel straight from the full input rows: the
             # identity half is never gathered into a separate tensor

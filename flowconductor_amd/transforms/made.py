@@ -202,7 +202,7 @@ class MADE(nn.Module):
 
         layers = [self.initial_layer] + [lin for block in self.blocks for lin in block.linear_layers]
         ctx_layers = ([self.context_layer] + [block.context_layer for block in self.blocks]) if context is not None else []
-        key = tuple((lin.weight._version, lin.bias._version, lin.weight.data_ptr()) for lin in layers + ctx_layers)
+        key = ops.cache_key(*[t for lin in layers + ctx_layers for t in (lin.weight, lin.bias)])
         if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
             hw = ops.FUSED_HIDDEN
             masked = [ops._pad_to((lin.weight * lin.mask).detach(), (hw, lin.in_features if i == 0 else hw))
@@ -225,7 +225,9 @@ class MADE(nn.Module):
         the columns with zeros (for a zero-padded hidden activation)."""
         lin = self.final_layer
         width = lin.in_features if width is None else width
-        key = (lin.weight._version, lin.weight.data_ptr(), lin.weight.device, width)
+        from flowconductor_amd import ops
+
+        key = ops.cache_key(lin.weight, extra=(width,))
         cache = getattr(self, "_masked_final", None)
         if cache is None or cache[0] != key:
             w = (lin.weight * lin.mask).detach()

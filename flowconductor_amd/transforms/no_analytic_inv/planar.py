@@ -2,14 +2,13 @@
 
 Forward direction only, like the reference.  Each is one fused row-per-wavefront HIP kernel.
 """
-import os
 
 import numpy as np
 import torch
 from torch import nn
 from torch.nn import init
 
-from flowconductor_amd import ops
+from flowconductor_amd import ops, options
 from flowconductor_amd.transforms.base import Transform
 from flowconductor_amd.transforms.orthogonal import HouseholderSequence
 
@@ -94,7 +93,7 @@ class SylvesterTransform(Transform):
         """(W1, W2, r_diag_prod) for the matrix-core kernel, recomputed only when a parameter changed."""
         params = (self.Q_orth.q_vectors, self.upper_entries1, self.log_upper_diag1, self.upper_entries2,
                   self.log_upper_diag2)
-        key = tuple((p._version, p.data_ptr()) for p in params)
+        key = ops.cache_key(*params)
         if getattr(self, "_mm_cache", None) is None or self._mm_cache[0] != key:
             self._mm_cache = (key, ops.pack_sylvester(self.Q_orth.q_vectors, self._create_R1(), self._create_R2()))
         return self._mm_cache[1]
@@ -107,7 +106,7 @@ class SylvesterTransform(Transform):
         with torch.no_grad():
             n = inputs.shape[0]
             if (inputs.dim() == 2 and inputs.is_cuda and ops.sylvester_mm_supported(n, self.features)
-                    and os.environ.get("FC_SYLVESTER_MM", "1") != "0"):
+                    and options.get("sylvester_mm")):
                 # batch-independent parameters: the Householder / triangular chains fold into two dense
                 # [D, D] matrices and the batch goes through the matrix cores
                 w1, w2, rdiag = self._mm_weights()
@@ -121,4 +120,4 @@ class SylvesterTransform(Transform):
             return ops.sylvester(inputs, self.Q_orth.q_vectors, self._create_R1(), self._create_R2(), self.bias)
 
     def inverse(self, inputs, context=None):
-        raise NotImplementedError("ups")
+        raise ops.InverseNotAvailable()

@@ -41,6 +41,8 @@ int fc_abi_version(void);
 /* ---- rational-quadratic spline ------------------------------------------------------- */
 #define FC_RQ_ACCUMULATE_LOGABSDET 1 /* fc_rq_spline_fused_linear: logabsdet[n] += sum (the caller's running
                                        total of CompositeTransform._cascade, transforms/base.py:45-52) */
+#define FC_RQ_FORCE_TILE 2 /* fc_rq_spline: always the LDS-tile kernel, never the register / wave kernel (A/B
+                              measurements; the results are the same) */
 
 typedef struct fc_rq_config {
   int32_t num_bins;       /* K */

@@ -1,12 +1,13 @@
 """Column-at-a-time inverse of the masked autoregressive transforms against the reference's
 D-full-passes scheme (autoregressive.py:44-53), restated by the oracle and by this package with
-FC_AR_INCREMENTAL=0."""
+options ar_incremental = "off"."""
 import copy
 
 import pytest
 import torch
 
 from _util import maxdiff
+from flowconductor_amd import options
 from oracle import torch_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -66,10 +67,10 @@ def test_incremental_inverse_matches_full_passes(kind, features, hidden, n, devi
         assert not t._incremental_ok(x.to(device))
         big = torch.zeros(8192, features, device=device)
         assert t._incremental_ok(big) == (kind not in ("maf", "shift"))
-        monkeypatch.setenv("FC_AR_INCREMENTAL", "force")
+        monkeypatch.setitem(options._values, "ar_incremental", "force")
         assert t._incremental_ok(x.to(device))
         y, lad = t.inverse(x.to(device))
-        monkeypatch.setenv("FC_AR_INCREMENTAL", "0")
+        monkeypatch.setitem(options._values, "ar_incremental", "off")
         assert not t._incremental_ok(x.to(device))
         y_full, lad_full = t.inverse(x.to(device))
     # D chained conditioner passes amplify rounding (the quadratic spline's inverse is ill-conditioned near its
@@ -92,7 +93,7 @@ def test_incremental_inverse_random_masks_round_trip(device, monkeypatch):
             p.mul_(1.5)
     t = t.to(device)
     z = torch.randn(500, 7, device=device)
-    monkeypatch.setenv("FC_AR_INCREMENTAL", "force")
+    monkeypatch.setitem(options._values, "ar_incremental", "force")
     with torch.no_grad():
         assert t._incremental_ok(z)
         x, lad_inv = t.inverse(z)
@@ -131,7 +132,7 @@ def test_rq_autoregressive_forward_on_fused_kernels(features, n, device, monkeyp
         with ops.KernelTimer("fc_rq_spline_fused_linear") as timer:
             y, lad = t(x.to(device))
         assert len(timer.pairs) == 1, "the fused final-layer + spline kernel did not run"
-        monkeypatch.setenv("FC_FUSED", "0")
+        monkeypatch.setitem(options._values, "fused_final_layer", False)
         y_unfused, lad_unfused = t(x.to(device))
     tol_y = 2e-5 * max(1.0, float(ref_y.abs().max())) + 4 * maxdiff(ref_y, ref_y64)
     tol_l = 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10) + 4 * maxdiff(ref_lad, ref_lad64)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from _util import maxdiff
-from flowconductor_amd import ops
+from flowconductor_amd import ops, options
 from oracle import torch_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -91,7 +91,7 @@ def test_conditional_coupling_flow(kind, n, device, monkeypatch):
         with ops.KernelTimer("fc_resnet_hidden_context") as timer:
             got = flow.log_prob(x.to(device), c.to(device))
         assert len(timer.pairs) == 4, "the context variant of the hidden-layer kernel did not run"
-        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        monkeypatch.setitem(options._values, "fused_hidden", False)
         got_torch = flow.log_prob(x.to(device), c.to(device))
         z, _ = flow._transform(x.to(device), c.to(device))
         back, _ = flow._transform.inverse(z, c.to(device))
@@ -174,7 +174,7 @@ def test_conditional_autoregressive_flow(kind, device, monkeypatch):
             assert len(fused.pairs) == 2
         z, _ = flow._transform(x.to(device), c.to(device))
         back, _ = flow._transform.inverse(z, c.to(device))
-        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        monkeypatch.setitem(options._values, "fused_hidden", False)
         got_torch = flow.log_prob(x.to(device), c.to(device))
     tol = 3e-4 * max(1.0, float(ref.abs().max()) / 10)
     assert maxdiff(got, ref) <= tol and maxdiff(got, got_torch) <= tol
@@ -216,7 +216,7 @@ def test_hyper_network_transforms_on_the_matrix_core_kernels(kind, device, monke
         assert len(hid.pairs) == 1, "the hyper-network's hidden stack did not run in fc_resnet_hidden"
         assert len(fused.pairs) == (1 if kind == "rq" else 0)
         back, lad_inv = t.inverse(y, c.to(device))
-        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        monkeypatch.setitem(options._values, "fused_hidden", False)
         y_torch, lad_torch = t(x.to(device), c.to(device))
     scale = max(1.0, float(ref_y.abs().max()))
     lscale = max(1.0, float(ref_lad.abs().max()) / 10)
@@ -260,7 +260,7 @@ def test_flow_with_embedding_net_and_conditional_layers(device, monkeypatch):
         with ops.KernelTimer("fc_resnet_hidden") as plain, ops.KernelTimer("fc_resnet_hidden_context") as withctx:
             got = flow.log_prob(x.to(device), c.to(device))
         assert len(plain.pairs) == 3 and len(withctx.pairs) == 1   # embedding + 2 hyper-networks; the coupling net
-        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        monkeypatch.setitem(options._values, "fused_hidden", False)
         got_torch = flow.log_prob(x.to(device), c.to(device))
     tol = 3e-4 * max(1.0, float(ref.abs().max()) / 10)
     assert maxdiff(got, ref) <= tol and maxdiff(got, got_torch) <= tol

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from _util import build_case, maxdiff
-from flowconductor_amd import ops
+from flowconductor_amd import ops, options
 from oracle import torch_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -30,7 +30,7 @@ def test_fused_matches_unfused_and_oracle(n, inverse, device, monkeypatch):
         with ops.KernelTimer("fc_rq_spline_fused_linear") as timer:
             y_f, lad_f = fn(xd)
         assert len(timer.pairs) == 1, "the fused kernel did not run"
-        monkeypatch.setenv("FC_FUSED", "0")
+        monkeypatch.setitem(options._values, "fused_final_layer", False)
         assert not t._fused_ok(xd)
         y_u, lad_u = fn(xd)
     scale = max(1.0, float(ref_y.abs().max()))
@@ -213,7 +213,7 @@ def test_fused_hidden_path_in_coupling(device, monkeypatch):
         with ops.KernelTimer("fc_resnet_hidden") as timer:
             y, lad = t(x.to(device))
         assert len(timer.pairs) == 1, "the hidden-layer kernel did not run"
-        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        monkeypatch.setitem(options._values, "fused_hidden", False)
         y2, lad2 = t(x.to(device))
     assert maxdiff(y, ref_y) <= 2e-5 * max(1.0, float(ref_y.abs().max()))
     assert maxdiff(lad, ref_lad) <= 3e-4
@@ -351,7 +351,7 @@ def test_made_hidden_stack_on_hip_kernel(kind, inverse, device, monkeypatch):
         with ops.KernelTimer("fc_resnet_hidden") as timer:
             y, lad = fn(x.to(device))
         assert len(timer.pairs) == (6 if inverse else 1), "the hidden-layer kernel did not run"
-        monkeypatch.setenv("FC_FUSED_HIDDEN", "0")
+        monkeypatch.setitem(options._values, "fused_hidden", False)
         y2, lad2 = fn(x.to(device))
     scale = max(1.0, float(ref_y.abs().max()))
     tol = 3e-4 if inverse else 2e-5      # the inverse chains D conditioner passes

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from _util import maxdiff
-from flowconductor_amd import ops
+from flowconductor_amd import ops, options
 from flowconductor_amd import transforms as T
 from oracle import torch_oracle as O
 
@@ -197,7 +197,7 @@ def test_sylvester_matrix_core_path(d, m, n, device, monkeypatch):
         with ops.KernelTimer("fc_sylvester_mm") as timer:
             y, lad = t(x.to(device))
         assert len(timer.pairs) == 1, "the matrix-core kernel did not run"
-        monkeypatch.setenv("FC_SYLVESTER_MM", "0")
+        monkeypatch.setitem(options._values, "sylvester_mm", False)
         y2, lad2 = t(x.to(device))
     sy, sl = max(1.0, float(ref_y.abs().max())), max(1.0, float(ref_lad.abs().max()))
     fy, fl = maxdiff(f32_y.double(), ref_y), maxdiff(f32_lad.double(), ref_lad)

@@ -1,5 +1,5 @@
 """Times one bijector kernel in isolation on the BASELINE.json cfg-3 layer shape and prints achieved
-algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [rq|rq_inv|rq_bwd|affine|fused|fused_inv|hidden]"""
+algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [--lib path.so] [--log2n 20] [rq|rq_inv|rq_bwd|affine|fused|fused_inv|hidden]"""
 import os
 import sys
 
@@ -11,8 +11,19 @@ from flowconductor_amd import ops  # noqa: E402
 
 
 def main():
-    which = sys.argv[1] if len(sys.argv) > 1 else "rq"
-    n = 1 << int(os.environ.get("LOG2N", "20"))
+    argv = sys.argv[1:]
+    log2n = 20
+    if "--lib" in argv:      # an ablation build of the same ABI (tools/probe/build_fused_variants.sh)
+        i = argv.index("--lib")
+        from flowconductor_amd import _hip
+        _hip.use_library(argv[i + 1])
+        del argv[i:i + 2]
+    if "--log2n" in argv:
+        i = argv.index("--log2n")
+        log2n = int(argv[i + 1])
+        del argv[i:i + 2]
+    which = argv[0] if argv else "rq"
+    n = 1 << log2n
     d, d_t, k = 64, 32, 8
     dev = torch.device("cuda:0")
     torch.manual_seed(0)

@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flowconductor_amd import transforms as T  # noqa: E402
+from flowconductor_amd import options  # noqa: E402
 
 
 def timed(fn, reps=10):
@@ -33,10 +34,10 @@ def main():
     with torch.no_grad():
         fused = unfused = float("inf")
         for _ in range(3):
-            os.environ["FC_FUSED"] = "1"
+            options._values["fused_final_layer"] = True
             fused = min(fused, timed(lambda: t(x)))
             y1, l1 = t(x)
-            os.environ["FC_FUSED"] = "0"
+            options._values["fused_final_layer"] = False
             unfused = min(unfused, timed(lambda: t(x)))
             y0, l0 = t(x)
     print(f"rq_ar forward D={features} N={n}: fused {fused:.3f} ms ({n / fused / 1e3:.0f} M samples/s), "

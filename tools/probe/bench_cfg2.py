@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flowconductor_amd import distributions, flows, transforms, utils  # noqa: E402
+from flowconductor_amd import options  # noqa: E402
 from flowconductor_amd.nn import nets  # noqa: E402
 
 torch.manual_seed(0)
@@ -25,4 +26,4 @@ with torch.no_grad():
     torch.cuda.synchronize()
 dt = (time.time() - t0) / 20
 print("cfg2: %.3f ms per log_prob of 2^18 samples -> %.1f M samples/s (FC_FUSED_HIDDEN=%s)"
-      % (dt * 1e3, (1 << 18) / dt / 1e6, os.environ.get("FC_FUSED_HIDDEN", "1")))
+      % (dt * 1e3, (1 << 18) / dt / 1e6, options.get("fused_hidden")))

@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flowconductor_amd import distributions, flows, transforms  # noqa: E402
+from flowconductor_amd import options  # noqa: E402
 from flowconductor_amd.utils.graphs import GraphedCall  # noqa: E402
 
 
@@ -38,9 +39,9 @@ def main():
     with torch.no_grad():
         for _ in range(2):
             for mode in ("1", "0"):
-                os.environ["FC_FUSED_HIDDEN"] = mode
+                options._values["fused_hidden"] = mode == "1"
                 res[mode] = min(res.get(mode, 1e9), timed(lambda: flow.log_prob(x, c)))
-        os.environ["FC_FUSED_HIDDEN"] = "1"
+        options._values["fused_hidden"] = True
         graphed = GraphedCall(flow.log_prob, x, c)
         res["graph"] = timed(lambda: graphed(x, c))
     print(f"conditional MAF N={n}: hidden kernel {res['1']:.3f} ms, PyTorch hidden layers {res['0']:.3f} ms "

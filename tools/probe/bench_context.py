@@ -9,6 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flowconductor_amd import distributions, flows, ops, transforms, utils  # noqa: E402
+from flowconductor_amd import options  # noqa: E402
 from flowconductor_amd.nn import nets  # noqa: E402
 
 
@@ -39,12 +40,12 @@ def main():
     best = {}
     for _ in range(2):
         for mode in ("1", "0"):
-            os.environ["FC_FUSED_HIDDEN"] = mode
+            options._values["fused_hidden"] = mode == "1"
             ms, lp = timed()
             if mode not in best or ms < best[mode][0]:
                 best[mode] = (ms, lp)
     with torch.no_grad(), ops.KernelTimer("fc_resnet_hidden_context") as t:
-        os.environ["FC_FUSED_HIDDEN"] = "1"
+        options._values["fused_hidden"] = True
         flow.log_prob(x, c)
     k = t.durations_ms()
     d = float((best["1"][1] - best["0"][1]).abs().max())

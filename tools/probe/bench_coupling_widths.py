@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flowconductor_amd import distributions, flows, transforms, utils  # noqa: E402
+from flowconductor_amd import options  # noqa: E402
 from flowconductor_amd.nn import nets  # noqa: E402
 
 
@@ -38,7 +39,7 @@ def main():
     best = {}
     for _ in range(2):
         for mode in ("1", "0"):
-            os.environ["FC_FUSED"] = mode
+            options._values["fused_final_layer"] = mode == "1"
             ms, lp = timed()
             if mode not in best or ms < best[mode][0]:
                 best[mode] = (ms, lp)

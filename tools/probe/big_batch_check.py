@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flowconductor_amd import transforms, utils  # noqa: E402
+from flowconductor_amd import options  # noqa: E402
 from flowconductor_amd.nn import nets  # noqa: E402
 
 n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 22)
@@ -22,8 +23,8 @@ with torch.no_grad():
 x = torch.randn(n, 64, device=dev)
 tail = slice(n - 4096, n)
 for mode in ("1", "0"):
-    os.environ["FC_FUSED"] = mode
-    os.environ["FC_FUSED_HIDDEN"] = mode
+    options._values["fused_final_layer"] = mode == "1"
+    options._values["fused_hidden"] = mode == "1"
     with torch.no_grad():
         y, lad = t(x)
         y_t, lad_t = t(x[tail].contiguous())

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Ablation builds of a fused kernel (FILE=fc_rq_fused3 by default; macro FC_ABL) into tools/probe/build/.
-# Run a variant with  FLOWCON_HIP_LIB=tools/probe/build/libfc_abl<N>.so python tools/bench_kernel.py fused
+# Run a variant with  python tools/bench_kernel.py --lib tools/probe/build/libfc_abl<N>.so fused
 set -e
 cd "$(dirname "$0")/../../flowconductor_amd/csrc"
 make -s

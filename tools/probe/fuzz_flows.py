@@ -10,6 +10,7 @@ from torch.nn import functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT]
 from flowconductor_amd import distributions, flows, ops, transforms as T, utils  # noqa: E402
+from flowconductor_amd import options  # noqa: E402
 from flowconductor_amd.nn import nets  # noqa: E402
 from oracle import torch_oracle as O  # noqa: E402
 
@@ -75,7 +76,7 @@ for c in range(cases):
         flow = flow.to(dev)
         cd = None if ctx is None else ctx.to(dev)
         got = flow.log_prob(x.to(dev), cd) if cd is not None else flow.log_prob(x.to(dev))
-        os.environ["FC_AR_INCREMENTAL"] = "force" if ri(0, 1) else "1"
+        options._values["ar_incremental"] = "force" if ri(0, 1) else "auto"
         z, _ = flow._transform(x.to(dev), cd)
         back, _ = flow._transform.inverse(z, cd)
     e = md(got, ref)

@@ -18,7 +18,7 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS_F32" \
            "GRBM_GUI_ACTIVE SQ_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_MISC"; do
   i=$((i+1))
-  LOG2N=${LOG2N:-20} rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/bench_kernel.py $KIND > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/p$i -- python3 $R/tools/bench_kernel.py --log2n ${LOG2N:-20} $KIND > $OUT/p$i.log 2>&1
   echo "pass $i exit $?"
 done
 cd $R

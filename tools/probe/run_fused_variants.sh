@@ -3,5 +3,5 @@
 for v in "$@"; do
   if [ "$v" = 0 ]; then lib=flowconductor_amd/csrc/libflowcon_hip.so; else lib=tools/probe/build/libfc_abl$v.so; fi
   echo -n "abl$v: "
-  FLOWCON_HIP_LIB=$lib timeout -k 10 120 python tools/bench_kernel.py fused 2>&1 | grep median || exit 1
+  timeout -k 10 120 python tools/bench_kernel.py --lib $lib fused 2>&1 | grep median || exit 1
 done
