@@ -101,6 +101,10 @@ SIGNATURES = {
     "fc_dense_mm": [_P, _P, _P, _P, _I64, _I32, _P],
     "fc_sylvester_mm": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
     "fc_affine_backward": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
+    "fc_comm_unique_id": [_P],
+    "fc_comm_init_rank": [ctypes.POINTER(ctypes.c_void_p), _I32, _P, _I32],
+    "fc_comm_destroy": [_P],
+    "fc_allreduce_loglik": [_P, _P, _P],
 }
 
 _lib = None

@@ -7,7 +7,84 @@ all-reduce of ``{sum of log_prob (f64), row count (f64)}`` = 16 bytes per evalua
 ring.  The reference has no distributed code at all; there is nothing to
 translate.  Outputs (noise, per-sample log_prob) stay sharded.
 """
+import ctypes
+
 import torch
+
+
+def rank_plan(rank, world, local_rank, scaling="weak", rows_per_gpu=1 << 20, total_rows=None, base_seed=1234):
+    """What rank ``rank`` of ``world`` does in a batch-sharded evaluation, as plain data:
+    ``device_index`` (one process per GPU: its LOCAL_RANK), ``seed`` (inputs are generated per rank on the device,
+    ``base_seed + rank``), the global row range ``[row_lo, row_hi)`` of its contiguous shard and ``n_local``.
+    ``scaling="weak"``: every rank owns ``rows_per_gpu`` rows (BASELINE.json configs[2] per GPU; at world = 8 the job
+    is configs[3]).  ``scaling="strong"``: ``total_rows`` (configs[3]: 2^23) are split into near-equal shards."""
+    if not 0 <= rank < world:
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    if scaling == "weak":
+        lo, hi = rank * rows_per_gpu, (rank + 1) * rows_per_gpu
+    elif scaling == "strong":
+        if total_rows is None:
+            raise ValueError("strong scaling needs total_rows")
+        lo, hi = shard_bounds(total_rows, rank, world)
+    else:
+        raise ValueError("scaling must be 'weak' or 'strong'")
+    return {"rank": rank, "world": world, "device_index": local_rank, "seed": base_seed + rank,
+            "row_lo": lo, "row_hi": hi, "n_local": hi - lo, "scaling": scaling}
+
+
+class LoglikAllReduce:
+    """The path's one collective through the C ABI: ``fc_allreduce_loglik`` (RCCL ``ncclAllReduce`` of two float64 on
+    the compute stream).  Built collectively by all ranks; the 128-byte RCCL unique id travels over the existing
+    ``torch.distributed`` process group (any backend -- it is host data).
+
+        reducer = LoglikAllReduce(device, group)          # every rank
+        total, count = reducer(log_prob)                   # per evaluation; returns Python floats
+    """
+
+    def __init__(self, device, group=None):
+        import torch.distributed as dist
+
+        from flowconductor_amd import _hip
+
+        self._lib = _hip.load()
+        self.device = torch.device(device)
+        self.world = dist.get_world_size(group) if group is not None or dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _hip.check(self._lib.fc_comm_unique_id(ident), "fc_comm_unique_id")
+        payload = [ident.raw]
+        if self.world > 1:
+            dist.broadcast_object_list(payload, src=0, group=group)
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(self.device):       # ncclCommInitRank binds the current device
+            _hip.check(self._lib.fc_comm_init_rank(ctypes.byref(comm), self.world, payload[0], self.rank),
+                       "fc_comm_init_rank")
+        self._comm = comm
+        self._stats = torch.zeros(2, dtype=torch.float64, device=self.device)
+
+    def __call__(self, log_prob):
+        from flowconductor_amd import _hip
+
+        stats = self._stats
+        stats[0] = log_prob.double().sum()
+        stats[1] = float(log_prob.numel())
+        with torch.cuda.device(self.device):
+            _hip.check(self._lib.fc_allreduce_loglik(ctypes.c_void_p(stats.data_ptr()), self._comm,
+                                                     _hip.stream_ptr(self.device)), "fc_allreduce_loglik")
+        total, count = stats.tolist()
+        return total, count
+
+    def close(self):
+        if getattr(self, "_comm", None):
+            self._lib.fc_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def shard_bounds(n, rank, world):
@@ -45,10 +122,12 @@ def allreduce_sum_count(log_prob, group=None):
     return total, count
 
 
-def sharded_log_prob_mean(log_prob_fn, local_inputs, context=None, chunk=None, group=None):
-    """Mean log-likelihood over all ranks' rows; each rank passes only its own shard."""
+def sharded_log_prob_mean(log_prob_fn, local_inputs, context=None, chunk=None, group=None, reducer=None):
+    """Mean log-likelihood over all ranks' rows; each rank passes only its own shard.  ``reducer``: a
+    ``LoglikAllReduce`` (RCCL through the C ABI); otherwise the reduction goes through ``torch.distributed`` on
+    ``group`` (gloo on CPU in the tests, nccl = RCCL on GPUs)."""
     lp = local_log_prob(log_prob_fn, local_inputs, context, chunk)
-    total, count = allreduce_sum_count(lp, group)
+    total, count = reducer(lp) if reducer is not None else allreduce_sum_count(lp, group)
     return total / count if count else float("nan")
 
 

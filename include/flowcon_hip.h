@@ -297,6 +297,23 @@ int fc_sylvester_mm(const float* x, float* y, float* logabsdet, const float* w1,
  * orthogonal matrix (orthogonal.py:63-85).  bias may be NULL.  d % 32 == 0, d <= 128, n % 16 == 0. */
 int fc_dense_mm(const float* x, float* y, const float* w, const float* bias, int64_t n, int32_t d, void* stream);
 
+/* ---- multi-GPU: the one collective of the path ------------------------------------------------------ */
+/* Batch-sharded log_prob (one process per GPU, contiguous row shards, replicated weights) exchanges
+ * only {sum of log_prob, row count}: 16 bytes per evaluation.  The reference has no distributed code; these entries
+ * are what SURVEY.md 8b names for the N > 1 path.  RCCL is resolved at run time (the process' already loaded
+ * librccl.so.1 first); without it these return hipErrorNotSupported.  Return value: 0, a hipError_t, or
+ * 10000 + ncclResult_t.
+ *   fc_comm_unique_id   rank 0 fills a 128-byte id and hands it to the other ranks by any host channel
+ *   fc_comm_init_rank   collective over all ranks; binds the calling thread's CURRENT device to `rank`
+ *   fc_allreduce_loglik sum_count: DEVICE pointer to two float64 {sum, count}, reduced in place (sum) across the
+ *                       ranks of `comm`, asynchronous on `stream` (ncclAllReduce, RCCL over xGMI)
+ *   fc_comm_destroy     releases the communicator */
+#define FC_COMM_UNIQUE_ID_BYTES 128
+int fc_comm_unique_id(void* id_out128);
+int fc_comm_init_rank(void** comm_out, int32_t nranks, const void* id128, int32_t rank);
+int fc_comm_destroy(void* comm);
+int fc_allreduce_loglik(double* sum_count, void* comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,12 +63,60 @@ def add_edge_rows(name, t, x):
     return x
 
 
+def make_knot_fixture(path):
+    """Functional-level fixture: inputs EXACTLY on interior knots of the rational-quadratic
+    spline, both directions, linear tails and the unit box.  The knots are computed with the reference's own op
+    sequence (rational_quadratic.py:91-98, 106-113) so that the chosen inputs are bit-for-bit the knot positions the
+    reference's bin search compares against (x == knot k  =>  bin k, theta = 0)."""
+    from flowcon.transforms.splines import rational_quadratic as rq
+    from torch.nn import functional as F
+
+    def knots(u, lo, hi, min_bin=1e-3):
+        k = u.shape[-1]
+        w = min_bin + (1 - min_bin * k) * F.softmax(u, dim=-1)
+        c = F.pad(torch.cumsum(w, dim=-1), pad=(1, 0), mode="constant", value=0.0)
+        c = (hi - lo) * c + lo
+        c[..., 0], c[..., -1] = lo, hi
+        return c
+
+    gen = torch.Generator().manual_seed(777)
+    out = {}
+    for tag, k, tails, bound in (("tails_k8", 8, "linear", 3.0), ("box_k10", 10, None, 1.0)):
+        n, d = 96, 4
+        uw = torch.randn(n, d, k, generator=gen) * 1.5
+        uh = torch.randn(n, d, k, generator=gen) * 1.5
+        ud = torch.randn(n, d, k - 1 if tails == "linear" else k + 1, generator=gen) * 1.5
+        lo, hi = (-bound, bound) if tails == "linear" else (0.0, 1.0)
+        which = torch.randint(1, k, (n, d), generator=gen)            # an interior knot per element
+        xk = knots(uw, lo, hi).gather(-1, which[..., None])[..., 0]
+        yk = knots(uh, lo, hi).gather(-1, which[..., None])[..., 0]
+        for direction, x in (("fwd", xk), ("inv", yk)):
+            for dt, suffix in ((torch.float32, ""), (torch.float64, "64")):
+                args = dict(inputs=x.to(dt).clone(), unnormalized_widths=uw.to(dt).clone(),
+                            unnormalized_heights=uh.to(dt).clone(), unnormalized_derivatives=ud.to(dt).clone(),
+                            inverse=direction == "inv")
+                if tails == "linear":
+                    y, lad = rq.unconstrained_rational_quadratic_spline(tails="linear", tail_bound=bound, **args)
+                else:
+                    y, lad = rq.rational_quadratic_spline(**args)
+                out["%s_%s_y%s" % (tag, direction, suffix)] = y.numpy()
+                out["%s_%s_lad%s" % (tag, direction, suffix)] = lad.numpy()
+            out["%s_%s_x" % (tag, direction)] = x.numpy()
+        out["%s_uw" % tag], out["%s_uh" % tag], out["%s_ud" % tag] = uw.numpy(), uh.numpy(), ud.numpy()
+        out["%s_knot" % tag] = which.numpy()
+    np.savez_compressed(path, **out)
+    print("wrote", path, sorted(out))
+
+
 def main():
     sys.path.insert(0, HERE)
     import cases
 
     L = import_reference()
     torch.set_num_threads(4)
+    make_knot_fixture(os.path.join(HERE, "fn_rq_interior_knots.npz"))
+    if "--knots-only" in sys.argv:
+        return
     for name, spec in cases.CASES.items():
         torch.manual_seed(1234)
         t = spec["build"](L)

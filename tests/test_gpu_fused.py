@@ -221,7 +221,7 @@ def test_fused_hidden_path_in_coupling(device, monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["typical", "zero_weights", "huge_h_rows", "tiny_h_rows", "mixed_row_scales",
-                                  "tiny_weights", "large_weights"])
+                                  "tiny_weights", "large_weights", "mixed_weight_rows"])
 def test_fused_linear_scaling_edge_cases(case, device):
     """The fused kernel computes W h on the f16 matrix cores after power-of-two scaling (per wave for the
     weights, per row for h).  Parity of the whole op against a float64 Linear + the oracle's spline on
@@ -249,6 +249,10 @@ def test_fused_linear_scaling_edge_cases(case, device):
     elif case == "large_weights":
         w *= 40.0
         h *= 0.025
+    elif case == "mixed_weight_rows":
+        # magnitudes from 1e-5 to 1 BETWEEN the 96 weight rows that share one wave's power-of-two scale (rows of one
+        # dim, and of the four dims of a wave): the small rows keep only the bits above 2^-22 of the wave's maximum
+        w *= torch.logspace(-5, 0, d_t * (3 * k - 1))[torch.randperm(d_t * (3 * k - 1))].unsqueeze(1) * 5.0
     cols = torch.arange(0, d, 2, dtype=torch.int32)
     params64 = (h.double() @ w.double().T + b.double())
     rows = params64.float().view(n, d_t, 3 * k - 1).clone()

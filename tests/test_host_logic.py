@@ -1,10 +1,14 @@
 """Host-side behaviour of the Transform mirror that needs no GPU: constructor checks, buffers,
 state_dict keys, error types raised before any kernel launch, mask builders, MADE masks."""
+import os
+
 import pytest
 import torch
 
 from _util import Lib
 from flowconductor_amd import ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 T, nets, utils = Lib.transforms, Lib.nets, Lib.utils
 
@@ -296,3 +300,63 @@ def test_activation_codes_and_made_predicates():
     w, b = made.masked_final(64)
     assert w.shape == (10, 64) and float(w[:, 20:].abs().max()) == 0.0
     assert torch.equal(w[:, :20], made.final_layer.weight.detach() * made.final_layer.mask)
+
+
+def test_rank_plan_maps_ranks_to_devices_seeds_and_shards():
+    """one process per GPU (device = LOCAL_RANK), inputs seeded 1234 + rank, contiguous shards; weak
+    scaling keeps 2^20 rows per GPU (world 8 = BASELINE configs[3]), strong scaling splits configs[3]'s 2^23 rows."""
+    from flowconductor_amd import parallel
+
+    world = 8
+    weak = [parallel.rank_plan(r, world, r, "weak", rows_per_gpu=1 << 20) for r in range(world)]
+    assert [p["device_index"] for p in weak] == list(range(8))
+    assert [p["seed"] for p in weak] == [1234 + r for r in range(8)]
+    assert all(p["n_local"] == 1 << 20 for p in weak)
+    assert weak[0]["row_lo"] == 0 and weak[-1]["row_hi"] == 1 << 23
+    assert all(a["row_hi"] == b["row_lo"] for a, b in zip(weak, weak[1:]))
+    for w in (1, 2, 4, 8, 3):
+        strong = [parallel.rank_plan(r, w, r, "strong", total_rows=1 << 23) for r in range(w)]
+        assert strong[0]["row_lo"] == 0 and strong[-1]["row_hi"] == 1 << 23
+        assert sum(p["n_local"] for p in strong) == 1 << 23
+        assert all(a["row_hi"] == b["row_lo"] for a, b in zip(strong, strong[1:]))
+        assert max(p["n_local"] for p in strong) - min(p["n_local"] for p in strong) <= 1
+    with pytest.raises(ValueError):
+        parallel.rank_plan(8, 8, 0)
+    with pytest.raises(ValueError):
+        parallel.rank_plan(0, 2, 0, "strong")
+
+
+def test_options_override_nests_and_restores():
+    from flowconductor_amd import options
+
+    assert options.get("fused_final_layer") is True
+    with options.override(fused_final_layer=False):
+        assert options.get("fused_final_layer") is False
+        with options.override(fused_hidden=False, fused_final_layer=True):
+            assert options.get("fused_final_layer") is True and options.get("fused_hidden") is False
+        assert options.get("fused_final_layer") is False and options.get("fused_hidden") is True
+    assert options.get("fused_final_layer") is True
+    with pytest.raises(KeyError):
+        with options.override(no_such_switch=1):
+            pass
+    try:
+        with options.override(sylvester_mm=False):
+            raise RuntimeError("boom")
+    except RuntimeError:
+        pass
+    assert options.get("sylvester_mm") is True
+
+
+def test_product_path_reads_no_environment_switches():
+    """A stray environment variable must not change what is timed: no os.environ / getenv under flowconductor_amd/."""
+    import re
+
+    pkg = os.path.join(ROOT, "flowconductor_amd")
+    offenders = []
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                text = open(os.path.join(base, f)).read()
+                if re.search(r"os\.environ|getenv\s*\(", text):
+                    offenders.append(os.path.relpath(os.path.join(base, f), ROOT))
+    assert not offenders, offenders

@@ -29,3 +29,25 @@ def test_oracle_matches_reference_golden(name):
                                              None if ctx is None else ctx.clone(), inverse=True)
             assert maxdiff(xi, g["xinv_%d" % n]) <= TOL * 5, (name, n)
             assert maxdiff(ladi, g["ladinv_%d" % n]) <= TOL * 50, (name, n)
+
+
+@pytest.mark.parametrize("tag,k,tails,bound", [("tails_k8", 8, "linear", 3.0), ("box_k10", 10, None, 1.0)])
+@pytest.mark.parametrize("direction", ["fwd", "inv"])
+def test_oracle_on_knots(tag, k, tails, bound, direction):
+    """The oracle's spline against reference vectors whose inputs sit exactly on interior knots (bin k at theta = 0:
+    the compare-count search of utils/torchutils.py:147-149 with `>=`)."""
+    import os
+
+    import numpy as np
+    from _util import GOLDEN_DIR
+    from oracle import torch_oracle as O
+
+    g = np.load(os.path.join(GOLDEN_DIR, "fn_rq_interior_knots.npz"))
+    uw, uh, ud = (torch.from_numpy(g["%s_%s" % (tag, s)]).clone() for s in ("uw", "uh", "ud"))
+    x = torch.from_numpy(g["%s_%s_x" % (tag, direction)]).clone()
+    if tails == "linear":
+        y, lad = O.unconstrained_rational_quadratic_spline(x, uw, uh, ud, inverse=direction == "inv", tail_bound=bound)
+    else:
+        y, lad = O.rational_quadratic_spline(x, uw, uh, ud, inverse=direction == "inv")
+    assert maxdiff(y, g["%s_%s_y" % (tag, direction)]) <= 2e-6 * bound
+    assert maxdiff(lad, g["%s_%s_lad" % (tag, direction)]) <= 2e-5
