@@ -3,7 +3,10 @@
 on synthetic Gaussian batches, one process per GPU, batch-sharded (BASELINE.json cfg 3/4).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W                       # weak scaling: 2^20 samples per GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --scaling strong --total-log2 23           # BASELINE.json configs[3]: 2^23 rows over the ranks
 
 One "step" = one ``Flow.log_prob`` pass of every rank's 2^20-sample shard through all 32
 layers (conditioners on PyTorch-ROCm, bijectors in the HIP kernels) + the RCCL all-reduce of
@@ -48,20 +51,28 @@ def build_flow():
 
 
 TRAFFIC_PROFILE = "profiles/r01h_hbm_traffic.json"
+# kernel symbol (substring) each C-ABI entry launches in this flow: the committed PMC profile must have counted THAT
+# kernel, or its number does not belong in this line
+EXPECTED_KERNELS = {"fc_rq_spline_fused_linear": "rq_fused_linear_kernel3", "fc_resnet_hidden": "resnet_hidden_kernel",
+                    "fc_rq_spline": "rq_wave_kernel"}
 
 
 def measured_traffic_per_launch(entry, rows_per_launch):
     """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes of this same command
-    (tools/profile_bench.sh: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs).  PMC counters cannot be
-    read from inside this process, so the number comes from profiles/; None if absent or if this run's
-    launch shape differs from the profiled one."""
+    (tools/profile_bench.sh: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc runs).  PMC counters cannot be read from
+    inside this process, so the number comes from profiles/ and the line names the profile (`traffic_profile`).
+    None if the profile is absent or this run's launch shape differs from the profiled one; a profile that counted a
+    DIFFERENT kernel than the one this flow launches is an error, not a stale number."""
     try:
         rec = json.load(open(os.path.join(ROOT, TRAFFIC_PROFILE)))
-        if rows_per_launch != (1 << 20):
-            return None
-        return rec[entry]["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError):
         return None
+    if entry not in rec or rows_per_launch != (1 << 20):
+        return None
+    if rec[entry].get("kernel") != EXPECTED_KERNELS[entry]:
+        raise SystemExit("bench.py: %s counted kernel %r for %s, this flow launches %r -- re-run tools/profile_bench.sh"
+                         % (TRAFFIC_PROFILE, rec[entry].get("kernel"), entry, EXPECTED_KERNELS[entry]))
+    return rec[entry]["traffic_bytes_per_launch"]
 
 
 def issue_bound(counters_file, launch_ms, rows_per_launch):
@@ -102,7 +113,7 @@ def host_cores():
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, int(os.environ.get("FC_BENCH_MAX_CORES", "64"))))
+    return max(1, min(n, 64))
 
 
 def log(msg):
@@ -181,31 +192,52 @@ def trained_like(flow_cpu, rows=2048):
     return flow2
 
 
+LEGACY_ENV_SWITCHES = ("FLOWCON_HIP_LIB", "FC_FUSED", "FC_FUSED_HIDDEN", "FC_SYLVESTER_MM", "FC_RQ_PATH",
+                       "FC_AR_INCREMENTAL")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-log2", type=int, default=20, help="log2 samples per GPU")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch-log2 samples on every GPU (configs[2] per GPU; 8 GPUs = configs[3]); "
+                         "strong: --total-log2 samples split over the GPUs (configs[3] at every N)")
+    ap.add_argument("--batch-log2", type=int, default=20, help="weak scaling: log2 samples per GPU")
+    ap.add_argument("--total-log2", type=int, default=23, help="strong scaling: log2 samples of the whole job")
     ap.add_argument("--chunk-log2", type=int, default=0, help="log2 rows per pass through the stack (0 = whole shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the secondary `configs` block (cfg 1, 2, 5, K=10)")
     ap.add_argument("--cpu-sample-log2", type=int, default=17)
+    ap.add_argument("--loglik-allreduce", default="abi", choices=["abi", "torch"],
+                    help="abi: fc_allreduce_loglik (RCCL through the C ABI); torch: torch.distributed.all_reduce")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo + FC_BENCH_SHARE_DEVICE0=1 rehearses the N>1 code path on a one-GPU box")
+                    help="gloo + --share-device0 rehearses the N>1 code path on a one-GPU box")
+    ap.add_argument("--share-device0", action="store_true",
+                    help="rehearsal only: every rank on the single GPU of the box (with --dist-backend gloo)")
     args = ap.parse_args()
 
+    stray = [k for k in LEGACY_ENV_SWITCHES if k in os.environ]
+    if stray:
+        raise SystemExit("bench.py: %s set in the environment; kernel selection is not driven by environment variables "
+                         "(flowconductor_amd.options) -- unset them" % ", ".join(stray))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+            raise SystemExit("launch with python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    if os.environ.get("FC_BENCH_SHARE_DEVICE0") == "1":
-        local_rank = 0  # rehearsal only: every rank on the single GPU of the box (with --dist-backend gloo)
-    device = torch.device("cuda", local_rank)
+
+    from flowconductor_amd import _hip, parallel
+
+    plan = parallel.rank_plan(rank, world, 0 if args.share_device0 else local_rank, args.scaling,
+                              rows_per_gpu=1 << args.batch_log2, total_rows=1 << args.total_log2)
+    device = torch.device("cuda", plan["device_index"])
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
@@ -217,21 +249,41 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from flowconductor_amd import parallel
-
-    flow = build_flow().to(device)
-    n_local = 1 << args.batch_log2
-    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    flow = build_flow().to(device)      # weights replicated: every rank builds the same flow under manual_seed(0)
+    n_local = plan["n_local"]
+    gen = torch.Generator(device=device).manual_seed(plan["seed"])
     x = torch.randn(n_local, FEATURES, device=device, generator=gen)
     chunk = (1 << args.chunk_log2) if args.chunk_log2 else None
 
+    # the path's one collective: {sum log_prob, count}, 16 bytes, through the C ABI (RCCL) when the job runs on RCCL
+    reducer, reducer_note = None, "none (1 rank)"
+    if world > 1:
+        reducer_note = "torch.distributed.all_reduce (%s)" % args.dist_backend
+        if args.loglik_allreduce == "abi" and args.dist_backend == "nccl":
+            ok = torch.ones(1, device=device)
+            try:
+                reducer = parallel.LoglikAllReduce(device, dist.group.WORLD)
+            except Exception as e:        # all ranks must take the same path: agree below
+                log("rank %d: fc_allreduce_loglik unavailable (%s: %s)" % (rank, type(e).__name__, e))
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 1.0:
+                reducer_note = "fc_allreduce_loglik (RCCL ncclAllReduce through the C ABI, %d ranks)" % world
+            else:
+                if reducer is not None:
+                    reducer.close()
+                reducer = None
+                reducer_note += " [fc_allreduce_loglik failed to initialise on some rank]"
+
     def step():
         with torch.no_grad():
-            return parallel.sharded_log_prob_mean(flow.log_prob, x, chunk=chunk, group=None if world == 1 else dist.group.WORLD)
+            return parallel.sharded_log_prob_mean(flow.log_prob, x, chunk=chunk, reducer=reducer,
+                                                  group=None if world == 1 else dist.group.WORLD)
 
     torch.set_num_threads(host_cores())
-    log("rank %d/%d on %s: %d samples/GPU, host cores %d" % (rank, world, torch.cuda.get_device_name(device),
-                                                             n_local, host_cores()))
+    log("rank %d/%d on cuda:%d (%s): %d samples (rows %d..%d, seed %d), %s scaling, host cores %d"
+        % (rank, world, plan["device_index"], torch.cuda.get_device_name(device), n_local, plan["row_lo"],
+           plan["row_hi"], plan["seed"], args.scaling, host_cores()))
     # Steady state is the metric: the first two passes of a process run ~10 % slower (allocator growth,
     # clock ramp -- profiles/r01h_per_step_launch_us.json), so two set-up passes precede the W warm-up steps.
     for _ in range(2 + args.warmup):
@@ -254,18 +306,24 @@ def main():
         else:
             mean_lp = step()
     torch.cuda.synchronize(device)
+    local_elapsed = time.perf_counter() - t0      # this rank's own K steps (before waiting for the others)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
+    per_rank = [{"rank": rank, "device_index": plan["device_index"], "seed": plan["seed"], "rows": [plan["row_lo"], plan["row_hi"]],
+                 "ms_per_step": 1e3 * local_elapsed / args.steps}]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
 
     log("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
     if rank == 0:
-        total = n_local * world * args.steps
+        total = sum(r["rows"][1] - r["rows"][0] for r in per_rank) * args.steps
         rows_per_launch = n_local if chunk is None else min(chunk, n_local)
         alg_bytes = algorithmic_bytes_per_sample_layer() * rows_per_launch
         fused_ms = timer_fused.durations_ms()
@@ -292,23 +350,37 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic N(0,I) inputs generated on device; default-init weights under manual_seed(0)",
-            "config": {"workload": "BASELINE.json configs[2]: 32-layer RQ-NSF coupling flow log_prob, "
-                                   "D=64, K=8 bins, linear tails, ResidualNet(64, 2 blocks) conditioners",
-                       "samples_per_gpu": n_local, "global_batch": n_local * world,
+            "arithmetic": "f32 inputs / outputs / spline arithmetic (VALU); the conditioner's matrix products run as "
+                          "3-term scaled two-piece f16 splits on v_mfma_f32_16x16x32_f16 with f32 accumulation "
+                          "(f32-GEMM accuracy: error vs float64 1.7e-7 of sum|W||h|, an f32 GEMM's own is 4.1e-7)",
+            "data": "synthetic N(0,I) inputs generated on device (seed 1234 + rank); default-init weights under "
+                    "manual_seed(0), replicated",
+            "config": {"workload": ("BASELINE.json configs[2]: 32-layer RQ-NSF coupling flow log_prob, D=64, K=8 bins, "
+                                    "linear tails, ResidualNet(64, 2 blocks) conditioners, 2^%d samples per GPU"
+                                    % args.batch_log2) if args.scaling == "weak" else
+                                   ("BASELINE.json configs[3]: the same flow, 2^%d samples sharded over %d GPU(s)"
+                                    % (args.total_log2, world)),
+                       "samples_per_gpu": n_local, "global_batch": total // args.steps,
                        "chunk_rows": rows_per_launch, "parallelism": "batch-sharded dp%d" % world,
                        "mean_log_prob": mean_lp},
+            "rccl_ranks": world if (world > 1 and args.dist_backend == "nccl") else 0,
+            "loglik_allreduce": reducer_note,
+            "per_rank": per_rank,
+            "library": _hip.library_info(),
+            "options": options.snapshot(),
         }
+        out["traffic_profile"] = TRAFFIC_PROFILE
         src = TRAFFIC_PROFILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 gfx950 correction)"
         unfused = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_per_launch("fc_rq_spline", rows_per_launch),
                    "traffic_source": src,
                    "kernel": "fc_rq_spline -> fc::rq_wave_kernel<8, true>", "launches_timed": launches,
                    "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                   "measured_in": "extra untimed pass with FC_FUSED=0" if fused_path else "timed region"}
+                   "measured_in": "extra untimed pass with options.override(fused_final_layer=False)" if fused_path
+                   else "timed region"}
         if not fused_path:
             out["roofline"] = unfused
         else:
@@ -329,7 +401,10 @@ def main():
                                "avg_launch_ms": f_avg,
                                "algorithmic_bytes_per_launch": f_bytes,
                                "share_of_step": sum(fused_ms) / (1e3 * elapsed / args.steps),
-                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01h_fused_sq_counters.txt",
+                               "binding_resource": "valu_issue",
+                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01h_fused_sq_counters.txt; "
+                                          "`frac` is the distance to the HBM roof the contract asks for, "
+                                          "`issue_bound.frac` the share of the SIMDs' issue cycles in use",
                                "issue_bound": issue_bound("profiles/r01h_fused_sq_counters.txt", f_avg, rows_per_launch),
                                # BASELINE.md section 4 prices a coupling bijector at B = 4 d_t (P + 2) + 8 bytes per
                                # sample and layer (parameters read from HBM).  The fused kernel never moves them; in
@@ -357,6 +432,7 @@ def main():
                                           "launches_timed": len(hidden_ms), "avg_launch_ms": h_avg,
                                           "algorithmic_bytes_per_launch": h_bytes,
                                           "share_of_step": sum(hidden_ms) / (1e3 * elapsed / args.steps),
+                                          "binding_resource": "mfma_issue / dependent-latency (a wave walks the layers serially)",
                                           "issue_bound": issue_bound("profiles/r01h_hidden_sq_counters.txt", h_avg,
                                                                      rows_per_launch),
                                           "matrix_pipe": {"algorithmic_tflops": hflops / (h_avg * 1e-3) / 1e12,
@@ -379,7 +455,17 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(flow_cpu, 1 << args.cpu_sample_log2, 1 << 14)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            if not args.no_configs:
+                # the other BASELINE.json configurations + the reference's default layer shape, same instrumentation
+                del x, flow
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_configs
+
+                out["configs"] = bench_configs.run(device, log=log)
         print(json.dumps(out))
+    if reducer is not None:
+        reducer.close()
     if dist is not None:
         dist.destroy_process_group()
 

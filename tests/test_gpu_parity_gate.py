@@ -278,3 +278,21 @@ def test_kernels_run_on_a_non_current_device_index(device):
     p = torch.randn(64, 8 * 23, device=x.device)
     y, lad = ops.rq_spline(x, p, None, num_bins=8, tails="linear", tail_bound=3.0)
     assert torch.isfinite(y).all() and torch.isfinite(lad).all()
+
+
+def test_loglik_allreduce_through_the_c_abi_single_rank(device):
+    """fc_comm_* / fc_allreduce_loglik (RCCL resolved at run time) on a one-rank communicator: the reduction of
+    {sum, count} is the identity; what is under test is the C-ABI plumbing on real hardware (unique id, communicator
+    bound to the device, ncclAllReduce of two float64 on the compute stream)."""
+    from flowconductor_amd import parallel
+
+    reducer = parallel.LoglikAllReduce(device)
+    assert reducer.world == 1 and reducer.rank == 0
+    lp = torch.randn(4097, device=device)
+    for _ in range(3):
+        total, count = reducer(lp)
+        assert count == 4097.0
+        assert abs(total - float(lp.double().sum())) <= 1e-9 * 4097
+    mean = parallel.sharded_log_prob_mean(lambda v: v.sum(dim=1), torch.ones(10, 3, device=device), reducer=reducer)
+    assert mean == 3.0
+    reducer.close()

@@ -1,0 +1,375 @@
+"""The BASELINE.json configurations other than the headline one, as bench.py's ``configs`` block (and on their own:
+``python tools/bench_configs.py [cfg1 cfg2 cfg5_shared cfg5_per_sample nsf_k10_h256]``, one JSON object per line).
+
+Every entry carries what the headline line carries: throughput, the dominant kernel's ``roofline`` (algorithmic bytes or
+flops of SURVEY.md 8d per launch / the average launch duration from HIP events on the launch stream), ``cpu_baseline``
+(the CPU oracle on a bounded sample, host cores stated) and ``parity`` (GPU vs the oracle on the same weights / inputs).
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import flowconductor_amd  # noqa: E402,F401
+from flowconductor_amd import distributions, flows, ops, transforms, utils  # noqa: E402
+from flowconductor_amd.nn import nets  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F16_PEAK_TFLOPS = 2500.0    # dense f16 MFMA peak, same guide (2:1-sparsity figures excluded)
+
+
+def _cores():
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def _time_gpu(fn, steps, warmup):
+    with torch.no_grad():
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def _kernel_ms(fn, names):
+    """Average launch duration (ms) of each named C-ABI entry over one call of ``fn`` (HIP events on the launch stream)."""
+    timers = [ops.KernelTimer(n) for n in names]
+    with torch.no_grad():
+        for t in timers:
+            t.__enter__()
+        try:
+            fn()
+        finally:
+            for t in reversed(timers):
+                t.__exit__(None, None, None)
+    torch.cuda.synchronize()
+    res = {}
+    for t in timers:
+        d = t.durations_ms()
+        res[t.name] = (sum(d) / len(d), len(d)) if d else (None, 0)
+    return res
+
+
+def _cpu_baseline(fn, units, what):
+    """``fn()`` processes ``units`` samples on the host (the oracle): one warm-up, then repeated for ~2 s."""
+    cores = _cores()
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        fn()
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 3 or time.perf_counter() - t0 < 2.0:
+            fn()
+            reps += 1
+            if reps >= 200:
+                break
+        dt = time.perf_counter() - t0
+    return {"value": units * reps / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%s, %d repeats, %.1f s" % (what, reps, dt)}
+
+
+def _hbm_roofline(kernel, entry, ms, launches, bytes_per_launch, note=None):
+    gbs = bytes_per_launch / (ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "traffic": None, "kernel": "%s -> %s" % (entry, kernel), "launches_timed": launches, "avg_launch_ms": ms,
+         "algorithmic_bytes_per_launch": bytes_per_launch}
+    if note:
+        r["note"] = note
+    return r
+
+
+def _maxdiff(a, b):
+    return float((a.detach().double().cpu() - b.detach().double().cpu()).abs().max())
+
+
+# ---- configs[0]: README flow ----------------------------------------------------------------------------------------
+
+def cfg1(device, steps=50, warmup=10):
+    """examples/toy_2d.py / README flow: 2 x [MaskedAffineAutoregressiveTransform(2, hidden 4), RandomPermutation],
+    N = 4096 -- launch-bound on a GPU (10 us of kernels behind ~50 us of Python per layer): eager and as ONE HIP graph."""
+    from flowconductor_amd.utils.graphs import GraphedCall
+    from oracle import torch_oracle as O
+
+    torch.manual_seed(0)
+    layers = []
+    for _ in range(2):
+        layers.append(transforms.MaskedAffineAutoregressiveTransform(features=2, hidden_features=4))
+        layers.append(transforms.RandomPermutation(features=2))
+    flow_cpu = flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([2])).eval()
+    import copy
+    flow = copy.deepcopy(flow_cpu).to(device)
+    n = 4096
+    x = torch.randn(n, 2, device=device, generator=torch.Generator(device=device).manual_seed(1234))
+    eager_s, lp = _time_gpu(lambda: flow.log_prob(x), steps, warmup)
+    graphed = GraphedCall(flow.log_prob, x, clone=False)
+    graph_s, lp_g = _time_gpu(lambda: graphed(x), steps, warmup)
+    km = _kernel_ms(lambda: flow.log_prob(x), ["fc_affine"])
+    ms, launches = km["fc_affine"]
+    with torch.no_grad():
+        ref = O.flow_log_prob(flow_cpu, x.cpu())
+    xc = x.cpu()
+    out = {"workload": "BASELINE.json configs[0]: README flow, 2 x [MAF(D=2, hidden 4), RandomPermutation], N=4096",
+           "metric": "log_prob samples/sec", "unit": "samples/s", "value": n / graph_s, "ms_per_step": graph_s * 1e3,
+           "eager": {"value": n / eager_s, "ms_per_step": eager_s * 1e3},
+           "hip_graph": {"value": n / graph_s, "ms_per_step": graph_s * 1e3, "launches_per_replay": 1},
+           "dtype": "f32",
+           "roofline": _hbm_roofline("affine tile kernel", "fc_affine", ms, launches, 40 * n,
+                                     "B = 4*d_t*(P+2)+8 = 40 B per sample and layer (SURVEY 8d); at N = 4096 the launch "
+                                     "is latency-bound: 164 KB per launch cannot load 256 CUs"),
+           "parity": {"max_abs_dlog_prob": _maxdiff(lp, ref), "max_abs_dlog_prob_graphed": _maxdiff(lp_g, ref),
+                      "rows": n},
+           "cpu_baseline": _cpu_baseline(lambda: O.flow_log_prob(flow_cpu, xc), n, "4096 samples per call")}
+    out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+# ---- configs[1]: 8-layer affine coupling ---------------------------------------------------------------------------
+
+def cfg2(device, steps=20, warmup=5):
+    """8 x AffineCouplingTransform, D = 32 (d_t = 16), ResidualNet(64, 2 blocks), N = 2^18."""
+    import copy
+
+    from oracle import torch_oracle as O
+
+    torch.manual_seed(0)
+    layers = [transforms.AffineCouplingTransform(utils.create_alternating_binary_mask(32, even=(i % 2 == 0)),
+                                                 lambda a, b: nets.ResidualNet(a, b, hidden_features=64, num_blocks=2))
+              for i in range(8)]
+    flow_cpu = flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([32])).eval()
+    flow = copy.deepcopy(flow_cpu).to(device)
+    n = 1 << 18
+    x = torch.randn(n, 32, device=device, generator=torch.Generator(device=device).manual_seed(1234))
+    step_s, _ = _time_gpu(lambda: flow.log_prob(x), steps, warmup)
+    km = _kernel_ms(lambda: flow.log_prob(x), ["fc_affine", "fc_resnet_hidden"])
+    a_ms, a_n = km["fc_affine"]
+    h_ms, h_n = km["fc_resnet_hidden"]
+    xs = x[:2048].cpu()
+    with torch.no_grad():
+        z_ref, lad_ref = O.transform_apply(flow_cpu._transform, xs.clone())
+        z, lad = flow._transform(x[:2048])
+    sample = 1 << 15
+    xc = torch.randn(sample, 32, generator=torch.Generator().manual_seed(99))
+    out = {"workload": "BASELINE.json configs[1]: 8-layer affine-coupling flow, D=32, ResidualNet(64, 2 blocks), N=2^18",
+           "metric": "log_prob samples/sec", "unit": "samples/s", "value": n / step_s, "ms_per_step": step_s * 1e3,
+           "dtype": "f32",
+           "roofline": _hbm_roofline("affine tile kernel", "fc_affine", a_ms, a_n, 264 * n,
+                                     "the bijector kernel: B = 4*16*(2+2)+8 = 264 B per sample and layer (SURVEY 8d)"),
+           "roofline_hidden": _hbm_roofline("resnet_hidden_kernel", "fc_resnet_hidden", h_ms, h_n, (4 * 32 + 4 * 64) * n,
+                                            "the layer's dominant kernel (conditioner hidden stack on the matrix cores): "
+                                            "x rows in, h rows out"),
+           "parity": {"max_rel_dsamples": float(((z.cpu().double() - z_ref.double()).abs()
+                                                 / z_ref.double().abs().clamp_min(1.0)).max()),
+                      "max_abs_dlogabsdet": _maxdiff(lad, lad_ref), "rows": 2048},
+           "cpu_baseline": _cpu_baseline(lambda: O.flow_log_prob(flow_cpu, xc), sample, "2^15 samples per call")}
+    out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+# ---- configs[4]: Sylvester flow ---------------------------------------------------------------------------------------
+
+def _sylvester(device):
+    torch.manual_seed(0)
+    t = transforms.SylvesterTransform(features=128, num_householder=32, device="cpu").eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.add_(torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel())) * 0.1)
+    return t
+
+
+def cfg5_shared(device, steps=20, warmup=5):
+    """SylvesterTransform(D = 128, 32 Householder vectors), batch-shared parameters, N = 2^18: with batch-independent
+    weights the Householder / triangular chains fold into two dense [128, 128] maps -- a true dense contraction, the
+    one place the path belongs on the matrix cores."""
+    import copy
+
+    from oracle import torch_oracle as O
+
+    t_cpu = _sylvester(device)
+    t = copy.deepcopy(t_cpu).to(device)
+    n, d = 1 << 18, 128
+    x = torch.randn(n, d, device=device, generator=torch.Generator(device=device).manual_seed(1234))
+    step_s, _ = _time_gpu(lambda: t(x), steps, warmup)
+    km = _kernel_ms(lambda: t(x), ["fc_sylvester_mm"])
+    ms, launches = km["fc_sylvester_mm"]
+    flops = 8.0 * d * d * n                 # 4 mat-vecs per sample (two remain after folding Q into R)
+    executed = 3.0 * 4.0 * d * d * n        # two [128,128] products, three split-f16 terms each
+    with torch.no_grad():
+        y_ref, lad_ref = O.transform_apply(t_cpu, x[:1024].cpu())
+        y, lad = t(x[:1024])
+    sample = 1 << 13
+    xc = torch.randn(sample, d, generator=torch.Generator().manual_seed(99))
+    tf = flops / (ms * 1e-3) / 1e12
+    out = {"workload": "BASELINE.json configs[4]: SylvesterTransform D=128, M=32 Householder vectors, shared parameters, "
+                       "N=2^18 (forward + logabsdet)",
+           "metric": "transform samples/sec", "unit": "samples/s", "value": n / step_s, "ms_per_step": step_s * 1e3,
+           "dtype": "f32 results; products = 3-term split-f16 MFMA (v_mfma_f32_16x16x32_f16)",
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
+                        "frac": tf / (MFMA_F16_PEAK_TFLOPS / 3.0), "traffic": None,
+                        "kernel": "fc_sylvester_mm -> fc::sylvester_mm_kernel<4, false>", "launches_timed": launches,
+                        "avg_launch_ms": ms, "algorithmic_flops_per_launch": flops,
+                        "executed_f16_flops_per_launch": executed,
+                        "note": "peak = dense f16 MFMA peak / 3 (an f32 product costs three f16 terms); algorithmic "
+                                "flops = SURVEY 8d's 8 D^2 per sample; HBM side: %d B/sample = %.0f GB/s"
+                                % (8 * d + 4, (8 * d + 4) * n / (ms * 1e-3) / 1e9)},
+           "parity": {"max_abs_doutputs": _maxdiff(y, y_ref), "max_abs_dlogabsdet": _maxdiff(lad, lad_ref), "rows": 1024},
+           "cpu_baseline": _cpu_baseline(lambda: O.transform_apply(t_cpu, xc), sample, "2^13 samples per call")}
+    out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def cfg5_per_sample(device, steps=5, warmup=2, log2n=18):
+    """The conditional form of configs[4]: a hyper-network's per-sample q [N, 32, 128], R1 / R2 [N, 128, 128],
+    bias [N, 128] (148 480 B of parameters per sample) -- HBM-bound by construction."""
+    n, d, m = 1 << log2n, 128, 32
+    gen = torch.Generator(device=device).manual_seed(1234)
+    x = torch.randn(n, d, device=device, generator=gen)
+    q = torch.randn(n, m, d, device=device, generator=gen)
+    r1 = torch.randn(n, d, d, device=device, generator=gen).mul_(d ** -0.5).triu_()
+    r2 = torch.randn(n, d, d, device=device, generator=gen).mul_(d ** -0.5).triu_()
+    r1.diagonal(dim1=1, dim2=2).tanh_()
+    r2.diagonal(dim1=1, dim2=2).tanh_()
+    b = torch.randn(n, d, device=device, generator=gen) * 0.1
+    step_s, _ = _time_gpu(lambda: ops.sylvester(x, q, r1, r2, b), steps, warmup)
+    km = _kernel_ms(lambda: ops.sylvester(x, q, r1, r2, b), ["fc_sylvester"])
+    ms, launches = km["fc_sylvester"]
+    byts = (4 * (2 * d * d + 2 * d + m * d)) * n
+    # float64 formula on 256 rows (planar.py:144-166 with per-sample parameters; the reference's own conditional class
+    # only runs for D = 2, SURVEY headline facts: this leg is "parity unpinned" by the reference)
+    k = 256
+    xs, qs, r1s, r2s, bs = (t[:k].double().cpu() for t in (x, q, r1, r2, b))
+
+    def refl(v, qq, reverse):
+        order = range(m - 1, -1, -1) if reverse else range(m)
+        for i in order:
+            qi = qq[:, i]
+            v = v - (v * qi).sum(-1, keepdim=True) * (2.0 / (qi * qi).sum(-1, keepdim=True)) * qi
+        return v
+
+    def f64_formula():
+        qtz = refl(xs, qs, True)
+        pre = torch.einsum("nij,nj->ni", r1s, qtz) + bs
+        act = torch.tanh(pre)
+        out = xs + refl(torch.einsum("nij,nj->ni", r2s, act), qs, False)
+        diag = 1 + (1 - act ** 2) * (torch.diagonal(r1s, dim1=1, dim2=2) * torch.diagonal(r2s, dim1=1, dim2=2))
+        return out, torch.log(diag).sum(-1)
+
+    y64, lad64 = f64_formula()
+    with torch.no_grad():
+        y, lad = ops.sylvester(x[:k], q[:k], r1[:k], r2[:k], b[:k])
+    out = {"workload": "BASELINE.json configs[4], conditional form: per-sample q [N,32,128], R1/R2 [N,128,128], N=2^%d"
+                       % log2n,
+           "metric": "transform samples/sec", "unit": "samples/s", "value": n / step_s, "ms_per_step": step_s * 1e3,
+           "dtype": "f32",
+           "roofline": _hbm_roofline("fc::sylvester_kernel (per-sample parameters)", "fc_sylvester", ms, launches, byts,
+                                     "SURVEY 8d accounting: 4*(2 D^2 + 2 D + M D) = 148 480 B per sample; the kernel reads "
+                                     "only the upper triangle of every R row, ~82 KB per sample actually moved"),
+           "parity": {"max_abs_doutputs_vs_f64_formula": _maxdiff(y, y64),
+                      "max_abs_dlogabsdet_vs_f64_formula": _maxdiff(lad, lad64), "rows": k,
+                      "note": "parity unpinned by the reference (its conditional Sylvester class runs for D = 2 only)"},
+           "cpu_baseline": _cpu_baseline(f64_formula, k, "the float64 torch formula on 256 samples per call")}
+    out["cpu_baseline"]["kind"] = "port (float64 formula: the reference class cannot run at D = 128)"
+    out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    del q, r1, r2
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---- the reference's DEFAULT NSF layer shape ---------------------------------------------------------------------------
+
+def nsf_k10_h256(device, steps=5, warmup=2, log2n=18, layers=16, hidden=256, bins=10):
+    """A 16-layer RQ-NSF coupling flow with the reference's default bin count (coupling.py:507: num_bins=10) and a
+    256-wide conditioner (nn/nets/resnet.py:62), D = 64, linear tails -- the general fused path."""
+    import copy
+
+    from oracle import torch_oracle as O
+
+    torch.manual_seed(0)
+    stack = [transforms.PiecewiseRationalQuadraticCouplingTransform(
+        utils.create_alternating_binary_mask(64, even=(i % 2 == 0)),
+        lambda a, b: nets.ResidualNet(a, b, hidden_features=hidden, num_blocks=2), num_bins=bins, tails="linear",
+        tail_bound=3.0) for i in range(layers)]
+    flow_cpu = flows.Flow(transforms.CompositeTransform(stack), distributions.StandardNormal([64])).eval()
+    flow = copy.deepcopy(flow_cpu).to(device)
+    n = 1 << log2n
+    x = torch.randn(n, 64, device=device, generator=torch.Generator(device=device).manual_seed(1234))
+    step_s, _ = _time_gpu(lambda: flow.log_prob(x), steps, warmup)
+    names = ["fc_rq_spline_fused_general", "fc_resnet_hidden_wide", "fc_rq_spline"]
+    km = _kernel_ms(lambda: flow.log_prob(x), names)
+    p = 3 * bins - 1
+    out = {"workload": "%d-layer RQ-NSF coupling flow, D=64, K=%d (reference default), linear tails, "
+                       "ResidualNet(%d, 2 blocks), N=2^%d" % (layers, bins, hidden, log2n),
+           "metric": "log_prob samples/sec", "unit": "samples/s", "value": n / step_s, "ms_per_step": step_s * 1e3,
+           "dtype": "f32 results; conditioner products = 3-term split-f16 MFMA"}
+    f_ms, f_n = km["fc_rq_spline_fused_general"]
+    if f_ms:
+        flops = 2.0 * hidden * 32 * p * n
+        tf = flops / (f_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
+                           "frac": tf / (MFMA_F16_PEAK_TFLOPS / 3.0), "traffic": None,
+                           "kernel": "fc_rq_spline_fused_general", "launches_timed": f_n, "avg_launch_ms": f_ms,
+                           "algorithmic_flops_per_launch": flops,
+                           "hbm_side": {"bytes_per_sample": 4 * hidden + 8 * 64 + 4,
+                                        "GBs": (4 * hidden + 8 * 64 + 4) * n / (f_ms * 1e-3) / 1e9}}
+    else:
+        s_ms, s_n = km["fc_rq_spline"]
+        if s_ms:
+            out["roofline"] = _hbm_roofline("rq spline kernel (unfused path)", "fc_rq_spline", s_ms, s_n,
+                                            (4 * 32 * (p + 2) + 8) * n)
+    h_ms, h_n = km["fc_resnet_hidden_wide"]
+    if h_ms:
+        hflops = 2.0 * (hidden * 32 + 4 * hidden * hidden) * n
+        out["roofline_hidden"] = {"bound": "mfma", "achieved": hflops / (h_ms * 1e-3) / 1e12,
+                                  "peak": MFMA_F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
+                                  "frac": hflops / (h_ms * 1e-3) / 1e12 / (MFMA_F16_PEAK_TFLOPS / 3.0),
+                                  "kernel": "fc_resnet_hidden_wide", "launches_timed": h_n, "avg_launch_ms": h_ms}
+    xs = x[:1024].cpu()
+    with torch.no_grad():
+        z_ref, lad_ref = O.transform_apply(flow_cpu._transform, xs.clone())
+        z, lad = flow._transform(x[:1024])
+    out["parity"] = {"max_rel_dsamples": float(((z.cpu().double() - z_ref.double()).abs()
+                                                / z_ref.double().abs().clamp_min(1.0)).max()),
+                     "max_abs_dlogabsdet": _maxdiff(lad, lad_ref), "rows": 1024}
+    sample = 1 << 13
+    xc = torch.randn(sample, 64, generator=torch.Generator().manual_seed(99))
+    out["cpu_baseline"] = _cpu_baseline(lambda: O.flow_log_prob(flow_cpu, xc), sample, "2^13 samples per call")
+    out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+ALL = {"cfg1": cfg1, "cfg2": cfg2, "cfg5_shared": cfg5_shared, "cfg5_per_sample": cfg5_per_sample,
+       "nsf_k10_h256": nsf_k10_h256}
+
+
+def run(device, which=None, log=None):
+    res = {}
+    for name in (which or list(ALL)):
+        t0 = time.perf_counter()
+        try:
+            res[name] = ALL[name](device)
+        except Exception as e:      # a secondary block must never take the headline line down with it
+            res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if log:
+            log("config %s done in %.1f s" % (name, time.perf_counter() - t0))
+    return res
+
+
+if __name__ == "__main__":
+    dev = torch.device("cuda:0")
+    for k, v in run(dev, sys.argv[1:] or None, log=lambda m: print("[bench_configs] " + m, file=sys.stderr)).items():
+        print(json.dumps({k: v}))
