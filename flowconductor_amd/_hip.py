@@ -94,6 +94,8 @@ SIGNATURES = {
                             ctypes.POINTER(SplineConfig), _P],
     "fc_rq_spline_fused_linear": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32,
                                   ctypes.POINTER(RQConfig), _P],
+    "fc_rq_spline_fused_general": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32,
+                                   ctypes.POINTER(RQConfig), _P],
     "fc_resnet_hidden": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, ctypes.c_float, _P],
     "fc_resnet_hidden_context": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32,
                                  _I32, ctypes.c_float, _P],

@@ -1,0 +1,279 @@
+// Fused final-Linear + RQ-spline kernel for GENERAL layer shapes (the reference's defaults and beyond):
+//   K = 4 .. 16 bins, linear tails or none, hidden width 64 / 128 / 256 (narrower widths run
+//   zero-padded), up to 32 transformed dims per launch, D <= 128.
+//
+//   params[n, :] = W h[n, :] + b        (flowcon/nn/nets/resnet.py:91,99: the conditioner's final Linear;
+//                                        num_bins defaults to 10, coupling.py:507; hidden_features is free, resnet.py:62)
+//   y, logabsdet = rq_spline(x, params) (coupling.py:279-293, 549-582; rational_quadratic.py:13-181)
+//
+// fc_rq_fused3.hip is the hand-scheduled special case (K = 8, hidden 64, linear tails: both weight pieces resident
+// in 96 registers of every wave).  At K = 10 the resident weights alone would need 128 registers per wave next to
+// two accumulator sets, at hidden 256 four times that: here the weights are NOT resident.  The host packs them once
+// per parameter version into matrix-core fragment order -- scaled by a power of two per group of 4 dims and split
+// into two f16 pieces (fc_split.h) -- and every wave streams the fragments of ITS dims from L2 (the whole image is
+// <= 1 MB, shared by the 32 CUs of an XCD) straight into A operands.  The rest is the structure of kernel 3:
+//   * product transposed (A = weight rows, B = h^T), so the C layout hands lane (sample s, dim 4w+g) all its 3K-/+1
+//     parameters in its own accumulators -- the [N, d_t (3K-/+1)] tensor never exists in memory;
+//   * one 512-thread workgroup per CU walks 32-row tiles; wave w owns dims 4w..4w+3; h tiles (scaled + split once per
+//     row) and x tiles double-buffered in LDS, next tile's global loads in flight during the current tile's work,
+//     ONE barrier per tile;
+//   * per tile a wave accumulates both 16-sample blocks against each weight fragment it fetches (3 split terms x 2
+//     blocks = 6 MFMAs per 2 KB of weights), then evaluates its two elements per lane with the stand-alone kernel's
+//     RQOp<K>::eval_core on register parameters (the same arithmetic, operation for operation, as fc_rq_spline).
+// The two waves of a SIMD are not phase-locked (nothing but the tile barrier couples them), so one wave's weight
+// fetch / MFMA phase overlaps the other's spline arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fc_device.h"
+#include "fc_lane.h"
+#include "fc_math.h"
+#include "fc_rq_op.h"
+#include "fc_split.h"
+#include "fc_tile.h"
+#include "../../include/flowcon_hip.h"
+
+namespace fc {
+
+constexpr int kGenRows = 32;      // rows per tile = two 16-sample blocks
+constexpr int kGenThreads = 512;
+
+struct GenArgs {
+  const float* x;          // [N, D]
+  float* y;                // [N, D]
+  const float* h;          // [N, H]  last hidden activation (H = 64, 128 or 256; zero-padded by the producer)
+  const f16x8* wfrag;      // [groups][H/32][T][2 pieces][64 lanes]  packed weight fragments (ops.pack_final_layer_general)
+  const float* wun;        // [groups]  2^-S of the group's weight scale
+  const float* bias;       // [groups][4][PP]
+  const int32_t* cols;     // [dt]
+  float* logabsdet;        // [N]
+  uint32_t* err;
+  int64_t tiles;           // 32-row tiles
+  int D, H, dt, accumulate;
+};
+
+template <int K, bool kTails>
+struct GenShape {
+  static constexpr int P = kTails ? 3 * K - 1 : 3 * K + 1;
+  static constexpr int PP = (P + 3) / 4 * 4;
+  static constexpr int T = PP / 4;               // 16-row MFMA tiles per wave (4 dims x PP parameters)
+  static constexpr int TC = T > 8 ? (T + 1) / 2 : T;   // fragments fetched per batch (register budget)
+};
+
+inline size_t gen_lds_bytes(int d, int h) {
+  const size_t hb = (size_t)2 * 2 * kGenRows * (h + 8) * 2;       // [buf][piece][row][H + 8] f16
+  const size_t xb = (size_t)2 * kGenRows * (d + 4) * 4;           // [buf][row][D + 4]
+  return hb + xb + 2 * kGenRows * 4 /* row scales */ + 2 * 8 * kGenRows * 4 /* logabsdet partials */ + 32 * 4 +
+         (size_t)32 * 52 * 4 /* bias image, PP <= 52 */;
+}
+
+// max over the aligned group of G lanes (16, 32 or 64) a row of h is spread over
+template <int G>
+__device__ __forceinline__ float group_allmax(float m, int lane) {
+  m = row16_allmax(m);
+  if constexpr (G >= 32) m = fmaxf(m, lane_xor16(m, lane));
+  if constexpr (G >= 64) m = fmaxf(m, lane_xor32(m, lane));
+  return m;
+}
+
+// HQ = H / 64 (1, 2, 4): float4 pieces of the h tile per thread
+template <int K, bool kTails, int HQ>
+__global__ __launch_bounds__(kGenThreads) void rq_fused_general_kernel(RQOp<K> op, GenArgs a) {
+  using S = GenShape<K, kTails>;
+  constexpr int PP = S::PP, T = S::T, TC = S::TC;
+  constexpr int R = kGenRows;
+  constexpr int H = 64 * HQ, KS = H / 32, HB = H + 8;
+  constexpr int kRowLanes = H / 4;                       // threads that share a row of the h tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  const int D = a.D;
+  const bool pad_x = (D & 3) == 0;
+  const int XS = pad_x ? D + 4 : D;
+  _Float16* hbuf = reinterpret_cast<_Float16*>(gsm);                              // [2][2][R][HB]
+  float* xbuf = reinterpret_cast<float*>(gsm + (size_t)2 * 2 * R * HB * 2);       // [2][R][D + 4]
+  float* hscale = xbuf + 2 * R * (D + 4);                                          // [2][R]
+  float* lpart = hscale + 2 * R;                                                   // [2][8][R]
+  int* cs = reinterpret_cast<int*>(lpart + 2 * 8 * R);                             // [32]
+  float* bias_lds = reinterpret_cast<float*>(cs + 32);                             // [8 groups][4][PP]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int s16 = lane & 15, g = lane >> 4;
+  const int64_t stride = gridDim.x, tile0 = blockIdx.x;
+  if (tile0 >= a.tiles) return;
+  if (tid < 32) cs[tid] = tid < a.dt ? a.cols[tid] : 0;
+  const int WD = (a.dt + 3) >> 2;                 // waves with spline work
+  const bool active = wave < WD;
+  const bool dim_ok = 4 * wave + g < a.dt;
+  const int grp = active ? wave : 0;
+
+  // bias image in LDS (read back per element: resident it would cost PP registers per lane); lane (s, g) uses the
+  // parameters of dim 4 grp + g, in accumulator order.  Weight unscale of the group.
+  for (int i = tid; i < WD * 4 * PP; i += kGenThreads) bias_lds[i] = a.bias[i];
+  const f32x4* bw = reinterpret_cast<const f32x4*>(bias_lds + (grp * 4 + g) * PP);
+  const float w_un = a.wun[grp];
+  const f16x8* wsrc = a.wfrag + (size_t)grp * KS * T * 2 * 64 + lane;
+
+  uint32_t err = 0;
+  const int xvec = R * D / 4;                     // float4 per x tile (R * D is a multiple of 4)
+  float4 hv[HQ], xv0, xv1;
+  xv0 = xv1 = float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < HQ; ++k) hv[k] = float4{0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int64_t t) __attribute__((always_inline)) {
+    const float4* hg = reinterpret_cast<const float4*>(a.h + t * R * H);
+#pragma unroll
+    for (int k = 0; k < HQ; ++k) hv[k] = hg[tid + kGenThreads * k];
+    const float4* xg = reinterpret_cast<const float4*>(a.x + t * R * D);
+    xv0 = xg[tid < xvec ? tid : 0];
+    xv1 = xg[tid + kGenThreads < xvec ? tid + kGenThreads : 0];
+  };
+  auto xslot = [&](int buf, int i) __attribute__((always_inline)) {
+    if (!pad_x) return reinterpret_cast<float4*>(xbuf + buf * R * (D + 4) + 4 * i);
+    const int e = i * 4, r = e / D, c = e - r * D;
+    return reinterpret_cast<float4*>(xbuf + buf * R * (D + 4) + r * XS + c);
+  };
+  // float4 index f = tid + 512 k of the [R, H] tile: row f / (H/4), columns 4 (f % (H/4)) ..; the H/4 threads of a
+  // row are an aligned group of 16 / 32 / 64 lanes of one wave
+  auto park = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < HQ; ++k) {
+      const int f = tid + kGenThreads * k, r = f / kRowLanes, c = (f % kRowLanes) * 4;
+      const float v[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w};
+      const float m = group_allmax<kRowLanes>(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), lane);
+      float sc, un;
+      pow2_scale(m, sc, un);
+      f16x4 p0, p1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        _Float16 ph, pl;
+        split2(v[j] * sc, ph, pl);
+        p0[j] = ph;
+        p1[j] = pl;
+      }
+      _Float16* dst = hbuf + ((size_t)(buf * 2) * R + r) * HB + c;
+      *reinterpret_cast<f16x4*>(dst) = p0;
+      *reinterpret_cast<f16x4*>(dst + (size_t)R * HB) = p1;
+      if ((f % kRowLanes) == 0) hscale[buf * R + r] = un;
+    }
+    if (tid < xvec) *xslot(buf, tid) = xv0;
+    if (tid + kGenThreads < xvec) *xslot(buf, tid + kGenThreads) = xv1;
+  };
+  auto hfrag = [&](int buf, int blk, int piece, int ks) __attribute__((always_inline)) {
+    return *reinterpret_cast<const f16x8*>(hbuf + ((size_t)(buf * 2 + piece) * R + 16 * blk + s16) * HB + 32 * ks + 8 * g);
+  };
+  auto write_out = [&](int64_t t, int buf) __attribute__((always_inline)) {
+    float4* yg = reinterpret_cast<float4*>(a.y + t * R * D);
+    if (tid < xvec) yg[tid] = *xslot(buf, tid);
+    if (tid + kGenThreads < xvec) yg[tid + kGenThreads] = *xslot(buf, tid + kGenThreads);
+    if (tid < R) {
+      const float* lp = lpart + buf * 8 * R + tid;
+      float l = lp[0];
+#pragma unroll
+      for (int w = 1; w < 8; ++w)
+        if (w < WD) l += lp[w * R];
+      a.logabsdet[t * R + tid] = a.accumulate ? a.logabsdet[t * R + tid] + l : l;
+    }
+  };
+
+  fetch(tile0);
+  park(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t tile = tile0; tile < a.tiles; tile += stride) {
+    const bool has_next = tile + stride < a.tiles;
+    if (has_next) fetch(tile + stride);
+    if (active) {
+      // ---- parameters of both blocks: acc[b][t] = sum over k of (scaled W)(scaled h)^T, three split terms ------------
+      f32x4 acc[2][T];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int ks = 0; ks < KS; ++ks) {
+        const f16x8 bh0 = hfrag(buf, 0, 0, ks), bl0 = hfrag(buf, 0, 1, ks);
+        const f16x8 bh1 = hfrag(buf, 1, 0, ks), bl1 = hfrag(buf, 1, 1, ks);
+        const f16x8* wk = wsrc + (size_t)ks * T * 2 * 64;
+#pragma unroll
+        for (int t0 = 0; t0 < T; t0 += TC) {
+          f16x8 ah[TC], al[TC];
+#pragma unroll
+          for (int t = 0; t < TC; ++t)
+            if (t0 + t < T) {
+              ah[t] = wk[((t0 + t) * 2 + 0) * 64];
+              al[t] = wk[((t0 + t) * 2 + 1) * 64];
+            }
+#pragma unroll
+          for (int t = 0; t < TC; ++t)
+            if (t0 + t < T) {
+              // small products first; consecutive MFMAs alternate between the two blocks' accumulators
+              acc[0][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh0, acc[0][t0 + t], 0, 0, 0);
+              acc[1][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh1, acc[1][t0 + t], 0, 0, 0);
+              acc[0][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl0, acc[0][t0 + t], 0, 0, 0);
+              acc[1][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl1, acc[1][t0 + t], 0, 0, 0);
+              acc[0][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh0, acc[0][t0 + t], 0, 0, 0);
+              acc[1][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh1, acc[1][t0 + t], 0, 0, 0);
+            }
+        }
+      }
+      // ---- the two elements of this lane: (sample 16 b + s16, dim 4 wave + g) --------------------------------------
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int row = 16 * b + s16;
+        float* xr = xbuf + buf * R * (D + 4) + row * XS + cs[(4 * wave + g) & 31];
+        const float xin = *xr;
+        const float c = hscale[buf * R + row] * w_un;      // undoes both scalings (a power of two)
+        float p[PP];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const f32x4 bt = bw[t];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[4 * t + r] = __builtin_fmaf(acc[b][t][r], c, bt[r]);
+        }
+        float yv, lad;
+        op.template eval_core<true>(p, xin, yv, lad, err);
+        if (dim_ok) *xr = yv;
+        const float l = rows4_allsum(dim_ok ? lad : 0.f, lane);
+        if (g == 0) lpart[(buf * 8 + wave) * R + row] = l;
+      }
+    }
+    if (has_next) park(buf ^ 1);
+    __syncthreads();
+    write_out(tile, buf);
+    buf ^= 1;
+  }
+  if (err && a.err) atomicOr(a.err, err);
+}
+
+template <int K, bool kTails, int HQ>
+hipError_t launch_general_hq(const RQOp<K>& op, const GenArgs& a, hipStream_t stream) {
+  const size_t lds = gen_lds_bytes(a.D, a.H);
+  if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
+  static PerDeviceOnce attr;
+  const hipError_t ea = ensure_max_dynamic_lds(
+      attr, reinterpret_cast<const void*>(&rq_fused_general_kernel<K, kTails, HQ>), 160 * 1024);
+  if (ea != hipSuccess) return ea;
+  const int64_t cus = device_cu_count();
+  const unsigned grid = (unsigned)(cus < a.tiles ? cus : a.tiles);
+  hipLaunchKernelGGL((rq_fused_general_kernel<K, kTails, HQ>), dim3(grid), dim3(kGenThreads), lds, stream, op, a);
+  return hipGetLastError();
+}
+
+template <int K, bool kTails>
+hipError_t launch_general(const RQParams& q, const GenArgs& a, hipStream_t stream) {
+  RQOp<K> op;
+  op.q = q;
+  op.inv_div = 1.f / q.wh_div;
+  op.inv_beta = 1.f / q.beta;
+  switch (a.H) {
+    case 64: return launch_general_hq<K, kTails, 1>(op, a, stream);
+    case 128: return launch_general_hq<K, kTails, 2>(op, a, stream);
+    case 256: return launch_general_hq<K, kTails, 4>(op, a, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// defined in fc_rq_fused_general_tails.hip / _box.hip (one translation unit per tail mode: they build in parallel)
+hipError_t launch_general_tails(int K, const RQParams& q, const GenArgs& a, hipStream_t stream);
+hipError_t launch_general_box(int K, const RQParams& q, const GenArgs& a, hipStream_t stream);
+
+}  // namespace fc

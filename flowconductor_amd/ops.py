@@ -545,6 +545,105 @@ def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, t
     return y, lad
 
 
+# ---- general fused final layer (any K = 4..16, tails or box, hidden <= 256) -------------------------------------
+
+GENERAL_BINS = range(4, 17)
+GENERAL_HIDDEN = (64, 128, 256)
+
+
+def general_hidden_width(hidden):
+    """Width (64 / 128 / 256) a hidden activation is zero-padded to for ``fc_rq_spline_fused_general``; None if wider."""
+    for w in GENERAL_HIDDEN:
+        if hidden <= w:
+            return w
+    return None
+
+
+def fused_general_supported(n, d, d_t, hidden, num_bins, tails):
+    """Shapes of the general fused final-layer + RQ-spline kernel: K = 4..16, linear tails or none, hidden <= 256,
+    <= 32 transformed dims per launch, D <= 128, >= 32 rows."""
+    return (general_hidden_width(hidden) is not None and 1 <= d_t <= FUSED_DT and num_bins in GENERAL_BINS
+            and tails in (None, "linear") and d <= 128 and n >= FUSED_ROWS)
+
+
+def pack_final_layer_general(weight, bias, num_bins, tails, hidden_pad):
+    """The conditioner's final Linear ([d_t * P, H] weight, [d_t * P] bias, P = 3K -/+ 1) as
+    ``fc_rq_spline_fused_general`` streams it: matrix-core A fragments of the power-of-two scaled weight split into
+    two f16 pieces (fc_split.h), one scale per group of 4 dims --
+
+        w_frag   f16 [groups, H/32, T, 2 (hi, lo), 64 lanes, 8]    T = ceil(P / 4) tiles of 16 rows: (dim g, param 4t + r)
+        w_unscale f32 [groups]                                      2^-S of the group
+        bias_pad f32 [groups, 4, 4 T]
+
+    (zero rows / dims / columns pad P to 4 T, d_t to 4 * groups, H to ``hidden_pad``)."""
+    k = num_bins
+    p = 3 * k - 1 if tails == "linear" else 3 * k + 1
+    pp = -(-p // 4) * 4
+    t = pp // 4
+    d_t = weight.shape[0] // p
+    groups = -(-d_t // 4)
+    hidden = weight.shape[1]
+    ks = hidden_pad // 32
+    w = weight.new_zeros(groups * 4, pp, hidden_pad, dtype=torch.float32)
+    w[:d_t, :p, :hidden] = weight.detach().reshape(d_t, p, hidden)
+    b = bias.new_zeros(groups * 4, pp, dtype=torch.float32)
+    b[:d_t, :p] = bias.detach().reshape(d_t, p)
+    # pow2_scale of fc_split.h on the group maximum: lift it into [2^10, 2^11)
+    m = w.reshape(groups, -1).abs().amax(dim=1)
+    _, exp = torch.frexp(m)                                   # m = mant * 2^exp, mant in [0.5, 1)
+    ok = (m > 0) & torch.isfinite(m) & (exp >= -115)
+    shift = torch.where(ok, 11 - exp, torch.zeros_like(exp))
+    scale = torch.ldexp(torch.ones_like(m), shift)
+    unscale = torch.ldexp(torch.ones_like(m), -shift)
+    ws = w.reshape(groups, 4, pp, hidden_pad) * scale.reshape(groups, 1, 1, 1)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+
+    def frag(piece):
+        # [G, dim 4, T, r 4, KS, gk 4, j 8] -> [G, KS, T, gk, dim, r, j] -> [G, KS, T, 64 lanes, 8]
+        v = piece.reshape(groups, 4, t, 4, ks, 4, 8).permute(0, 4, 2, 5, 1, 3, 6)
+        return v.reshape(groups, ks, t, 64, 8)
+
+    w_frag = torch.stack((frag(hi), frag(lo)), dim=3).contiguous()
+    return w_frag, unscale.float().contiguous(), b.reshape(groups, 4, pp).contiguous()
+
+
+def rq_spline_fused_general(inputs, hidden, w_frag, w_unscale, bias_pad, cols, *, num_bins, tails, tail_bound=1.0,
+                            left=0.0, right=1.0, bottom=0.0, top=1.0, min_bin_width=DEFAULT_MIN_BIN_WIDTH,
+                            min_bin_height=DEFAULT_MIN_BIN_HEIGHT, min_derivative=DEFAULT_MIN_DERIVATIVE,
+                            wh_divisor=1.0, inverse=False, logabsdet_accum=None, enable_identity_init=False):
+    """RQ-spline coupling bijector with the conditioner's final Linear fused in, general shapes (rows a multiple of
+    32; ``hidden`` [N, 64 / 128 / 256] zero-padded; packed weights from ``pack_final_layer_general``).  Semantics and
+    return values as ``rq_spline_fused_linear``; without tails inputs outside the box raise InputOutsideDomain."""
+    lib = _hip.load()
+    x = _prep_2d(inputs, align16=True)
+    h = _aligned16(_hip.dev_f32(hidden, "hidden"))
+    _hip.require_no_grad(inputs, hidden)
+    n, d = x.shape
+    cols = _as_cols(cols, x.device)
+    d_t = cols.numel()
+    hw = h.shape[1]
+    if (n % FUSED_ROWS != 0 or h.shape[0] != n or hw not in GENERAL_HIDDEN or not 1 <= d_t <= FUSED_DT
+            or w_frag.shape[0] != -(-d_t // 4) or w_frag.shape[1] != hw // 32):
+        raise ValueError("general fused RQ layer: unsupported shapes %s / %s" % (tuple(x.shape), tuple(h.shape)))
+    cfg = _rq_config(num_bins, tails, tail_bound, (left, right, bottom, top), min_bin_width, min_bin_height,
+                     min_derivative, enable_identity_init, wh_divisor, inverse)
+    y = torch.empty_like(x)
+    if logabsdet_accum is not None:
+        lad = logabsdet_accum
+        if lad.dtype != torch.float32 or lad.shape != (n,) or not lad.is_contiguous() or lad.device != x.device:
+            raise ValueError("logabsdet_accum must be a contiguous float32 [N] tensor on the inputs' device")
+        cfg.flags = 1  # FC_RQ_ACCUMULATE_LOGABSDET
+    else:
+        lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    err = _err_word(x.device, True)
+    _call("fc_rq_spline_fused_general", lib.fc_rq_spline_fused_general, x.device, _hip.ptr(x), _hip.ptr(y),
+          _hip.ptr(h), _hip.ptr(w_frag), _hip.ptr(w_unscale), _hip.ptr(bias_pad), _hip.ptr(cols), _hip.ptr(lad),
+          _hip.ptr(err), n, d, d_t, hw, cfg, _hip.stream_ptr(x.device))
+    _finish(True)
+    return y, lad
+
+
 # ---- affine / additive ------------------------------------------------------------------------
 
 AFFINE_SIGMOID_PLUS2 = 0

@@ -296,74 +296,104 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             wh_divisor=_softmax_divisor(self.transform_net, warn=True), inverse=inverse)
 
     # ---- fused final conditioner layer (SURVEY.md 8f #4) -------------------------------------------
-    # When the conditioner is this package's ResidualNet with the north-star shape (hidden 64, K = 8, linear
-    # tails) its last nn.Linear is evaluated INSIDE the spline kernel on the matrix cores (split-f16
-    # products, f32-GEMM accuracy), so the [N, 736] parameter tensor never touches HBM; the hidden layers
-    # run in fc_resnet_hidden.  The kernel takes up to 32 transformed dims per launch: wider layers
-    # (D <= 128) chain one launch per 32 dims, each passing the other columns through.  Inference only.
-    # Any other conditioner / shape takes the generic path; FC_FUSED=0 disables it.
+    # When the conditioner is this package's ResidualNet its last nn.Linear is evaluated INSIDE the spline kernel on the
+    # matrix cores (split-f16 products, f32-GEMM accuracy), so the [N, d_t (3K -/+ 1)] parameter tensor never touches
+    # HBM.  Two kernels: "k8" -- the hand-scheduled north-star shape (K = 8, linear tails, hidden <= 64: weights
+    # resident in registers, fc_rq_spline_fused_linear) -- and "general" -- K = 4..16, tails linear or None, hidden
+    # <= 256, weights streamed from L2 in packed fragment order (fc_rq_spline_fused_general; the reference's default
+    # layer, num_bins = 10, lands here).  Both take up to 32 transformed dims per launch: wider layers (D <= 128)
+    # chain one launch per 32 dims, each passing the other columns through.  The hidden layers run in fc_resnet_hidden
+    # when that kernel covers them, else on PyTorch-ROCm.  Inference only; any other conditioner / shape takes the
+    # generic path; options.override(fused_final_layer=False) disables it.
 
-    def _fused_ok(self, inputs):
+    def _fused_mode(self, inputs):
+        """None, "k8" or "general"."""
         net = self.transform_net
         if torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in net.parameters())):
-            return False   # training: conditioner on PyTorch autograd + the spline's own backward kernel
-        return (options.get("fused_final_layer") and _is_plain_resnet(net) and not ops.has_hooks(net)
-                and inputs.dim() == 2
-                and inputs.is_cuda and inputs.dtype == torch.float32
-                and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1],
-                                               min(self.num_transform_features, ops.FUSED_DT),
-                                               net.hidden_features, self.num_bins, self.tails))
+            return None   # training: conditioner on PyTorch autograd + the spline's own backward kernel
+        if not (options.get("fused_final_layer") and _is_plain_resnet(net) and not ops.has_hooks(net)
+                and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32):
+            return None
+        n, d = inputs.shape
+        d_t = min(self.num_transform_features, ops.FUSED_DT)
+        if ops.fused_linear_supported(n, d, d_t, net.hidden_features, self.num_bins, self.tails):
+            return "k8"
+        if ops.fused_general_supported(n, d, d_t, net.hidden_features, self.num_bins, self.tails):
+            return "general"
+        return None
 
-    def _fused_chunks(self, device):
-        """[(w_pad, bias_pad, cols)] per group of <= 32 transformed dims: the final Linear's rows of those dims in
-        the kernel's layout + their column indices."""
+    def _fused_ok(self, inputs):
+        return self._fused_mode(inputs) is not None
+
+    def _fused_chunks(self, device, mode):
+        """Per group of <= 32 transformed dims: the final Linear's rows of those dims in the kernel's layout + their
+        column indices -- (w_pad, bias_pad, cols) for "k8", (w_frag, w_unscale, bias_pad, cols) for "general"."""
         lin = self.transform_net.final_layer
-        key = ops.cache_key(lin.weight, lin.bias)
+        key = ops.cache_key(lin.weight, lin.bias, extra=(mode,))
         if getattr(self, "_packed", None) is None or self._packed[0] != key:
-            per_dim = 3 * self.num_bins - 1
+            per_dim = self._transform_dim_multiplier()
             cols = self._cols(device)
+            hidden_pad = ops.general_hidden_width(lin.in_features)
             chunks = []
             for lo in range(0, self.num_transform_features, ops.FUSED_DT):
                 hi = min(lo + ops.FUSED_DT, self.num_transform_features)
                 rows = slice(lo * per_dim, hi * per_dim)
-                chunks.append(ops.pack_final_layer(lin.weight[rows], lin.bias[rows], self.num_bins)
-                              + (cols[lo:hi].contiguous(),))
+                if mode == "k8":
+                    packed = ops.pack_final_layer(lin.weight[rows], lin.bias[rows], self.num_bins)
+                else:
+                    packed = ops.pack_final_layer_general(lin.weight[rows], lin.bias[rows], self.num_bins, self.tails,
+                                                          hidden_pad)
+                chunks.append(packed + (cols[lo:hi].contiguous(),))
             self._packed = (key, chunks)
         return self._packed[1]
 
     def _apply_accumulate(self, inputs, context, inverse, total):
         """CompositeTransform fast path: the fused kernel adds this layer's logabsdet onto ``total`` itself."""
-        if not self._fused_ok(inputs) or self.unconditional_transform is not None:
+        if self._fused_mode(inputs) is None or self.unconditional_transform is not None:
             outputs, logabsdet = self._run(inputs, context, inverse)
             total += logabsdet
             return outputs
         outputs, _ = self._run(inputs, context, inverse, total=total)
         return outputs
 
+    def _hidden_for_fused(self, inputs, identity_split, context, width):
+        """[N, width] hidden activation of the conditioner (zero columns beyond ``hidden_features``): the hidden-layer
+        kernel straight from the full input rows where it covers the net, PyTorch-ROCm otherwise / for leftover rows."""
+        net = self.transform_net
+        n = inputs.shape[0]
+
+        def on_torch(rows_identity, ctx):
+            h = net.hidden(rows_identity, ctx)
+            return h if h.shape[1] == width else torch.nn.functional.pad(h, (0, width - h.shape[1]))
+
+        body16 = n - n % ops.HIDDEN_ROWS
+        if (identity_split is None and width == 64 and body16 > 0 and options.get("fused_hidden")
+                and net.hip_hidden_supported(inputs.shape[1], context)):
+            hidden = net.hidden_hip(inputs[:body16], self._id_cols(inputs.device),
+                                    None if context is None else context[:body16])
+            if body16 < n:
+                hidden = torch.cat((hidden, on_torch(inputs[body16:, self.identity_features],
+                                                     None if context is None else context[body16:])))
+            return hidden
+        if identity_split is None:
+            identity_split = inputs[:, self.identity_features]
+        return on_torch(identity_split, context)
+
     def _run(self, inputs, context, inverse, total=None):
-        if not self._fused_ok(inputs):
+        mode = self._fused_mode(inputs)
+        if mode is None:
             return super()._run(inputs, context, inverse)
         self._check(inputs)
         net = self.transform_net
         n = inputs.shape[0]
-        body16 = n - n % ops.HIDDEN_ROWS
         identity_split = logabsdet_identity = None
-        if (self.unconditional_transform is None and body16 > 0
-                and options.get("fused_hidden")
-                and net.hip_hidden_supported(inputs.shape[1], context)):
-            # hidden layers of the conditioner in one matrix-core kernel straight from the full input rows: the
-            # identity half is never gathered into a separate tensor
-            hidden = net.hidden_hip(inputs[:body16], self._id_cols(inputs.device),
-                                    None if context is None else context[:body16])
-            if body16 < n:
-                hidden = torch.cat((hidden, net.hidden_padded(inputs[body16:, self.identity_features],
-                                                              None if context is None else context[body16:])))
-        else:
+        if self.unconditional_transform is not None:
             identity_split = inputs[:, self.identity_features]
-            if inverse and self.unconditional_transform is not None:
+            if inverse:
                 identity_split, logabsdet_identity = self.unconditional_transform.inverse(identity_split, context)
-            hidden = net.hidden_padded(identity_split, context)
-        chunks = self._fused_chunks(inputs.device)
+        width = 64 if mode == "k8" else ops.general_hidden_width(net.hidden_features)
+        hidden = self._hidden_for_fused(inputs, identity_split, context, width)
+        chunks = self._fused_chunks(inputs.device, mode)
         kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                   min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
                   wh_divisor=_softmax_divisor(net, warn=False), inverse=inverse)
@@ -371,8 +401,14 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         def fused(rows, h, accum):
             # the groups only depend on the identity columns: any order, each launch passes the rest through
             lad = accum
-            for w_pad, bias_pad, cols in chunks:
-                rows, lad = ops.rq_spline_fused_linear(rows, h, w_pad, bias_pad, cols, logabsdet_accum=lad, **kw)
+            for chunk in chunks:
+                if mode == "k8":
+                    w_pad, bias_pad, cols = chunk
+                    rows, lad = ops.rq_spline_fused_linear(rows, h, w_pad, bias_pad, cols, logabsdet_accum=lad, **kw)
+                else:
+                    w_frag, w_un, bias_pad, cols = chunk
+                    rows, lad = ops.rq_spline_fused_general(rows, h, w_frag, w_un, bias_pad, cols, tails=self.tails,
+                                                            logabsdet_accum=lad, **kw)
             return rows, lad
 
         body = n - n % ops.FUSED_ROWS
@@ -381,8 +417,9 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         else:
             # the < 32 leftover rows go through the final Linear + the stand-alone kernel
             out_a, lad_a = fused(inputs[:body], hidden[:body], None if total is None else total[:body])
-            out_b, lad_b = self._coupling_kernel(inputs[body:].contiguous(), net.final_from_padded(hidden[body:]),
-                                                 inverse)
+            tail_params = torch.nn.functional.linear(hidden[body:, :net.final_layer.in_features],
+                                                     net.final_layer.weight, net.final_layer.bias)
+            out_b, lad_b = self._coupling_kernel(inputs[body:].contiguous(), tail_params, inverse)
             outputs = torch.cat((out_a, out_b))
             if total is None:
                 logabsdet = torch.cat((lad_a, lad_b))

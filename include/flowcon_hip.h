@@ -82,6 +82,23 @@ int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const fl
                               uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t, int32_t hidden,
                               const fc_rq_config* cfg, void* stream);
 
+/* The same fusion for general layer shapes -- the reference's DEFAULT coupling layer has num_bins = 10
+ * (coupling.py:507), any hidden_features (nn/nets/resnet.py:62) and allows tails = None (coupling.py:543-547):
+ * K = 4..16, cfg->tails 0 or 1, hidden in {64, 128, 256} (narrower activations zero-padded), 1 <= d_t <= 32, d <= 128,
+ * n % 32 == 0.  The weights are not resident in registers here: the host packs them once per parameter version into
+ * matrix-core fragment order (scaled by a power of two per group of 4 dims, split into two f16 pieces) and every wave
+ * streams the fragments of its dims from L2.
+ *   h         [n, hidden]
+ *   w_frag    f16 [groups][hidden/32][T][2][64][8], groups = ceil(d_t/4), T = ceil(P/4), P = 3K -/+ 1: fragment
+ *             (group, k-step, tile t, piece hi/lo): lane l holds 2^S W[dim 4 group + ((l&15)>>2)][param 4t + (l&3)]
+ *             [k = 32 kstep + 8 (l>>4) + j], j < 8
+ *   w_unscale f32 [groups] = 2^-S;  bias_pad f32 [groups][4][4T]
+ * cfg->flags: FC_RQ_ACCUMULATE_LOGABSDET.  Without tails, inputs outside [left, right] set FC_ERR_OUTSIDE_DOMAIN. */
+int fc_rq_spline_fused_general(const float* x, float* y, const float* h, const void* w_frag,
+                               const float* w_unscale, const float* bias_pad, const int32_t* cols,
+                               float* logabsdet, uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t,
+                               int32_t hidden, const fc_rq_config* cfg, void* stream);
+
 /* Backward of fc_affine in the forward direction, per-sample parameters (coupling.py:234-252,
  * autoregressive.py:97-129 under torch.autograd): grad_x[n, cols[j]] = gy s; grad_params in the layout of
  * `params` for the same `activation`.  Other columns of grad_x are NOT written. */
