@@ -145,6 +145,37 @@ class ResidualNet(nn.Module):
                 return False
         return True
 
+    def hip_hidden_wide_supported(self, features_total, context=None):
+        """True when ``fc_resnet_hidden_wide`` covers this net: 64 < hidden <= 256 (zero-padded to 128 / 256), no
+        context, no batch norm, dropout inactive, a known activation, <= 64 input features, <= 16 blocks."""
+        from flowconductor_amd import ops
+
+        if not 64 < self.hidden_features <= 256 or context is not None or self.context_features is not None:
+            return False
+        in_f = self.initial_layer.in_features
+        if in_f > 64 or in_f > features_total or len(self.blocks) > 16:
+            return False
+        for block in self.blocks:
+            code = ops.activation_code(block.activation)
+            if block.use_batch_norm or code is None or code != ops.activation_code(self.blocks[0].activation):
+                return False
+            if block.dropout.p > 0 and self.training:
+                return False
+        return True
+
+    def hidden_hip_wide(self, rows, id_cols):
+        """h [N, 128 or 256] from FULL input rows + the identity column indices (N a multiple of 64); columns
+        ``hidden_features``.. are zero."""
+        from flowconductor_amd import ops
+
+        width = ops.general_hidden_width(self.hidden_features)
+        key = ops.cache_key(*self.parameters(), extra=("wide", width))
+        if getattr(self, "_hip_packed_wide", None) is None or self._hip_packed_wide[0] != key:
+            self._hip_packed_wide = (key, ops.pack_resnet_hidden_wide(self, width))
+        act = ops.activation_code(self.blocks[0].activation) if len(self.blocks) else (ops.ACT_RELU, 0.0)
+        return ops.resnet_hidden_wide(rows, id_cols, self._hip_packed_wide[1], self.initial_layer.in_features,
+                                      len(self.blocks), width, act)
+
     def hidden_padded(self, inputs, context=None):
         """``hidden`` on PyTorch, zero-padded to the kernel's 64 columns (leftover rows next to ``hidden_hip``)."""
         h = self.hidden(inputs, context)

@@ -450,6 +450,63 @@ def activation_code(fn):
 
 CONTEXT_GLU, CONTEXT_ADDITIVE = 1, 2
 
+WIDE_ROWS = 64
+
+
+def _pow2_scale(m):
+    """fc_split.h pow2_scale on a tensor of maxima: (scale, unscale) lifting each into [2^10, 2^11)."""
+    _, exp = torch.frexp(m)                                   # m = mant * 2^exp, mant in [0.5, 1)
+    ok = (m > 0) & torch.isfinite(m) & (exp >= -115)
+    shift = torch.where(ok, 11 - exp, torch.zeros_like(exp))
+    return torch.ldexp(torch.ones_like(m), shift), torch.ldexp(torch.ones_like(m), -shift)
+
+
+def _a_fragments(w):
+    """[rows (multiple of 16), K (multiple of 32)] f32, already scaled -> f16 [rows/16, K/32, 2 (hi, lo), 64, 8]: the
+    matrix-core A fragments of v_mfma_f32_16x16x32_f16 (lane l holds row l & 15, k = 32 kstep + 8 (l >> 4) + j)."""
+    rows, k = w.shape
+    hi = w.to(torch.float16)
+    lo = (w - hi.float()).to(torch.float16)
+
+    def frag(piece):
+        return piece.reshape(rows // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(rows // 16, k // 32, 64, 8)
+
+    return torch.stack((frag(hi), frag(lo)), dim=2).contiguous()
+
+
+def pack_resnet_hidden_wide(net, width):
+    """Hidden layers of a ResidualNet with 64 < hidden_features <= 256 (no context) as ``fc_resnet_hidden_wide``
+    streams them: every layer's weight zero-padded to ``width`` (128 / 256) rows and 32-multiples of columns, scaled
+    by a power of two per layer, split into two f16 pieces, in fragment order; all layers in one flat f16 buffer.
+    Returns (w_frag, w_unscale [1 + 2 blocks], bias [1 + 2 blocks, width])."""
+    layers = [net.initial_layer] + [lin for block in net.blocks for lin in block.linear_layers]
+    frags, uns, biases = [], [], []
+    for i, lin in enumerate(layers):
+        kin = (32 if lin.in_features <= 32 else 64) if i == 0 else width
+        w = _pad_to(lin.weight.detach().float(), (width, kin))
+        sc, un = _pow2_scale(w.abs().amax().reshape(1))
+        frags.append(_a_fragments(w * sc).reshape(-1))
+        uns.append(un)
+        biases.append(_pad_to(lin.bias.detach().float(), (width,)))
+    return torch.cat(frags).contiguous(), torch.cat(uns).float().contiguous(), torch.stack(biases).contiguous()
+
+
+def resnet_hidden_wide(inputs, id_cols, packed, in_features, num_blocks, width, activation=(ACT_RELU, 0.0)):
+    """Hidden layers of a wide conditioner on the rows of ``inputs`` (multiple of 64 rows) -> h [N, width]."""
+    lib = _hip.load()
+    x = _prep_2d(inputs)
+    _hip.require_no_grad(inputs)
+    n, d = x.shape
+    if n % WIDE_ROWS != 0 or width not in (128, 256):
+        raise ValueError("fc_resnet_hidden_wide needs a multiple of %d rows and a width of 128 or 256" % WIDE_ROWS)
+    w_frag, w_un, bias = packed
+    ids = _as_cols(id_cols, x.device)
+    h = torch.empty(n, width, dtype=torch.float32, device=x.device)
+    _call("fc_resnet_hidden_wide", lib.fc_resnet_hidden_wide, x.device, _hip.ptr(x), _hip.ptr(h), _hip.ptr(ids),
+          _hip.ptr(w_frag), _hip.ptr(w_un), _hip.ptr(bias), n, d, in_features, width, num_blocks, int(activation[0]),
+          float(activation[1]), _hip.stream_ptr(x.device))
+    return h
+
 
 def resnet_hidden(inputs, id_cols, packed, in_features, num_blocks, context=None, activation=(ACT_RELU, 0.0),
                   context_mode=CONTEXT_GLU):

@@ -375,6 +375,13 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
                 hidden = torch.cat((hidden, on_torch(inputs[body16:, self.identity_features],
                                                      None if context is None else context[body16:])))
             return hidden
+        body64 = n - n % ops.WIDE_ROWS
+        if (identity_split is None and width > 64 and body64 > 0 and options.get("fused_hidden")
+                and net.hip_hidden_wide_supported(inputs.shape[1], context)):
+            hidden = net.hidden_hip_wide(inputs[:body64], self._id_cols(inputs.device))
+            if body64 < n:
+                hidden = torch.cat((hidden, on_torch(inputs[body64:, self.identity_features], None)))
+            return hidden
         if identity_split is None:
             identity_split = inputs[:, self.identity_features]
         return on_torch(identity_split, context)

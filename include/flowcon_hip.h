@@ -138,6 +138,19 @@ int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const flo
                      int32_t in_features, int32_t hidden, int32_t num_blocks, int32_t activation,
                      float activation_param, void* stream);
 
+/* The same stack for WIDE conditioners: hidden in {128, 256} (hidden_features is a free constructor argument,
+ * resnet.py:62; narrower widths zero-padded by the host), any num_blocks <= 16, no context.  The activations of a
+ * 64-sample tile live in LDS as matrix-core B operands shared by the workgroup's 8 waves; wave w owns the output
+ * features [w hidden/8, (w+1) hidden/8) of every layer and streams their weight fragments from L2.  n % 64 == 0.
+ *   w_frag    f16: layer 0 [hidden/16][K0S][2][64][8] (K0S = 1 for in_features <= 32, else 2), then per layer
+ *             [hidden/16][hidden/32][2][64][8]: fragment (tile t, k-step, piece hi/lo): lane l holds
+ *             2^S_layer W[16 t + (l & 15)][32 kstep + 8 (l >> 4) + j], j < 8
+ *   w_unscale f32 [1 + 2 num_blocks] = 2^-S_layer;  bias f32 [1 + 2 num_blocks][hidden] */
+int fc_resnet_hidden_wide(const float* x, float* h, const int32_t* id_cols, const void* w_frag,
+                          const float* w_unscale, const float* bias, int64_t n, int32_t d, int32_t in_features,
+                          int32_t hidden, int32_t num_blocks, int32_t activation, float activation_param,
+                          void* stream);
+
 /* The same with a context (resnet.py:48-49, 94-97): the initial layer sees [x[:, id_cols] | context]
  * (w0 [64, in_features + context_features]) and every block gates its output,
  *   h += (W2 relu(W1 relu(h) + b1) + b2) * sigmoid(Wc context + bc)      (F.glu of the concatenation),

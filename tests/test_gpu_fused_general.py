@@ -46,9 +46,15 @@ def test_general_fused_layer_matches_oracle_and_unfused(k, tails, hidden, device
     d, n = 16, 1000          # 1000 = 31 tiles of 32 rows + 8 leftover rows
     t = _layer(d, hidden, k, tails, seed=100 * k + hidden)
     x = _inputs(n, d, tails, seed=k)
+    import copy
     with torch.no_grad():
         y_ref, lad_ref = O.transform_apply(t, x.clone())
         xi_ref, ladi_ref = O.transform_apply(t, y_ref.clone(), inverse=True)
+        # the reference's own f32 noise floor on these (steep, every-bin) splines: |f32 - f64| of the oracle
+        t64 = copy.deepcopy(t).double()
+        y64, lad64 = O.transform_apply(t64, x.double())
+        xi64, ladi64 = O.transform_apply(t64, y_ref.double(), inverse=True)
+    fy, fl, fxi, fli = (maxdiff(a, b) for a, b in ((y_ref, y64), (lad_ref, lad64), (xi_ref, xi64), (ladi_ref, ladi64)))
     td, xd = t.to(device), x.to(device)
     with torch.no_grad():
         assert td._fused_mode(xd) == "general"
@@ -59,11 +65,13 @@ def test_general_fused_layer_matches_oracle_and_unfused(k, tails, hidden, device
         monkeypatch.setitem(options._values, "fused_final_layer", False)
         y_u, lad_u = td(xd)
     scale = max(1.0, float(y_ref.abs().max()))
-    assert maxdiff(y, y_ref) <= 2e-5 * scale
-    assert maxdiff(lad, lad_ref) <= 2e-4 * max(1.0, float(lad_ref.abs().max()) / 10)
+    lscale = max(1.0, float(lad_ref.abs().max()))
+    # 1e-5 relative + 8 x the reference's own float32 noise floor (the bound of tests/test_gpu_golden.py)
+    assert maxdiff(y, y_ref) <= 1e-5 * scale + 8 * fy
+    assert maxdiff(lad, lad_ref) <= 1e-5 * lscale + 8 * fl
     assert maxdiff(y, y_u) <= 5e-5 * scale and maxdiff(lad, lad_u) <= 1e-3
-    assert maxdiff(xi, xi_ref) <= 3e-4 * scale
-    assert maxdiff(ladi, ladi_ref) <= 3e-3 * max(1.0, float(ladi_ref.abs().max()) / 10)
+    assert maxdiff(xi, xi_ref) <= 1e-5 * scale + 8 * fxi
+    assert maxdiff(ladi, ladi_ref) <= 1e-5 * lscale + 8 * fli
     assert torch.isfinite(y).all() and torch.isfinite(lad).all()
 
 
@@ -149,3 +157,76 @@ def test_default_constructed_nsf_layer_takes_the_fused_path(device):
             y, lad = stack.to(device)(x.to(device))
     assert len(timer.pairs) == 4
     assert maxdiff(y, y_ref) <= 2e-5 and maxdiff(lad, lad_ref) <= 3e-4
+
+
+# ---- the wide hidden-layer kernel (fc_resnet_hidden_wide) -----------------------------------------------------------
+
+@pytest.mark.parametrize("hidden,in_f,blocks,d,n", [(256, 32, 2, 64, 64), (256, 32, 2, 64, 6400), (128, 32, 2, 64, 1024),
+                                                   (128, 16, 1, 32, 128), (256, 64, 3, 128, 192), (200, 7, 2, 15, 64),
+                                                   (100, 33, 4, 70, 256), (256, 6, 0, 12, 64), (128, 32, 2, 64, 100032)])
+def test_wide_hidden_kernel_matches_torch_float64(hidden, in_f, blocks, d, n, device):
+    """fc_resnet_hidden_wide against the same nn.Module evaluated in float64 on the CPU; widths that are zero-padded to
+    128 / 256 keep their padding columns exactly 0."""
+    import copy
+
+    torch.manual_seed(hidden + in_f + blocks)
+    net = nets.ResidualNet(in_f, 8, hidden_features=hidden, num_blocks=blocks).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)      # make the residual blocks matter (their last layer is initialised ~1e-3)
+    ids = torch.randperm(d)[:in_f].sort().values
+    x = torch.randn(n, d) * torch.logspace(-2, 1, n).unsqueeze(1)      # row scales over three decades
+    with torch.no_grad():
+        ref = copy.deepcopy(net).double().hidden(x[:, ids].double())
+        ref32 = net.hidden(x[:, ids])
+        assert net.hip_hidden_wide_supported(d)
+        with ops.KernelTimer("fc_resnet_hidden_wide") as timer:
+            got = net.to(device).hidden_hip_wide(x.to(device), ids.to(device))
+        assert len(timer.pairs) == 1
+    width = 128 if hidden <= 128 else 256
+    assert got.shape == (n, width)
+    assert float(got[:, hidden:].abs().max()) == 0.0 if hidden < width else True
+    floor = maxdiff(ref32, ref)      # an f32 GEMM stack's own distance from the float64 result
+    assert maxdiff(got[:, :hidden], ref) <= 1e-5 * max(1.0, float(ref.abs().max())) + 4 * floor
+
+
+@pytest.mark.parametrize("name", ["tanh", "silu", "elu", "leaky_relu", "sigmoid"])
+def test_wide_hidden_kernel_other_activations(name, device):
+    import copy
+
+    from torch import nn
+    from torch.nn import functional as F
+
+    acts = {"tanh": torch.tanh, "silu": F.silu, "elu": nn.ELU(alpha=1.3), "leaky_relu": nn.LeakyReLU(0.2),
+            "sigmoid": nn.Sigmoid()}
+    torch.manual_seed(5)
+    net = nets.ResidualNet(20, 8, hidden_features=160, num_blocks=2, activation=acts[name]).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.7)
+    ids = torch.arange(1, 41, 2)
+    x = torch.randn(320, 41)
+    with torch.no_grad():
+        ref = copy.deepcopy(net).double().hidden(x[:, ids].double())
+        got = net.to(device).hidden_hip_wide(x.to(device), ids.to(device))
+    assert maxdiff(got[:, :160], ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float(got[:, 160:].abs().max()) == 0.0
+
+
+def test_wide_nsf_flow_runs_both_wide_kernels(device):
+    """K = 10, hidden 256 (the shape of bench.py's `nsf_k10_h256` block): every layer = one fc_resnet_hidden_wide + one
+    fc_rq_spline_fused_general launch; against the oracle, with leftover rows (n % 64 != 0)."""
+    torch.manual_seed(0)
+    d = 64
+    layers = [T.PiecewiseRationalQuadraticCouplingTransform(
+        utils.create_alternating_binary_mask(d, even=(i % 2 == 0)),
+        lambda a, b: nets.ResidualNet(a, b, hidden_features=256, num_blocks=2), num_bins=10, tails="linear",
+        tail_bound=3.0) for i in range(4)]
+    stack = T.CompositeTransform(layers).eval()
+    x = torch.randn(64 * 9 + 37, d) * 1.3
+    with torch.no_grad():
+        y_ref, lad_ref = O.transform_apply(stack, x.clone())
+        with ops.KernelTimer("fc_rq_spline_fused_general") as tf, ops.KernelTimer("fc_resnet_hidden_wide") as th:
+            y, lad = stack.to(device)(x.to(device))
+    assert len(tf.pairs) == 4 and len(th.pairs) == 4
+    assert maxdiff(y, y_ref) <= 2e-5 * max(1.0, float(y_ref.abs().max())) and maxdiff(lad, lad_ref) <= 3e-4
