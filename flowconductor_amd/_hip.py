@@ -96,6 +96,8 @@ SIGNATURES = {
                                   ctypes.POINTER(RQConfig), _P],
     "fc_rq_spline_fused_general": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32,
                                    ctypes.POINTER(RQConfig), _P],
+    "fc_rq_fused_linear_backward": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32,
+                                    ctypes.POINTER(RQConfig), _P],
     "fc_resnet_hidden": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, ctypes.c_float, _P],
     "fc_resnet_hidden_wide": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, ctypes.c_float, _P],
     "fc_resnet_hidden_context": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32,

@@ -50,5 +50,7 @@ __device__ __forceinline__ float rows4_allmax(float v, int lane) {
   v = fmaxf(v, lane_xor32(v, lane));
   return fmaxf(v, lane_xor16(v, lane));
 }
+// max over all 64 lanes, every lane gets it
+__device__ __forceinline__ float wave64_allmax(float v, int lane) { return rows4_allmax(row16_allmax(v), lane); }
 
 }  // namespace fc

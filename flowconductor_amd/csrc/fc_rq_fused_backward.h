@@ -1,0 +1,394 @@
+// Backward of the fused final-Linear + RQ-spline coupling layer (training through the HIP path), gfx950.
+//
+//   forward:   params = W h + b;   y, logabsdet = rq_spline(x, params)            (fc_rq_fused_general.h)
+//   backward:  given gy = dL/dy [N, D], gl = dL/dlogabsdet [N]
+//       G[n, f]  = dL/dparams                      (closed-form spline backward, fc_rq_backward.hip)
+//       gx       = gy on the identity columns, gy dy/dx + gl dlad/dx on the transformed ones
+//       gh[n, :] = W^T G[n, :]                     (gradient into the conditioner's hidden stack)
+//       gW       = sum_n G[n, :] (x) h[n, :],   gb = sum_n G[n, :]
+//
+// What torch.autograd does for the reference (examples/toy_2d.py:57-68) materialises params [N, d_t P] in the forward
+// and G [N, d_t P] in the backward and runs three library GEMMs over them: ~9 GB of HBM traffic per layer at N = 2^19.
+// Here neither tensor ever exists: the parameters are RECOMPUTED on the matrix cores from the saved h (the forward
+// kernel's product, fragment for fragment), the spline backward runs on them in registers, and G goes from the lane's
+// registers straight into the two products that consume it.  Two launches share this code (`kRole`), each recomputing
+// G, because the second product's accumulators (the wave's [4 dims x P, 64] slice of gW) fill the register file:
+//
+//   kRole 0 ("dx"): gx, gh, gb.   gh^T = W^T G: the lane's own 3K-/+1 gradients ARE its B operand (accumulator order =
+//           k order, the trick of fc_resnet_hidden.hip); per (sample, wave) power-of-two scale; the 8 waves' partial
+//           gh tiles are summed in a fixed order through LDS (deterministic).
+//   kRole 1 ("dw"): gW.   gW = G^T h contracts over SAMPLES, which live on lanes: G passes through a wave-private LDS
+//           strip, one 16-feature tile at a time, to become an A operand (features on rows, samples on k); h^T comes
+//           from a transposed copy of the h tile.  h keeps its per-row scale 2^T_s (shared with the recompute product),
+//           so G is pre-multiplied by 2^-T_s (exact); one running power-of-two scale per wave for G: when a tile
+//           needs a smaller one the accumulators are rescaled (exact), so the sum over all tiles stays in one scale.
+//
+// hidden == 64 (the conditioner width fc_resnet_hidden serves), K = 4..16 where the accumulators fit (T <= 8).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fc_device.h"
+#include "fc_lane.h"
+#include "fc_math.h"
+#include "fc_rq_op.h"
+#include "fc_rq_backward_op.h"
+#include "fc_split.h"
+#include "fc_tile.h"
+#include "fc_rq_fused_general.h"
+#include "../../include/flowcon_hip.h"
+
+namespace fc {
+
+struct BwdArgs {
+  const float* x;          // [N, D]  layer input (saved by the forward)
+  const float* h;          // [N, 64] conditioner's last hidden activation (saved by the forward)
+  const float* gy;         // [N, D]
+  const float* gl;         // [N] or null (zeros)
+  const f16x8* wfrag;      // forward fragments  [groups][2][T][2][64]        (ops.pack_final_layer_general, hidden 64)
+  const float* wun;        // [groups]
+  const float* bias;       // [groups][4][PP]
+  const f16x8* wtfrag;     // role 0: W^T fragments [groups][4 hidden tiles][KK][2][64]   (ops.pack_final_layer_transposed)
+  const int32_t* cols;     // [dt]
+  float* gx;               // role 0: [N, D]
+  float* gh;               // role 0: [N, 64]
+  float* gb;               // role 0: [groups][4][PP], accumulated with atomics (zeroed by the caller)
+  float* gw;               // role 1: [groups][4][PP][64], accumulated with atomics (zeroed by the caller)
+  int64_t tiles;           // 32-row tiles
+  int D, dt;
+};
+
+constexpr int kBwdH = 64, kBwdHB = kBwdH + 8, kBwdR = kGenRows, kBwdTS = 32 + 8;   // TS: f16 per row of a transposed image
+
+inline size_t bwd_lds_bytes(int d, int role) {
+  size_t b = (size_t)2 * 2 * kBwdR * kBwdHB * 2;            // hbuf [buf][piece][row][72]
+  b += (size_t)2 * 2 * kBwdR * (d + 4) * 4;                 // xbuf + gbuf, [buf][row][D + 4]
+  b += 2 * kBwdR * 4 * 2;                                   // hscale, gl  [buf][row]
+  b += 32 * 4 + (size_t)32 * 52 * 4;                        // cols, bias image
+  if (role == 0) b += (size_t)8 * kBwdR * (kBwdH + 4) * 4;  // partial gh tiles of the 8 waves
+  else b += (size_t)2 * 2 * kBwdH * kBwdTS * 2 + (size_t)8 * 2 * 16 * kBwdTS * 2;   // h^T [buf][piece][64][40], G^T strips
+  return b;
+}
+
+template <int K, bool kTails, int kRole>
+__global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams q, float inv_div, BwdArgs a) {
+  using S = GenShape<K, kTails>;
+  constexpr int P = S::P, PP = S::PP, T = S::T;
+  constexpr int PP8 = (PP + 7) / 8 * 8, KK = PP8 / 8;       // role 0: k-steps of the W^T product (8 parameters per lane)
+  constexpr int R = kBwdR, H = kBwdH, HB = kBwdHB, KS = 2, TS = kBwdTS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
+  const int D = a.D;
+  const bool pad_x = (D & 3) == 0;
+  const int XS = pad_x ? D + 4 : D;
+  _Float16* hbuf = reinterpret_cast<_Float16*>(bsm);                             // [2][2][R][HB]
+  float* xbuf = reinterpret_cast<float*>(bsm + (size_t)2 * 2 * R * HB * 2);       // [2][R][D + 4]
+  float* gbuf = xbuf + 2 * R * (D + 4);                                           // [2][R][D + 4]  gy in, gx out
+  float* hscale = gbuf + 2 * R * (D + 4);                                         // [2][R]
+  float* glb = hscale + 2 * R;                                                    // [2][R]
+  int* cs = reinterpret_cast<int*>(glb + 2 * R);                                  // [32]
+  float* bias_lds = reinterpret_cast<float*>(cs + 32);                            // [8][4][PP] (<= 32 * 52)
+  float* part = bias_lds + 32 * 52;                                               // role 0: [8][R][H + 4]
+  _Float16* htbuf = reinterpret_cast<_Float16*>(bias_lds + 32 * 52);              // role 1: [2][2][H][TS]
+  _Float16* strips = htbuf + (size_t)2 * 2 * H * TS;                              // role 1: [8 waves][2][16][TS]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int s16 = lane & 15, g = lane >> 4;
+  const int64_t stride = gridDim.x, tile0 = blockIdx.x;
+  if (tile0 >= a.tiles) return;
+  if (tid < 32) cs[tid] = tid < a.dt ? a.cols[tid] : 0;
+  const int WD = (a.dt + 3) >> 2;
+  const bool active = wave < WD;
+  const bool dim_ok = 4 * wave + g < a.dt;
+  const int grp = active ? wave : 0;
+  for (int i = tid; i < WD * 4 * PP; i += kGenThreads) bias_lds[i] = a.bias[i];
+  const f32x4* bw = reinterpret_cast<const f32x4*>(bias_lds + (grp * 4 + g) * PP);
+  const float w_un = a.wun[grp];
+  const f16x8* wsrc = a.wfrag + (size_t)grp * KS * T * 2 * 64 + lane;
+
+  const int xvec = R * D / 4;
+  float4 hv, xv0, xv1, gv0, gv1;
+  float glv = 0.f;
+  hv = xv0 = xv1 = gv0 = gv1 = float4{0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int64_t t) __attribute__((always_inline)) {
+    hv = reinterpret_cast<const float4*>(a.h + t * R * H)[tid];
+    const float4* xg = reinterpret_cast<const float4*>(a.x + t * R * D);
+    const float4* gg = reinterpret_cast<const float4*>(a.gy + t * R * D);
+    const int i0 = tid < xvec ? tid : 0, i1 = tid + kGenThreads < xvec ? tid + kGenThreads : 0;
+    xv0 = xg[i0]; xv1 = xg[i1];
+    gv0 = gg[i0]; gv1 = gg[i1];
+    if (tid < R) glv = a.gl ? a.gl[t * R + tid] : 0.f;
+  };
+  auto slot = [&](float* base, int buf, int i) __attribute__((always_inline)) {
+    if (!pad_x) return reinterpret_cast<float4*>(base + buf * R * (D + 4) + 4 * i);
+    const int e = i * 4, r = e / D, c = e - r * D;
+    return reinterpret_cast<float4*>(base + buf * R * (D + 4) + r * XS + c);
+  };
+  auto park = [&](int buf) __attribute__((always_inline)) {
+    {   // thread tid holds h[row tid / 16][4 (tid % 16) ..]: the 16 threads of a row are one DPP row
+      const int r = tid >> 4, c = (tid & 15) * 4;
+      const float v[4] = {hv.x, hv.y, hv.z, hv.w};
+      const float m = row16_allmax(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      float sc, un;
+      pow2_scale(m, sc, un);
+      f16x4 p0, p1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        _Float16 ph, pl;
+        split2(v[j] * sc, ph, pl);
+        p0[j] = ph;
+        p1[j] = pl;
+      }
+      _Float16* dst = hbuf + ((size_t)(buf * 2) * R + r) * HB + c;
+      *reinterpret_cast<f16x4*>(dst) = p0;
+      *reinterpret_cast<f16x4*>(dst + (size_t)R * HB) = p1;
+      if constexpr (kRole == 1) {   // the same scaled pieces, transposed: [hidden][sample]
+        _Float16* dt = htbuf + ((size_t)(buf * 2) * H + c) * TS + r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dt[(size_t)j * TS] = p0[j];
+          dt[((size_t)H + j) * TS] = p1[j];
+        }
+      }
+      if ((tid & 15) == 0) hscale[buf * R + r] = un;
+    }
+    if (tid < xvec) {
+      *slot(xbuf, buf, tid) = xv0;
+      *slot(gbuf, buf, tid) = gv0;
+    }
+    if (tid + kGenThreads < xvec) {
+      *slot(xbuf, buf, tid + kGenThreads) = xv1;
+      *slot(gbuf, buf, tid + kGenThreads) = gv1;
+    }
+    if (tid < R) glb[buf * R + tid] = glv;
+  };
+  auto hfrag = [&](int buf, int blk, int piece, int ks) __attribute__((always_inline)) {
+    return *reinterpret_cast<const f16x8*>(hbuf + ((size_t)(buf * 2 + piece) * R + 16 * blk + s16) * HB + 32 * ks + 8 * g);
+  };
+
+  // role 0: sums of G over this lane's samples (the bias gradient); role 1: the wave's slice of gW
+  float gbacc[kRole == 0 ? PP : 1];
+  f32x4 dw[kRole == 1 ? T : 1][4];
+  int dw_shift = 1000;        // role 1: the accumulators hold sum G' 2^dw_shift  (1000 = nothing accumulated yet)
+  if constexpr (kRole == 0) {
+#pragma unroll
+    for (int i = 0; i < PP; ++i) gbacc[i] = 0.f;
+  } else {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int ht = 0; ht < 4; ++ht) dw[t][ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  fetch(tile0);
+  park(0);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t tile = tile0; tile < a.tiles; tile += stride) {
+    const bool has_next = tile + stride < a.tiles;
+    if (has_next) fetch(tile + stride);
+    if (active) {
+      // ---- per 16-sample block: recompute its parameters (the forward kernel's product), spline backward -> G ------
+      float gp[kRole == 1 ? 2 : 1][PP8];
+#pragma unroll(kRole == 1 ? 2 : 1)
+      for (int b = 0; b < 2; ++b) {
+        __builtin_amdgcn_sched_barrier(0);     // the two blocks' register-hungry spline code must not interleave
+        f32x4 acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const f16x8 bh0 = hfrag(buf, b, 0, ks), bl0 = hfrag(buf, b, 1, ks);
+          const f16x8* wk = wsrc + (size_t)ks * T * 2 * 64;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const f16x8 ah = wk[(t * 2 + 0) * 64], al = wk[(t * 2 + 1) * 64];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, acc[t], 0, 0, 0);
+          }
+        }
+        float (&gpb)[PP8] = gp[kRole == 1 ? b : 0];
+        const int row = 16 * b + s16;
+        const int col = cs[(4 * wave + g) & 31];
+        const float xin = xbuf[buf * R * (D + 4) + row * XS + col];
+        float* gslot = gbuf + buf * R * (D + 4) + row * XS + col;
+        const float gyv = *gslot, glr = glb[buf * R + row];
+        const float c = hscale[buf * R + row] * w_un;
+        {
+          float p[PP];
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const f32x4 bt = bw[t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[4 * t + r] = __builtin_fmaf(acc[t][r], c, bt[r]);
+          }
+          float gxv, gpe[3 * K + 1];
+          rq_backward_element<K>(q, inv_div, K, P, p, xin, gyv, glr, gxv, gpe);
+#pragma unroll
+          for (int i = 0; i < PP8; ++i) gpb[i] = (i < P && dim_ok) ? gpe[i < P ? i : 0] : 0.f;
+          if constexpr (kRole == 0) {
+            if (dim_ok) *gslot = gxv;
+          }
+        }
+        if constexpr (kRole == 0) {
+#pragma unroll
+          for (int i = 0; i < PP; ++i) gbacc[i] += gpb[i];
+          // ---- gh^T partial of this wave: W^T (this wave's rows) x G, the lane's gradients as its own B operand -----
+          float m = 0.f;
+#pragma unroll
+          for (int i = 0; i < PP; ++i) m = fmaxf(m, fabsf(gpb[i]));
+          m = rows4_allmax(m, lane);
+          float sc, un;
+          pow2_scale(m, sc, un);
+          f16x8 bh[KK], bl[KK];
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              _Float16 ph, pl;
+              split2(gpb[8 * kk + j] * sc, ph, pl);
+              bh[kk][j] = ph;
+              bl[kk][j] = pl;
+            }
+          const float cc = un * w_un;
+          const f16x8* wt = a.wtfrag + (size_t)grp * 4 * KK * 2 * 64 + lane;
+#pragma unroll
+          for (int ht = 0; ht < 4; ++ht) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+              const f16x8 ah = wt[((size_t)(ht * KK + kk) * 2 + 0) * 64], al = wt[((size_t)(ht * KK + kk) * 2 + 1) * 64];
+              o = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[kk], o, 0, 0, 0);
+              o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[kk], o, 0, 0, 0);
+              o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[kk], o, 0, 0, 0);
+            }
+            // lane (sample s16, hidden 16 ht + 4 g + r)
+            *reinterpret_cast<float4*>(part + ((size_t)wave * R + 16 * b + s16) * (H + 4) + 16 * ht + 4 * g) =
+                float4{o[0] * cc, o[1] * cc, o[2] * cc, o[3] * cc};
+          }
+        }
+      }
+      if constexpr (kRole == 1) {
+        // ---- gW slice of this wave: (G 2^-T_s)^T x (h 2^T_s), contraction over the tile's 32 samples ---------------
+        float m = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float un_s = hscale[buf * R + 16 * b + s16];
+#pragma unroll
+          for (int i = 0; i < PP; ++i) {
+            gp[b][i] *= un_s;
+            m = fmaxf(m, fabsf(gp[b][i]));
+          }
+        }
+        m = wave64_allmax(m, lane);
+        // ideal shift of this tile (pow2_scale: lift m into [2^10, 2^11)); keep one running shift per wave
+        const uint32_t e = (__float_as_uint(m) >> 23) & 255u;
+        const int shift = (e >= 11u && e < 255u) ? 137 - (int)e : dw_shift;   // 2^(10 - floor(log2 m)); tiny tiles join in
+        if (shift < dw_shift) {
+          if (dw_shift != 1000) {
+            const float resc = __uint_as_float((uint32_t)(127 + shift - dw_shift) << 23);   // 2^(shift - dw_shift) <= 1
+            const bool under = shift - dw_shift < -126;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+              for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dw[t][ht][r] = under ? 0.f : dw[t][ht][r] * resc;
+          }
+          dw_shift = shift;
+        }
+        const float sc = dw_shift == 1000 ? 1.f : __uint_as_float((uint32_t)(127 + dw_shift) << 23);
+        _Float16* strip = strips + (size_t)wave * 2 * 16 * TS;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          // G^T tile t -> strip[piece][rho = 4 g + r][sample]: A operand rows are (dim g, param 4 t + r)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              _Float16 ph, pl;
+              split2(gp[b][4 * t + r] * sc, ph, pl);
+              strip[(size_t)(4 * g + r) * TS + 16 * b + s16] = ph;
+              strip[(size_t)(16 + 4 * g + r) * TS + 16 * b + s16] = pl;
+            }
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(strip + (size_t)s16 * TS + 8 * g);
+          const f16x8 al = *reinterpret_cast<const f16x8*>(strip + (size_t)(16 + s16) * TS + 8 * g);
+#pragma unroll
+          for (int ht = 0; ht < 4; ++ht) {
+            const _Float16* hb = htbuf + ((size_t)(buf * 2) * H + 16 * ht + s16) * TS + 8 * g;
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(hb);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(hb + (size_t)H * TS);
+            dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, dw[t][ht], 0, 0, 0);
+            dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, dw[t][ht], 0, 0, 0);
+            dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, dw[t][ht], 0, 0, 0);
+          }
+        }
+      }
+    }
+    if (has_next) park(buf ^ 1);
+    __syncthreads();
+    if constexpr (kRole == 0) {
+      // gx tile (gy with the transformed columns overwritten) and gh tile (the waves' partials in wave order)
+      float4* og = reinterpret_cast<float4*>(a.gx + tile * R * D);
+      if (tid < xvec) og[tid] = *slot(gbuf, buf, tid);
+      if (tid + kGenThreads < xvec) og[tid + kGenThreads] = *slot(gbuf, buf, tid + kGenThreads);
+      const int r = tid >> 4, c = (tid & 15) * 4;
+      float4 s = *reinterpret_cast<const float4*>(part + (size_t)r * (H + 4) + c);
+      for (int w = 1; w < WD; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)w * R + r) * (H + 4) + c);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      reinterpret_cast<float4*>(a.gh + tile * R * H)[tid] = s;
+      __syncthreads();      // `part` is rewritten by the next tile
+    }
+    buf ^= 1;
+  }
+  if (!active) return;
+  if constexpr (kRole == 0) {
+    // gb: sum over the 16 sample lanes of a row, one atomic per (dim, parameter) and workgroup
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+      const float v = row16_allsum(gbacc[i]);
+      if (s16 == 0 && i < P && dim_ok) atomicAdd(a.gb + (size_t)(grp * 4 + g) * PP + i, v);
+    }
+  } else {
+    // lane (hidden 16 ht + s16, feature rho = 4 g + r of tile t) = gW[(dim 4 grp + g), param 4 t + r][hidden]
+    if (dw_shift != 1000 && dim_ok) {
+      const float un = __uint_as_float((uint32_t)(127 - dw_shift) << 23);
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (4 * t + r < P)
+              atomicAdd(a.gw + ((size_t)(grp * 4 + g) * PP + 4 * t + r) * H + 16 * ht + s16, dw[t][ht][r] * un);
+    }
+  }
+}
+
+hipError_t launch_backward_tails(int K, int role, const RQParams& q, const BwdArgs& a, hipStream_t stream);
+hipError_t launch_backward_box(int K, int role, const RQParams& q, const BwdArgs& a, hipStream_t stream);
+
+template <int K, bool kTails, int kRole>
+hipError_t launch_backward_role(const RQParams& q, const BwdArgs& a, hipStream_t stream) {
+  const size_t lds = bwd_lds_bytes(a.D, kRole);
+  if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
+  static PerDeviceOnce attr;
+  const hipError_t ea = ensure_max_dynamic_lds(
+      attr, reinterpret_cast<const void*>(&rq_fused_backward_kernel<K, kTails, kRole>), 160 * 1024);
+  if (ea != hipSuccess) return ea;
+  const int64_t cus = device_cu_count();
+  const unsigned grid = (unsigned)(cus < a.tiles ? cus : a.tiles);
+  hipLaunchKernelGGL((rq_fused_backward_kernel<K, kTails, kRole>), dim3(grid), dim3(kGenThreads), lds, stream, q,
+                     1.f / q.wh_div, a);
+  return hipGetLastError();
+}
+
+template <int K, bool kTails>
+hipError_t launch_backward(int role, const RQParams& q, const BwdArgs& a, hipStream_t stream) {
+  if constexpr (GenShape<K, kTails>::T > 8) return hipErrorInvalidValue;
+  else
+    return role == 0 ? launch_backward_role<K, kTails, 0>(q, a, stream) : launch_backward_role<K, kTails, 1>(q, a, stream);
+}
+
+}  // namespace fc

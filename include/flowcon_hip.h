@@ -99,6 +99,21 @@ int fc_rq_spline_fused_general(const float* x, float* y, const float* h, const v
                                float* logabsdet, uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t,
                                int32_t hidden, const fc_rq_config* cfg, void* stream);
 
+/* Backward of the fused layer above (forward direction, hidden == 64): what torch.autograd yields for the reference's
+ * final Linear + spline (nn/nets/resnet.py:99 + rational_quadratic.py:13-181; the reference trains through them,
+ * examples/toy_2d.py:57-68) WITHOUT the [n, d_t P] parameter / parameter-gradient tensors: the parameters are recomputed
+ * on the matrix cores from the saved h, the closed-form spline backward runs on them in registers.
+ *   role 0: grad_x [n, d] (= grad_y on the other columns), grad_h [n, 64] = W^T G, grad_bias_pad [groups][4][4T] += sum_n G
+ *   role 1: grad_w_pad [groups][4][4T][64] += sum_n G (x) h          (both accumulate with atomics: zero them first)
+ * w_frag / w_unscale / bias_pad as for fc_rq_spline_fused_general with hidden == 64; wt_frag f16
+ * [groups][4 hidden tiles][KK][2][64][8], KK = ceil(4T / 8): fragment (hidden tile ht, k-step kk, piece): lane l holds
+ * 2^S W[dim 4 group + (l>>4)][param 8 kk + j][hidden 16 ht + (l&15)].  n % 32 == 0; cfg->inverse must be 0; 4T <= 32. */
+int fc_rq_fused_linear_backward(int32_t role, const float* x, const float* h, const float* grad_y,
+                                const float* grad_logabsdet, const void* w_frag, const float* w_unscale,
+                                const float* bias_pad, const void* wt_frag, const int32_t* cols, float* grad_x,
+                                float* grad_h, float* grad_bias_pad, float* grad_w_pad, int64_t n, int32_t d,
+                                int32_t d_t, const fc_rq_config* cfg, void* stream);
+
 /* Backward of fc_affine in the forward direction, per-sample parameters (coupling.py:234-252,
  * autoregressive.py:97-129 under torch.autograd): grad_x[n, cols[j]] = gy s; grad_params in the layout of
  * `params` for the same `activation`.  Other columns of grad_x are NOT written. */
