@@ -167,7 +167,9 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   // role 0: sums of G over this lane's samples (the bias gradient); role 1: the wave's slice of gW
   float gbacc[kRole == 0 ? PP : 1];
   f32x4 dw[kRole == 1 ? T : 1][4];
-  int dw_shift = 1000;        // role 1: the accumulators hold sum G' 2^dw_shift  (1000 = nothing accumulated yet)
+  int fshift[kRole == 1 ? PP : 1];     // role 1: per feature, the accumulators hold sum G' 2^fshift (1000 = nothing yet)
+#pragma unroll
+  for (int i = 0; i < (kRole == 1 ? PP : 1); ++i) fshift[i] = 1000;
   if constexpr (kRole == 0) {
 #pragma unroll
     for (int i = 0; i < PP; ++i) gbacc[i] = 0.f;
@@ -269,34 +271,33 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
       }
       if constexpr (kRole == 1) {
         // ---- gW slice of this wave: (G 2^-T_s)^T x (h 2^T_s), contraction over the tile's 32 samples ---------------
-        float m = 0.f;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const float un_s = hscale[buf * R + 16 * b + s16];
 #pragma unroll
-          for (int i = 0; i < PP; ++i) {
-            gp[b][i] *= un_s;
-            m = fmaxf(m, fabsf(gp[b][i]));
-          }
+          for (int i = 0; i < PP; ++i) gp[b][i] *= un_s;
         }
-        m = wave64_allmax(m, lane);
-        // ideal shift of this tile (pow2_scale: lift m into [2^10, 2^11)); keep one running shift per wave
-        const uint32_t e = (__float_as_uint(m) >> 23) & 255u;
-        const int shift = (e >= 11u && e < 255u) ? 137 - (int)e : dw_shift;   // 2^(10 - floor(log2 m)); tiny tiles join in
-        if (shift < dw_shift) {
-          if (dw_shift != 1000) {
-            const float resc = __uint_as_float((uint32_t)(127 + shift - dw_shift) << 23);   // 2^(shift - dw_shift) <= 1
-            const bool under = shift - dw_shift < -126;
+        // One power-of-two scale PER FEATURE (a row of the A operand; constant along the contraction over samples):
+        // the ideal shift of this tile's 32 values lifts their maximum into [2^10, 2^11).  The accumulators of a
+        // feature hold sum G' 2^fshift; when a tile needs a smaller shift they are rescaled (exact), tiny tiles join in.
 #pragma unroll
-            for (int t = 0; t < T; ++t)
+        for (int i = 0; i < PP; ++i) {
+          const float m = row16_allmax(fmaxf(fabsf(gp[0][i]), fabsf(gp[1][i])));
+          const uint32_t e = (__float_as_uint(m) >> 23) & 255u;
+          const int shift = (e >= 11u && e < 255u) ? 137 - (int)e : fshift[i];
+          if (shift < fshift[i]) {
+            if (fshift[i] != 1000) {
+              const int dlt = shift - fshift[i];
+              const float resc = dlt < -126 ? 0.f : __uint_as_float((uint32_t)(127 + dlt) << 23);
 #pragma unroll
-              for (int ht = 0; ht < 4; ++ht)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dw[t][ht][r] = under ? 0.f : dw[t][ht][r] * resc;
+              for (int ht = 0; ht < 4; ++ht) dw[i >> 2][ht][i & 3] *= resc;
+            }
+            fshift[i] = shift;
           }
-          dw_shift = shift;
+          const float sc = fshift[i] == 1000 ? 1.f : __uint_as_float((uint32_t)(127 + fshift[i]) << 23);
+          gp[0][i] *= sc;
+          gp[1][i] *= sc;
         }
-        const float sc = dw_shift == 1000 ? 1.f : __uint_as_float((uint32_t)(127 + dw_shift) << 23);
         _Float16* strip = strips + (size_t)wave * 2 * 16 * TS;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               _Float16 ph, pl;
-              split2(gp[b][4 * t + r] * sc, ph, pl);
+              split2(gp[b][4 * t + r], ph, pl);
               strip[(size_t)(4 * g + r) * TS + 16 * b + s16] = ph;
               strip[(size_t)(16 + 4 * g + r) * TS + 16 * b + s16] = pl;
             }
@@ -352,16 +353,17 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
     }
   } else {
     // lane (hidden 16 ht + s16, feature rho = 4 g + r of tile t) = gW[(dim 4 grp + g), param 4 t + r][hidden]
-    if (dw_shift != 1000 && dim_ok) {
-      const float un = __uint_as_float((uint32_t)(127 - dw_shift) << 23);
+    if (dim_ok) {
 #pragma unroll
       for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht)
+        for (int r = 0; r < 4; ++r)
+          if (4 * t + r < P && fshift[4 * t + r] != 1000) {
+            const float un = __uint_as_float((uint32_t)(127 - fshift[4 * t + r]) << 23);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (4 * t + r < P)
+            for (int ht = 0; ht < 4; ++ht)
               atomicAdd(a.gw + ((size_t)(grp * 4 + g) * PP + 4 * t + r) * H + 16 * ht + s16, dw[t][ht][r] * un);
+          }
     }
   }
 }

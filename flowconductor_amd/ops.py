@@ -665,6 +665,80 @@ def pack_final_layer_general(weight, bias, num_bins, tails, hidden_pad):
     return w_frag, unscale.float().contiguous(), b.reshape(groups, 4, pp).contiguous()
 
 
+def pack_final_layer_transposed(weight, num_bins, tails):
+    """W^T fragments of the final Linear for the backward product gh = W^T G (``fc_rq_fused_linear_backward`` role 0):
+    f16 [groups, 4 hidden tiles, KK, 2 (hi, lo), 64 lanes, 8], KK = ceil(4T / 8); lane l of fragment (group, ht, kk)
+    holds 2^S W[dim 4 group + (l >> 4)][param 8 kk + j][hidden 16 ht + (l & 15)] -- the k order in which a lane of the
+    kernel holds its own parameter gradients.  Same per-group scale as ``pack_final_layer_general``.  hidden <= 64."""
+    k = num_bins
+    p = 3 * k - 1 if tails == "linear" else 3 * k + 1
+    pp = -(-p // 4) * 4
+    pp8 = -(-pp // 8) * 8
+    kk = pp8 // 8
+    d_t = weight.shape[0] // p
+    groups = -(-d_t // 4)
+    hidden = weight.shape[1]
+    w = weight.new_zeros(groups * 4, pp8, 64, dtype=torch.float32)
+    w[:d_t, :p, :hidden] = weight.detach().reshape(d_t, p, hidden)
+    sc, _ = _pow2_scale(w.reshape(groups, -1).abs().amax(dim=1))
+    ws = w.reshape(groups, 4, pp8, 64) * sc.reshape(groups, 1, 1, 1)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.float()).to(torch.float16)
+
+    def frag(piece):
+        # [G, gk = dim 4, KK, j 8, HT 4, rho 16] -> [G, HT, KK, gk, rho, j] -> [G, HT, KK, 64 lanes, 8]
+        v = piece.reshape(groups, 4, kk, 8, 4, 16).permute(0, 4, 2, 1, 5, 3)
+        return v.reshape(groups, 4, kk, 64, 8)
+
+    return torch.stack((frag(hi), frag(lo)), dim=3).contiguous()
+
+
+def rq_fused_linear_backward(inputs, hidden, grad_outputs, grad_logabsdet, packed, packed_t, cols, *, num_bins, tails,
+                             tail_bound=1.0, left=0.0, right=1.0, bottom=0.0, top=1.0,
+                             min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
+                             min_derivative=DEFAULT_MIN_DERIVATIVE, wh_divisor=1.0, enable_identity_init=False):
+    """Gradients of ``rq_spline_fused_general(inputs, hidden, *packed, cols, ...)`` (forward direction, hidden width
+    64, rows a multiple of 32): returns ``(grad_inputs [N, D], grad_hidden [N, 64], grad_weight [d_t * P, 64],
+    grad_bias [d_t * P])`` for the <= 32 dims of ``cols`` -- two launches of ``fc_rq_fused_linear_backward``."""
+    lib = _hip.load()
+    x = _prep_2d(inputs.detach(), align16=True)
+    h = _aligned16(_hip.dev_f32(hidden.detach(), "hidden"))
+    gy = _aligned16(_hip.dev_f32(grad_outputs, "grad_outputs"))
+    gl = None if grad_logabsdet is None else _hip.dev_f32(grad_logabsdet, "grad_logabsdet")
+    n, d = x.shape
+    cols = _as_cols(cols, x.device)
+    d_t = cols.numel()
+    w_frag, w_un, bias_pad = packed
+    if n % FUSED_ROWS != 0 or h.shape != (n, 64) or not 1 <= d_t <= FUSED_DT:
+        raise ValueError("fused RQ layer backward: unsupported shapes %s / %s" % (tuple(x.shape), tuple(h.shape)))
+    cfg = _rq_config(num_bins, tails, tail_bound, (left, right, bottom, top), min_bin_width, min_bin_height,
+                     min_derivative, enable_identity_init, wh_divisor, False)
+    p = 3 * num_bins - 1 if tails == "linear" else 3 * num_bins + 1
+    pp = bias_pad.shape[-1]
+    groups = bias_pad.shape[0]
+    gx = torch.empty_like(x)
+    gh = torch.empty(n, 64, dtype=torch.float32, device=x.device)
+    gb = torch.zeros(groups, 4, pp, dtype=torch.float32, device=x.device)
+    gw = torch.zeros(groups, 4, pp, 64, dtype=torch.float32, device=x.device)
+    args = (_hip.ptr(x), _hip.ptr(h), _hip.ptr(gy), _hip.ptr(gl), _hip.ptr(w_frag), _hip.ptr(w_un),
+            _hip.ptr(bias_pad), _hip.ptr(packed_t), _hip.ptr(cols), _hip.ptr(gx), _hip.ptr(gh), _hip.ptr(gb),
+            _hip.ptr(gw), n, d, d_t, cfg, _hip.stream_ptr(x.device))
+    _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 0, *args)
+    _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 1, *args)
+    grad_w = gw.reshape(groups * 4, pp, 64)[:d_t, :p].reshape(d_t * p, 64)
+    grad_b = gb.reshape(groups * 4, pp)[:d_t, :p].reshape(d_t * p)
+    return gx, gh, grad_w, grad_b
+
+
+def fused_backward_supported(n, d, d_t, hidden, num_bins, tails):
+    """Shapes of the fused training path: hidden <= 64, 3K -/+ 1 <= 32 parameters per dim (K <= 10 / 11), <= 32 dims per
+    launch, D <= 128."""
+    if tails not in (None, "linear") or num_bins not in GENERAL_BINS or hidden > 64:
+        return False
+    p = 3 * num_bins - 1 if tails == "linear" else 3 * num_bins + 1
+    return p <= 32 and 1 <= d_t <= FUSED_DT and d <= 128 and n >= FUSED_ROWS
+
+
 def rq_spline_fused_general(inputs, hidden, w_frag, w_unscale, bias_pad, cols, *, num_bins, tails, tail_bound=1.0,
                             left=0.0, right=1.0, bottom=0.0, top=1.0, min_bin_width=DEFAULT_MIN_BIN_WIDTH,
                             min_bin_height=DEFAULT_MIN_BIN_HEIGHT, min_derivative=DEFAULT_MIN_DERIVATIVE,

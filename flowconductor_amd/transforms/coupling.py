@@ -329,8 +329,11 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
         """Per group of <= 32 transformed dims: the final Linear's rows of those dims in the kernel's layout + their
         column indices -- (w_pad, bias_pad, cols) for "k8", (w_frag, w_unscale, bias_pad, cols) for "general"."""
         lin = self.transform_net.final_layer
-        key = ops.cache_key(lin.weight, lin.bias, extra=(mode,))
-        if getattr(self, "_packed", None) is None or self._packed[0] != key:
+        key = ops.cache_key(lin.weight, lin.bias)
+        cache = getattr(self, "_packed", None)
+        if cache is None or cache[0] != key:
+            cache = self._packed = (key, {})
+        if mode not in cache[1]:
             per_dim = self._transform_dim_multiplier()
             cols = self._cols(device)
             hidden_pad = ops.general_hidden_width(lin.in_features)
@@ -340,21 +343,29 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
                 rows = slice(lo * per_dim, hi * per_dim)
                 if mode == "k8":
                     packed = ops.pack_final_layer(lin.weight[rows], lin.bias[rows], self.num_bins)
-                else:
+                elif mode == "general":
                     packed = ops.pack_final_layer_general(lin.weight[rows], lin.bias[rows], self.num_bins, self.tails,
                                                           hidden_pad)
+                else:   # "transposed": W^T fragments of the backward product gh = W^T G
+                    packed = (ops.pack_final_layer_transposed(lin.weight[rows], self.num_bins, self.tails), rows)
                 chunks.append(packed + (cols[lo:hi].contiguous(),))
-            self._packed = (key, chunks)
-        return self._packed[1]
+            cache[1][mode] = chunks
+        return cache[1][mode]
 
     def _apply_accumulate(self, inputs, context, inverse, total):
         """CompositeTransform fast path: the fused kernel adds this layer's logabsdet onto ``total`` itself."""
-        if self._fused_mode(inputs) is None or self.unconditional_transform is not None:
+        if (self._fused_mode(inputs) is None or self.unconditional_transform is not None
+                or self._fused_training_ok(inputs, context, inverse)):
             outputs, logabsdet = self._run(inputs, context, inverse)
             total += logabsdet
             return outputs
         outputs, _ = self._run(inputs, context, inverse, total=total)
         return outputs
+
+    def _fused_kw(self, net):
+        return dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
+                    min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
+                    wh_divisor=_softmax_divisor(net, warn=False))
 
     def _hidden_for_fused(self, inputs, identity_split, context, width):
         """[N, width] hidden activation of the conditioner (zero columns beyond ``hidden_features``): the hidden-layer
@@ -386,7 +397,28 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             identity_split = inputs[:, self.identity_features]
         return on_torch(identity_split, context)
 
+    def _fused_training_ok(self, inputs, context, inverse):
+        """Training through the HIP kernels (SURVEY 8f #3 with #4): conditioner forward in fc_resnet_hidden + the fused
+        final-layer kernel, backward in fc_rq_fused_linear_backward -- no [N, d_t P] tensor in either direction."""
+        net = self.transform_net
+        return (not inverse and context is None and self.unconditional_transform is None
+                and options.get("fused_training") and options.get("fused_final_layer") and options.get("fused_hidden")
+                and torch.is_grad_enabled() and _is_plain_resnet(net) and not ops.has_hooks(net)
+                and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and (inputs.requires_grad or any(p.requires_grad for p in net.parameters()))
+                and net.hip_hidden_supported(inputs.shape[1], None)
+                and ops.fused_backward_supported(inputs.shape[0], inputs.shape[1],
+                                                 min(self.num_transform_features, ops.FUSED_DT), net.hidden_features,
+                                                 self.num_bins, self.tails))
+
     def _run(self, inputs, context, inverse, total=None):
+        if self._fused_training_ok(inputs, context, inverse):
+            self._check(inputs)
+            outputs, logabsdet = _FusedRQCouplingFunction.apply(self, inputs, *self.transform_net.parameters())
+            if total is not None:
+                total += logabsdet
+                logabsdet = total
+            return outputs, logabsdet
         mode = self._fused_mode(inputs)
         if mode is None:
             return super()._run(inputs, context, inverse)
@@ -439,6 +471,75 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             outputs[:, self.identity_features] = identity_split
             logabsdet = logabsdet + logabsdet_identity
         return outputs, logabsdet
+
+
+class _FusedRQCouplingFunction(torch.autograd.Function):
+    """One RQ coupling layer with a ResidualNet(hidden <= 64) conditioner as ONE autograd node.
+
+    forward: hidden stack in ``fc_resnet_hidden``, final Linear + spline in ``fc_rq_spline_fused_general``; saves the
+    layer input and the [N, 64] hidden activation (512 B per sample) instead of the [N, d_t P] parameter tensor.
+    backward: ``fc_rq_fused_linear_backward`` (gx, gh, gW, gb of the final layer; parameters recomputed on the matrix
+    cores), then the hidden stack's gradients -- its forward is recomputed from the saved input columns."""
+
+    @staticmethod
+    def forward(ctx, layer, inputs, *net_params):
+        net = layer.transform_net
+        n = inputs.shape[0]
+        with torch.no_grad():
+            x = inputs.detach()
+            pad = (-n) % ops.FUSED_ROWS
+            if pad:       # whole 32-row tiles: zero rows (inside every spline's interval) that get zero upstream gradients
+                x = torch.cat((x, x.new_zeros(pad, x.shape[1])))
+            hidden = layer._hidden_for_fused(x, None, None, 64)
+            kw = layer._fused_kw(net)
+            rows, lad = x, None
+            for w_frag, w_un, bias_pad, cols in layer._fused_chunks(x.device, "general"):
+                rows, lad = ops.rq_spline_fused_general(rows, hidden, w_frag, w_un, bias_pad, cols, tails=layer.tails,
+                                                        logabsdet_accum=lad, inverse=False, **kw)
+        ctx.layer, ctx.n = layer, n
+        ctx.save_for_backward(x, hidden)
+        ctx.param_ids = [id(p) for p in net_params]
+        return rows[:n], lad[:n]
+
+    @staticmethod
+    def backward(ctx, grad_outputs, grad_logabsdet):
+        layer, n = ctx.layer, ctx.n
+        net = layer.transform_net
+        x, hidden = ctx.saved_tensors
+        rows_total = x.shape[0]
+        gy = torch.zeros_like(x) if grad_outputs is None else grad_outputs
+        gl = grad_logabsdet
+        if rows_total != n:
+            gy = torch.cat((gy, gy.new_zeros(rows_total - n, gy.shape[1])))
+            gl = None if gl is None else torch.cat((gl, gl.new_zeros(rows_total - n)))
+        kw = layer._fused_kw(net)
+        lin = net.final_layer
+        grad_w = torch.zeros_like(lin.weight)
+        grad_b = torch.zeros_like(lin.bias)
+        gh = None
+        g = gy.contiguous()
+        fwd_chunks = layer._fused_chunks(x.device, "general")
+        for (w_frag, w_un, bias_pad, cols), (wt_frag, rows_slice, _) in zip(fwd_chunks,
+                                                                           layer._fused_chunks(x.device, "transposed")):
+            # each group reads x at its own columns only (the others were not touched by it): the saved input serves all
+            g, gh_c, gw_c, gb_c = ops.rq_fused_linear_backward(x, hidden, g, gl, (w_frag, w_un, bias_pad), wt_frag, cols,
+                                                               tails=layer.tails, **kw)
+            gh = gh_c if gh is None else gh + gh_c
+            grad_w[rows_slice] = gw_c[:, :lin.in_features]
+            grad_b[rows_slice] = gb_c
+        # hidden stack: recompute its forward from the identity columns (PyTorch-ROCm ops) and pull gh through it
+        hidden_params = [p for p in net.parameters() if p is not lin.weight and p is not lin.bias]
+        with torch.enable_grad():
+            xid = x[:, layer.identity_features].detach().requires_grad_(True)
+            h2 = net.hidden(xid)
+            wanted = [xid] + [p for p in hidden_params if p.requires_grad]
+            got = torch.autograd.grad(h2, wanted, gh[:, :h2.shape[1]], allow_unused=True)
+        g[:, layer.identity_features] += got[0]
+        by_id = {id(lin.weight): grad_w, id(lin.bias): grad_b}
+        for p, gp_ in zip(wanted[1:], got[1:]):
+            by_id[id(p)] = gp_
+        grads = tuple(by_id.get(pid) for pid in ctx.param_ids)
+        return (None, g[:n]) + grads
 
 
 def _divisor_if_hidden_features(net):

@@ -82,7 +82,11 @@ def test_coupling_layer_trains_through_hip_path(device):
     y_ref, lad_ref = O.transform_apply(t_cpu, x.double())
     ((y_ref * gy.double()).sum() + (lad_ref * gl.double()).sum()).backward()
 
-    with ops.KernelTimer("fc_rq_spline_backward") as timer:
+    from flowconductor_amd import options
+
+    # (the fused training path, which this layer shape would take by default, has its own tests in
+    #  tests/test_gpu_fused_backward.py; here: conditioner on PyTorch autograd + the stand-alone spline backward kernel)
+    with options.override(fused_training=False), ops.KernelTimer("fc_rq_spline_backward") as timer:
         y, lad = t_gpu(x.to(device))
         ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
     assert len(timer.pairs) == 1, "the backward kernel did not run"

@@ -1,0 +1,140 @@
+"""Backward of the fused final-Linear + RQ-spline layer (fc_rq_fused_linear_backward) and the training path built on
+it, against torch.autograd on the oracle in float64 (the gradient-consistency oracle of the reference's
+tests/transforms/transform_test.py:29-37 is autograd itself)."""
+import copy
+
+import pytest
+import torch
+
+from _util import Lib, maxdiff
+from flowconductor_amd import ops, options
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+T, nets, utils, flows, distributions = Lib.transforms, Lib.nets, Lib.utils, Lib.flows, Lib.distributions
+
+
+def _relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("k,tails,d,d_t,n", [(8, "linear", 64, 32, 256), (10, "linear", 64, 32, 160), (10, None, 16, 8, 96),
+                                            (4, "linear", 12, 6, 64), (8, "linear", 63, 31, 96), (5, None, 10, 3, 32)])
+def test_fused_linear_backward_operator_vs_float64_autograd(k, tails, d, d_t, n, device):
+    torch.manual_seed(7 * k + d)
+    hidden = 64
+    p = 3 * k - 1 if tails == "linear" else 3 * k + 1
+    x = torch.rand(n, d) if tails is None else torch.randn(n, d) * 1.5
+    if tails == "linear" and n >= 8:
+        x[3], x[4] = 4.0, -3.5                                  # rows outside the tail interval: identity, no gradient
+    h = torch.relu(torch.randn(n, hidden)) * 1.5 + torch.randn(n, hidden) * 0.2
+    h *= torch.logspace(-2, 1, n).unsqueeze(1)
+    w = torch.randn(d_t * p, hidden) * (1.0 / hidden ** 0.5)
+    b = torch.randn(d_t * p) * 0.3
+    cols = torch.arange(0, 2 * d_t, 2, dtype=torch.int32)[:d_t]
+    gy = torch.randn(n, d)
+    gl = torch.randn(n)
+    kw = dict(wh_divisor=float(hidden) ** 0.5)
+    # float64 autograd reference
+    x64, h64, w64, b64 = (t.double().requires_grad_(True) for t in (x, h, w, b))
+    rows = (h64 @ w64.T + b64).view(n, d_t, p)
+    out, lad_e = O.rq_from_rows(x64[:, cols.long()], rows.clone(), k, tails, 3.0, False, **kw)
+    y64 = x64.clone()
+    y64 = y64.index_copy(1, cols.long(), out)
+    loss = (y64 * gy.double()).sum() + (lad_e.sum(dim=1) * gl.double()).sum()
+    gx_ref, gh_ref, gw_ref, gb_ref = torch.autograd.grad(loss, (x64, h64, w64, b64))
+    packed = ops.pack_final_layer_general(w.to(device), b.to(device), k, tails, 64)
+    packed_t = ops.pack_final_layer_transposed(w.to(device), k, tails)
+    gx, gh, gw, gb = ops.rq_fused_linear_backward(x.to(device), h.to(device), gy.to(device), gl.to(device), packed,
+                                                  packed_t, cols.to(device), num_bins=k, tails=tails, tail_bound=3.0,
+                                                  **kw)
+    # f32 arithmetic against a float64 reference: relative to the largest entry of each gradient
+    assert _relerr(gx, gx_ref) <= 2e-4
+    assert _relerr(gh, gh_ref) <= 2e-4
+    assert _relerr(gw, gw_ref) <= 2e-4
+    assert _relerr(gb, gb_ref) <= 2e-4
+    # the identity columns pass the upstream gradient through bit for bit
+    ident = [c for c in range(d) if c not in set(cols.tolist())]
+    assert torch.equal(gx[:, ident].cpu(), gy[:, ident])
+
+
+def _layer(d, hidden, k, tails, seed, blocks=2):
+    torch.manual_seed(seed)
+    t = T.PiecewiseRationalQuadraticCouplingTransform(
+        utils.create_alternating_binary_mask(d, even=True),
+        lambda i, o: nets.ResidualNet(i, o, hidden_features=hidden, num_blocks=blocks),
+        num_bins=k, tails=tails, tail_bound=3.0)
+    with torch.no_grad():
+        lin = t.transform_net.final_layer
+        lin.weight.copy_(torch.randn(lin.weight.shape) * (1.0 / hidden ** 0.5))
+        lin.bias.copy_(torch.randn(lin.bias.shape) * 0.3)
+        for p in t.transform_net.blocks.parameters():
+            p.mul_(1.5)
+    return t
+
+
+@pytest.mark.parametrize("d,hidden,k,tails,n", [(64, 64, 8, "linear", 256), (64, 64, 10, "linear", 200),
+                                                (16, 32, 10, None, 77), (128, 64, 8, "linear", 96),
+                                                (10, 20, 5, "linear", 33)])
+def test_coupling_layer_trains_through_fused_kernels(d, hidden, k, tails, n, device):
+    """Parameter and input gradients of one RQ coupling layer on the fused training path (forward: fc_resnet_hidden +
+    fc_rq_spline_fused_general; backward: fc_rq_fused_linear_backward twice per 32 transformed dims) against float64
+    autograd on the oracle.  Batches that are not whole 32-row tiles, D = 128 (two groups of 32 dims), narrow nets."""
+    t_cpu = _layer(d, hidden, k, tails, seed=d + k)
+    t_gpu = copy.deepcopy(t_cpu).to(device).train()
+    t_cpu = t_cpu.double().train()
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(n, d, generator=gen) if tails is None else torch.randn(n, d, generator=gen) * 1.5
+    gy = torch.randn(n, d, generator=gen)
+    gl = torch.randn(n, generator=gen)
+    x64 = x.double().requires_grad_(True)
+    y_ref, lad_ref = O.transform_apply(t_cpu, x64)
+    ((y_ref * gy.double()).sum() + (lad_ref * gl.double()).sum()).backward()
+
+    xd = x.to(device).requires_grad_(True)
+    groups = -(-t_gpu.num_transform_features // 32)
+    with ops.KernelTimer("fc_rq_fused_linear_backward") as tb, ops.KernelTimer("fc_rq_spline_fused_general") as tf, \
+            ops.KernelTimer("fc_rq_spline_backward") as told:
+        y, lad = t_gpu(xd)
+        ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
+    assert len(tb.pairs) == 2 * groups and len(tf.pairs) == groups and not told.pairs
+    assert maxdiff(y.detach(), y_ref.detach()) <= 2e-5 * max(1.0, float(y_ref.detach().abs().max()))
+    assert maxdiff(lad.detach(), lad_ref.detach()) <= 3e-4
+    assert _relerr(xd.grad, x64.grad) <= 2e-4
+    for (name, p_ref), (_, p) in zip(t_cpu.named_parameters(), t_gpu.named_parameters()):
+        assert p.grad is not None, name
+        assert _relerr(p.grad, p_ref.grad) <= 3e-4, name
+
+
+def test_flow_trains_on_the_fused_path_like_the_unfused_one(device):
+    """-log_prob(x).mean().backward() through a 6-layer flow (reference default K = 10): fused training path vs the
+    conditioner-on-PyTorch path, same weights: the same loss and the same gradients to rounding; an Adam step lowers the
+    loss (examples/toy_2d.py:57-68)."""
+    torch.manual_seed(0)
+    d = 16
+    layers = [T.PiecewiseRationalQuadraticCouplingTransform(
+        utils.create_alternating_binary_mask(d, even=(i % 2 == 0)),
+        lambda a, b: nets.ResidualNet(a, b, hidden_features=64, num_blocks=2), num_bins=10, tails="linear",
+        tail_bound=3.0) for i in range(6)]
+    flow = flows.Flow(T.CompositeTransform(layers), distributions.StandardNormal([d])).to(device).train()
+    x = (torch.randn(1000, d) * 0.6 + 0.4).to(device)
+    loss_f = -flow.log_prob(x).mean()
+    loss_f.backward()
+    grads_f = [p.grad.clone() for p in flow.parameters()]
+    flow.zero_grad()
+    with options.override(fused_training=False):
+        loss_u = -flow.log_prob(x).mean()
+        loss_u.backward()
+    assert abs(float(loss_f.detach()) - float(loss_u.detach())) <= 1e-5 * max(1.0, abs(float(loss_u.detach())))
+    for gf, p in zip(grads_f, flow.parameters()):
+        assert _relerr(gf, p.grad) <= 5e-4
+    opt = torch.optim.Adam(flow.parameters(), lr=2e-3)
+    losses = []
+    for _ in range(8):
+        opt.zero_grad()
+        loss = -flow.log_prob(x).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0] and all(l == l for l in losses)

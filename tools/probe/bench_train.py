@@ -1,6 +1,11 @@
-"""Training step of the cfg-3 flow (32 x RQ coupling, D = 64, K = 8): -log_prob.mean().backward() + Adam step through
-the HIP forward / backward bijector kernels with the conditioners on PyTorch autograd.
-python tools/probe/bench_train.py [log2 rows]"""
+"""Training step of the cfg-3 flow (32 x RQ coupling, D = 64, K = 8): -log_prob.mean().backward() + Adam step.
+
+Two paths, same flow, same data, interleaved in one process:
+  fused    forward in fc_resnet_hidden + fc_rq_spline_fused_general, backward in fc_rq_fused_linear_backward (+ the hidden
+           stack's backward): no [N, 736] parameter / gradient tensor in either direction
+  unfused  conditioners on PyTorch autograd (library GEMMs), bijector forward / backward in fc_rq_spline(_backward)
+python tools/probe/bench_train.py [log2 rows] [--json]"""
+import json
 import os
 import sys
 import time
@@ -8,12 +13,16 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from flowconductor_amd import distributions, flows, ops, transforms, utils  # noqa: E402
+from flowconductor_amd import distributions, flows, ops, options, transforms, utils  # noqa: E402
 from flowconductor_amd.nn import nets  # noqa: E402
+
+KERNELS = ("fc_rq_spline", "fc_rq_spline_backward", "fc_rq_spline_fused_general", "fc_rq_fused_linear_backward",
+           "fc_resnet_hidden", "fc_resnet_hidden_backward")
 
 
 def main():
-    n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 17)
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = 1 << (int(args[0]) if args else 17)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     layers = [transforms.PiecewiseRationalQuadraticCouplingTransform(
@@ -31,23 +40,40 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    timers = [ops.KernelTimer(k) for k in ("fc_rq_spline", "fc_rq_spline_backward")]
-    t0 = time.perf_counter()
-    reps = 3
-    with timers[0], timers[1]:
-        for _ in range(reps):
-            loss = step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / reps * 1e3
-    f = timers[0].durations_ms()
-    b = timers[1].durations_ms()
-    print(f"train step N={n}: {ms:.1f} ms ({n / ms / 1e3:.2f} M samples/s), loss {float(loss):.3f}; "
-          f"fc_rq_spline {sum(f) / reps:.1f} ms/step in {len(f) // reps} launches, "
-          f"fc_rq_spline_backward {sum(b) / reps:.1f} ms/step in {len(b) // reps} launches; "
-          f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    res = {}
+    for mode in ("fused", "unfused", "fused", "unfused"):
+        with options.override(fused_training=(mode == "fused")):
+            torch.cuda.reset_peak_memory_stats()
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            timers = [ops.KernelTimer(k) for k in KERNELS]
+            for t in timers:
+                t.__enter__()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                loss = step()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            for t in reversed(timers):
+                t.__exit__(None, None, None)
+        rec = {"ms_per_step": ms, "samples_per_s": n / ms * 1e3, "loss": float(loss),
+               "peak_GiB": torch.cuda.max_memory_allocated() / 2 ** 30,
+               "kernels_ms_per_step": {t.name: [round(sum(t.durations_ms()) / reps, 3), len(t.pairs) // reps]
+                                       for t in timers if t.pairs}}
+        if mode not in res or ms < res[mode]["ms_per_step"]:
+            res[mode] = rec
+    res["speedup"] = res["unfused"]["ms_per_step"] / res["fused"]["ms_per_step"]
+    res["rows"] = n
+    if "--json" in sys.argv:
+        print(json.dumps(res))
+        return
+    for mode in ("fused", "unfused"):
+        r = res[mode]
+        print(f"train step N={n} [{mode}]: {r['ms_per_step']:.1f} ms ({r['samples_per_s'] / 1e6:.2f} M samples/s), loss "
+              f"{r['loss']:.3f}, peak {r['peak_GiB']:.1f} GiB; kernels (ms/step, launches): {r['kernels_ms_per_step']}")
+    print(f"fused / unfused: x{res['speedup']:.2f}")
 
 
 if __name__ == "__main__":
