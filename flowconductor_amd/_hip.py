@@ -68,6 +68,15 @@ class SplineConfig(ctypes.Structure):
     ]
 
 
+class PackJob(ctypes.Structure):
+    """Mirror of ``fc_pack_job``."""
+
+    _fields_ = [("w", ctypes.c_void_p), ("b", ctypes.c_void_p), ("frag", ctypes.c_void_p), ("unscale", ctypes.c_void_p),
+                ("bias_out", ctypes.c_void_p), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("mode", ctypes.c_int32), ("p", ctypes.c_int32), ("pp", ctypes.c_int32), ("nks", ctypes.c_int32),
+                ("nt", ctypes.c_int32), ("group", ctypes.c_int32)]
+
+
 _P = ctypes.c_void_p
 _I32 = ctypes.c_int32
 _I64 = ctypes.c_int64
@@ -99,6 +108,7 @@ SIGNATURES = {
     "fc_rq_fused_linear_backward": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32,
                                     ctypes.POINTER(RQConfig), _P],
     "fc_resnet_hidden": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, ctypes.c_float, _P],
+    "fc_resnet_hidden_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P],
     "fc_resnet_hidden_wide": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, ctypes.c_float, _P],
     "fc_resnet_hidden_context": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _I32,
                                  _I32, ctypes.c_float, _P],
@@ -106,6 +116,8 @@ SIGNATURES = {
     "fc_dense_mm": [_P, _P, _P, _P, _I64, _I32, _P],
     "fc_sylvester_mm": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
     "fc_affine_backward": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
+    "fc_pack_fragments": [_P, _I32, _P],
+    "fc_pack_job_bytes": [],
     "fc_comm_unique_id": [_P],
     "fc_comm_init_rank": [ctypes.POINTER(ctypes.c_void_p), _I32, _P, _I32],
     "fc_comm_destroy": [_P],

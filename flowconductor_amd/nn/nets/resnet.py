@@ -176,6 +176,36 @@ class ResidualNet(nn.Module):
         return ops.resnet_hidden_wide(rows, id_cols, self._hip_packed_wide[1], self.initial_layer.in_features,
                                       len(self.blocks), width, act)
 
+    def hip_hidden_backward_supported(self):
+        """True when ``fc_resnet_hidden_backward`` covers this net: hidden <= 64, <= 2 blocks, ReLU, no context, no batch
+        norm, dropout inactive."""
+        from flowconductor_amd import ops
+
+        if self.hidden_features > 64 or len(self.blocks) > 2 or self.context_features is not None:
+            return False
+        if self.initial_layer.in_features > 64:
+            return False
+        for block in self.blocks:
+            code = ops.activation_code(block.activation)
+            if block.use_batch_norm or code is None or code[0] != ops.ACT_RELU or (block.dropout.p > 0 and self.training):
+                return False
+        return True
+
+    def hidden_backward_packed(self):
+        from flowconductor_amd import ops
+
+        # persistent device-side pack plan (one launch per refresh); rebuilt when the parameter storages moved
+        w0 = self.initial_layer.weight
+        plan = getattr(self, "_hip_packed_bwd", None)
+        if plan is None or plan[0] != (w0.data_ptr(), w0.device):
+            pack, packed = ops.device_pack_resnet_hidden_backward(self)
+            plan = self._hip_packed_bwd = [(w0.data_ptr(), w0.device), pack, packed, None]
+        key = ops.cache_key(*self.parameters())
+        if plan[3] != key:
+            plan[1].run()
+            plan[3] = key
+        return plan[2]
+
     def hidden_padded(self, inputs, context=None):
         """``hidden`` on PyTorch, zero-padded to the kernel's 64 columns (leftover rows next to ``hidden_hip``)."""
         h = self.hidden(inputs, context)

@@ -5,6 +5,7 @@ outputs with torch, pass raw device pointers + the current HIP stream through th
 turn the device error word into the reference's Python exceptions.
 """
 import contextlib
+import ctypes
 import math
 import threading
 
@@ -453,12 +454,18 @@ CONTEXT_GLU, CONTEXT_ADDITIVE = 1, 2
 WIDE_ROWS = 64
 
 
+def _exact_pow2(shift):
+    """2^shift as float32, built from the exponent bits (``torch.ldexp`` goes through ``pow`` and is not exact on every
+    backend)."""
+    return ((shift.to(torch.int32) + 127) << 23).view(torch.float32)
+
+
 def _pow2_scale(m):
-    """fc_split.h pow2_scale on a tensor of maxima: (scale, unscale) lifting each into [2^10, 2^11)."""
+    """fc_split.h pow2_scale on a tensor of maxima: (scale, unscale), exact powers of two lifting each into [2^10, 2^11)."""
     _, exp = torch.frexp(m)                                   # m = mant * 2^exp, mant in [0.5, 1)
     ok = (m > 0) & torch.isfinite(m) & (exp >= -115)
     shift = torch.where(ok, 11 - exp, torch.zeros_like(exp))
-    return torch.ldexp(torch.ones_like(m), shift), torch.ldexp(torch.ones_like(m), -shift)
+    return _exact_pow2(shift), _exact_pow2(-shift)
 
 
 def _a_fragments(w):
@@ -489,6 +496,156 @@ def pack_resnet_hidden_wide(net, width):
         uns.append(un)
         biases.append(_pad_to(lin.bias.detach().float(), (width,)))
     return torch.cat(frags).contiguous(), torch.cat(uns).float().contiguous(), torch.stack(biases).contiguous()
+
+
+HIDDEN_BWD_ROWS = 128
+
+PACK_FINAL, PACK_FINAL_T, PACK_HIDDEN, PACK_HIDDEN_T, PACK_HIDDEN_T0 = range(5)
+
+
+class DevicePack:
+    """A set of ``fc_pack_job``s with persistent output buffers: ``run()`` re-packs all of them in ONE launch (training
+    re-packs every optimizer step; with tensor ops that is ~100 tiny launches per coupling layer).  The source pointers
+    are the parameters' storages, which optimizers update in place."""
+
+    def __init__(self, device):
+        self.device = device
+        self.jobs = []
+        self.keep = []            # tensors the jobs point into
+        self._jobs_dev = None
+
+    def add(self, mode, weight, bias, frag, unscale, bias_out=None, p=0, pp=0, nks=0, nt=0, group=0):
+        if not weight.is_contiguous() or weight.dtype != torch.float32:
+            raise ValueError("DevicePack sources must be contiguous float32 tensors")
+        job = _hip.PackJob()
+        job.w, job.b = weight.data_ptr(), (0 if bias is None else bias.data_ptr())
+        job.frag, job.unscale = frag.data_ptr(), unscale.data_ptr()
+        job.bias_out = 0 if bias_out is None else bias_out.data_ptr()
+        job.rows, job.cols = weight.shape
+        job.mode, job.p, job.pp, job.nks, job.nt, job.group = mode, p, pp, nks, nt, group
+        self.jobs.append(job)
+        self.keep += [weight, bias, frag, unscale, bias_out]
+
+    def run(self):
+        lib = _hip.load()
+        if self._jobs_dev is None:
+            if lib.fc_pack_job_bytes() != ctypes.sizeof(_hip.PackJob):
+                raise RuntimeError("fc_pack_job layout mismatch between the header and the ctypes mirror")
+            raw = b"".join(bytes(j) for j in self.jobs)
+            self._jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        _call("fc_pack_fragments", lib.fc_pack_fragments, self.device, _hip.ptr(self._jobs_dev), len(self.jobs),
+              _hip.stream_ptr(self.device))
+
+
+def device_pack_final_layer(weight, bias, num_bins, tails, cols_chunks):
+    """Forward and W^T fragments of the final Linear (hidden <= 64) for every group of <= 32 transformed dims, packed on
+    the device.  ``cols_chunks``: [(row slice of the weight, cols tensor)].  Returns ``(pack, chunks)`` with chunks =
+    [(w_frag, w_unscale, bias_pad, wt_frag, cols, row slice)]; call ``pack.run()`` whenever the weights changed."""
+    k = num_bins
+    p = 3 * k - 1 if tails == "linear" else 3 * k + 1
+    pp = -(-p // 4) * 4
+    t = pp // 4
+    kk = -(-pp // 8)
+    dev = weight.device
+    pack = DevicePack(dev)
+    chunks = []
+    for rows, cols in cols_chunks:
+        w, b = weight[rows], bias[rows]
+        d_t = w.shape[0] // p
+        groups = -(-d_t // 4)
+        w_frag = torch.empty(groups, 2, t, 2, 64, 8, dtype=torch.float16, device=dev)
+        wt_frag = torch.empty(groups, 4, kk, 2, 64, 8, dtype=torch.float16, device=dev)
+        w_un = torch.empty(groups, dtype=torch.float32, device=dev)
+        wt_un = torch.empty(groups, dtype=torch.float32, device=dev)       # (equal to w_un: the same group maximum)
+        bias_pad = torch.empty(groups, 4, pp, dtype=torch.float32, device=dev)
+        for g in range(groups):
+            pack.add(PACK_FINAL, w, b, w_frag[g], w_un[g:g + 1], bias_pad[g], p=p, pp=pp, nks=2, nt=t, group=g)
+            pack.add(PACK_FINAL_T, w, None, wt_frag[g], wt_un[g:g + 1], None, p=p, pp=pp, nks=kk, nt=4, group=g)
+        chunks.append((w_frag, w_un, bias_pad, wt_frag, cols, rows))
+    return pack, chunks
+
+
+def device_pack_resnet_hidden_backward(net):
+    """``pack_resnet_hidden_backward`` on the device: returns ``(pack, packed)``; ``pack.run()`` refreshes ``packed``."""
+    dev = net.initial_layer.weight.device
+    k0 = net.initial_layer.in_features
+    k0s = 1 if k0 <= 32 else 2
+    layers = [net.initial_layer] + [lin for block in net.blocks for lin in block.linear_layers]
+    n_layers = len(layers)
+    frag0, frag_l = k0s * 4 * 2 * 64 * 8, 2 * 4 * 2 * 64 * 8
+    w_frag = torch.empty(frag0 + (n_layers - 1) * frag_l, dtype=torch.float16, device=dev)
+    wt_frag = torch.empty((n_layers - 1) * frag_l + 2 * (2 * k0s) * 2 * 64 * 8, dtype=torch.float16, device=dev)
+    w_un = torch.empty(n_layers, dtype=torch.float32, device=dev)
+    wt_un = torch.empty(n_layers, dtype=torch.float32, device=dev)
+    bias_acc = torch.empty(n_layers, 64, dtype=torch.float32, device=dev)
+    pack = DevicePack(dev)
+    off = 0
+    for i, lin in enumerate(layers):
+        size = frag0 if i == 0 else frag_l
+        pack.add(PACK_HIDDEN, lin.weight, lin.bias, w_frag[off:off + size], w_un[i:i + 1], bias_acc[i],
+                 nks=k0s if i == 0 else 2, nt=4)
+        off += size
+    for i, lin in enumerate(layers[1:]):
+        pack.add(PACK_HIDDEN_T, lin.weight, None, wt_frag[i * frag_l:(i + 1) * frag_l], wt_un[i + 1:i + 2], None, nks=2, nt=4)
+    pack.add(PACK_HIDDEN_T0, layers[0].weight, None, wt_frag[(n_layers - 1) * frag_l:], wt_un[0:1], None, nks=2, nt=2 * k0s)
+    return pack, (w_frag, wt_frag, w_un, bias_acc, k0s)
+
+
+def _hb_perm():
+    """Feature held by accumulator tile t, row rho of the hidden-layer kernels: 32 (t >> 1) + 8 g + 4 (t & 1) + r with
+    g = rho >> 2, r = rho & 3 (the order in which the C layout of one layer is the B operand of the next)."""
+    return torch.tensor([32 * (t >> 1) + 8 * (rho >> 2) + 4 * (t & 1) + (rho & 3) for t in range(4) for rho in range(16)])
+
+
+def pack_resnet_hidden_backward(net):
+    """Everything ``fc_resnet_hidden_backward`` needs of a ResidualNet with hidden <= 64, <= 2 ReLU blocks, no context:
+    forward fragments (rows in accumulator order), fragments of the transposed weights for the W^T products, one
+    power-of-two scale per layer shared by both, biases in accumulator order.  Returns
+    ``(w_frag, wt_frag, w_unscale [L], bias_acc [L, 64], k0s)``."""
+    hw = 64
+    perm = _hb_perm().to(net.initial_layer.weight.device)
+    k0 = net.initial_layer.in_features
+    k0s = 1 if k0 <= 32 else 2
+    layers = [net.initial_layer] + [lin for block in net.blocks for lin in block.linear_layers]
+    wf, wt, uns, biases = [], [], [], []
+    scaled = []
+    for i, lin in enumerate(layers):
+        w = _pad_to(lin.weight.detach().float(), (hw, 32 * k0s if i == 0 else hw))
+        sc, un = _pow2_scale(w.abs().amax().reshape(1))
+        scaled.append(w * sc)
+        uns.append(un)
+        wf.append(_a_fragments(scaled[-1][perm]).permute(1, 0, 2, 3, 4).reshape(-1))         # [ks][t][piece][lane][8]
+        biases.append(_pad_to(lin.bias.detach().float(), (hw,))[perm].reshape(4, 4, 4).permute(1, 0, 2).reshape(-1))
+    for w in scaled[1:]:
+        wt.append(_a_fragments(w.t().contiguous()[perm]).permute(1, 0, 2, 3, 4).reshape(-1))
+    wt.append(_a_fragments(scaled[0].t().contiguous()).permute(1, 0, 2, 3, 4).reshape(-1))     # W0^T: rows natural
+    return (torch.cat(wf).contiguous(), torch.cat(wt).contiguous(), torch.cat(uns).float().contiguous(),
+            torch.stack(biases).contiguous(), k0s)
+
+
+def resnet_hidden_backward(inputs, grad_hidden, id_cols, packed, in_features, num_blocks):
+    """Backward of ``resnet_hidden`` (hidden 64, <= 2 ReLU blocks, no context; rows a multiple of 128): returns
+    ``(grad_x_id [N, in_features], grad_w0 [64, in_features], grad_wb [2 blocks, 64, 64], grad_b [L, 64])`` with the
+    activations recomputed from ``inputs``."""
+    lib = _hip.load()
+    x = _prep_2d(inputs.detach())
+    gh = _aligned16(_hip.dev_f32(grad_hidden, "grad_hidden"))
+    n, d = x.shape
+    if n % HIDDEN_BWD_ROWS != 0 or gh.shape != (n, 64) or not 0 <= num_blocks <= 2:
+        raise ValueError("fc_resnet_hidden_backward: unsupported shapes")
+    w_frag, wt_frag, w_un, bias_acc, k0s = packed
+    ids = _as_cols(id_cols, x.device)
+    layers = 1 + 2 * num_blocks
+    gxid = torch.empty(n, 32 * k0s, dtype=torch.float32, device=x.device)
+    nb2 = max(1, 2 * num_blocks)
+    acc = torch.zeros(64 * 32 * k0s + nb2 * 4096 + layers * 64, dtype=torch.float32, device=x.device)   # one memset
+    gw0 = acc[:64 * 32 * k0s].view(64, 32 * k0s)
+    gwb = acc[64 * 32 * k0s:64 * 32 * k0s + nb2 * 4096].view(nb2, 64, 64)
+    gb = acc[64 * 32 * k0s + nb2 * 4096:].view(layers, 64)
+    _call("fc_resnet_hidden_backward", lib.fc_resnet_hidden_backward, x.device, _hip.ptr(x), _hip.ptr(gh), _hip.ptr(ids),
+          _hip.ptr(w_frag), _hip.ptr(wt_frag), _hip.ptr(w_un), _hip.ptr(bias_acc), _hip.ptr(gxid), _hip.ptr(gw0),
+          _hip.ptr(gwb), _hip.ptr(gb), n, d, in_features, 64, num_blocks, ACT_RELU, _hip.stream_ptr(x.device))
+    return gxid[:, :in_features], gw0[:, :in_features], gwb, gb
 
 
 def resnet_hidden_wide(inputs, id_cols, packed, in_features, num_blocks, width, activation=(ACT_RELU, 0.0)):
@@ -645,13 +802,7 @@ def pack_final_layer_general(weight, bias, num_bins, tails, hidden_pad):
     w[:d_t, :p, :hidden] = weight.detach().reshape(d_t, p, hidden)
     b = bias.new_zeros(groups * 4, pp, dtype=torch.float32)
     b[:d_t, :p] = bias.detach().reshape(d_t, p)
-    # pow2_scale of fc_split.h on the group maximum: lift it into [2^10, 2^11)
-    m = w.reshape(groups, -1).abs().amax(dim=1)
-    _, exp = torch.frexp(m)                                   # m = mant * 2^exp, mant in [0.5, 1)
-    ok = (m > 0) & torch.isfinite(m) & (exp >= -115)
-    shift = torch.where(ok, 11 - exp, torch.zeros_like(exp))
-    scale = torch.ldexp(torch.ones_like(m), shift)
-    unscale = torch.ldexp(torch.ones_like(m), -shift)
+    scale, unscale = _pow2_scale(w.reshape(groups, -1).abs().amax(dim=1))
     ws = w.reshape(groups, 4, pp, hidden_pad) * scale.reshape(groups, 1, 1, 1)
     hi = ws.to(torch.float16)
     lo = (ws - hi.float()).to(torch.float16)
@@ -718,8 +869,9 @@ def rq_fused_linear_backward(inputs, hidden, grad_outputs, grad_logabsdet, packe
     groups = bias_pad.shape[0]
     gx = torch.empty_like(x)
     gh = torch.empty(n, 64, dtype=torch.float32, device=x.device)
-    gb = torch.zeros(groups, 4, pp, dtype=torch.float32, device=x.device)
-    gw = torch.zeros(groups, 4, pp, 64, dtype=torch.float32, device=x.device)
+    acc = torch.zeros(groups * 4 * pp * 65, dtype=torch.float32, device=x.device)      # one memset for both accumulators
+    gb = acc[:groups * 4 * pp].view(groups, 4, pp)
+    gw = acc[groups * 4 * pp:].view(groups, 4, pp, 64)
     args = (_hip.ptr(x), _hip.ptr(h), _hip.ptr(gy), _hip.ptr(gl), _hip.ptr(w_frag), _hip.ptr(w_un),
             _hip.ptr(bias_pad), _hip.ptr(packed_t), _hip.ptr(cols), _hip.ptr(gx), _hip.ptr(gh), _hip.ptr(gb),
             _hip.ptr(gw), n, d, d_t, cfg, _hip.stream_ptr(x.device))

@@ -352,6 +352,27 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
             cache[1][mode] = chunks
         return cache[1][mode]
 
+    def _train_chunks(self, device):
+        """Training: forward + W^T fragments of the final Linear for every group of <= 32 dims, re-packed on the device
+        in one launch whenever the weights changed -- [(w_frag, w_unscale, bias_pad, wt_frag, cols, row slice)]."""
+        lin = self.transform_net.final_layer
+        plan = getattr(self, "_train_pack", None)
+        if plan is None or plan[0] is not lin.weight or plan[0].device != device or plan[1] != lin.weight.data_ptr():
+            per_dim = self._transform_dim_multiplier()
+            cols = self._cols(device)
+            spec = []
+            for lo in range(0, self.num_transform_features, ops.FUSED_DT):
+                hi = min(lo + ops.FUSED_DT, self.num_transform_features)
+                spec.append((slice(lo * per_dim, hi * per_dim), cols[lo:hi].contiguous()))
+            pack, chunks = ops.device_pack_final_layer(lin.weight.detach(), lin.bias.detach(), self.num_bins, self.tails,
+                                                       spec)
+            plan = self._train_pack = [lin.weight, lin.weight.data_ptr(), pack, chunks, None]
+        key = ops.cache_key(lin.weight, lin.bias)
+        if plan[4] != key:
+            plan[2].run()
+            plan[4] = key
+        return plan[3]
+
     def _apply_accumulate(self, inputs, context, inverse, total):
         """CompositeTransform fast path: the fused kernel adds this layer's logabsdet onto ``total`` itself."""
         if (self._fused_mode(inputs) is None or self.unconditional_transform is not None
@@ -487,13 +508,13 @@ class _FusedRQCouplingFunction(torch.autograd.Function):
         n = inputs.shape[0]
         with torch.no_grad():
             x = inputs.detach()
-            pad = (-n) % ops.FUSED_ROWS
-            if pad:       # whole 32-row tiles: zero rows (inside every spline's interval) that get zero upstream gradients
+            pad = (-n) % ops.HIDDEN_BWD_ROWS
+            if pad:       # whole 128-row rounds: zero rows (inside every spline's interval) that get zero upstream gradients
                 x = torch.cat((x, x.new_zeros(pad, x.shape[1])))
             hidden = layer._hidden_for_fused(x, None, None, 64)
             kw = layer._fused_kw(net)
             rows, lad = x, None
-            for w_frag, w_un, bias_pad, cols in layer._fused_chunks(x.device, "general"):
+            for w_frag, w_un, bias_pad, _, cols, _ in layer._train_chunks(x.device):
                 rows, lad = ops.rq_spline_fused_general(rows, hidden, w_frag, w_un, bias_pad, cols, tails=layer.tails,
                                                         logabsdet_accum=lad, inverse=False, **kw)
         ctx.layer, ctx.n = layer, n
@@ -514,20 +535,36 @@ class _FusedRQCouplingFunction(torch.autograd.Function):
             gl = None if gl is None else torch.cat((gl, gl.new_zeros(rows_total - n)))
         kw = layer._fused_kw(net)
         lin = net.final_layer
-        grad_w = torch.zeros_like(lin.weight)
-        grad_b = torch.zeros_like(lin.bias)
-        gh = None
+        chunks = layer._train_chunks(x.device)
+        grad_w = grad_b = gh = None
         g = gy.contiguous()
-        fwd_chunks = layer._fused_chunks(x.device, "general")
-        for (w_frag, w_un, bias_pad, cols), (wt_frag, rows_slice, _) in zip(fwd_chunks,
-                                                                           layer._fused_chunks(x.device, "transposed")):
+        for w_frag, w_un, bias_pad, wt_frag, cols, rows_slice in chunks:
             # each group reads x at its own columns only (the others were not touched by it): the saved input serves all
             g, gh_c, gw_c, gb_c = ops.rq_fused_linear_backward(x, hidden, g, gl, (w_frag, w_un, bias_pad), wt_frag, cols,
                                                                tails=layer.tails, **kw)
             gh = gh_c if gh is None else gh + gh_c
-            grad_w[rows_slice] = gw_c[:, :lin.in_features]
-            grad_b[rows_slice] = gb_c
-        # hidden stack: recompute its forward from the identity columns (PyTorch-ROCm ops) and pull gh through it
+            if len(chunks) == 1:
+                grad_w, grad_b = gw_c[:, :lin.in_features], gb_c
+            else:
+                if grad_w is None:
+                    grad_w, grad_b = torch.zeros_like(lin.weight), torch.zeros_like(lin.bias)
+                grad_w[rows_slice] = gw_c[:, :lin.in_features]
+                grad_b[rows_slice] = gb_c
+        by_id = {id(lin.weight): grad_w, id(lin.bias): grad_b}
+        if net.hip_hidden_backward_supported():
+            # hidden stack in fc_resnet_hidden_backward: activations recomputed from the identity columns in registers
+            gxid, gw0, gwb, gb = ops.resnet_hidden_backward(x, gh, layer._id_cols(x.device), net.hidden_backward_packed(),
+                                                            net.initial_layer.in_features, len(net.blocks))
+            g.index_add_(1, layer.identity_features, gxid)
+            hf = net.hidden_features
+            by_id[id(net.initial_layer.weight)] = gw0[:hf]
+            by_id[id(net.initial_layer.bias)] = gb[0, :hf]
+            for bi, block in enumerate(net.blocks):
+                for li, l2 in enumerate(block.linear_layers):
+                    by_id[id(l2.weight)] = gwb[2 * bi + li, :hf, :hf]
+                    by_id[id(l2.bias)] = gb[1 + 2 * bi + li, :hf]
+            return (None, g[:n]) + tuple(by_id.get(pid) for pid in ctx.param_ids)
+        # otherwise: recompute its forward from the identity columns (PyTorch-ROCm ops) and pull gh through it
         hidden_params = [p for p in net.parameters() if p is not lin.weight and p is not lin.bias]
         with torch.enable_grad():
             xid = x[:, layer.identity_features].detach().requires_grad_(True)
@@ -535,7 +572,6 @@ class _FusedRQCouplingFunction(torch.autograd.Function):
             wanted = [xid] + [p for p in hidden_params if p.requires_grad]
             got = torch.autograd.grad(h2, wanted, gh[:, :h2.shape[1]], allow_unused=True)
         g[:, layer.identity_features] += got[0]
-        by_id = {id(lin.weight): grad_w, id(lin.bias): grad_b}
         for p, gp_ in zip(wanted[1:], got[1:]):
             by_id[id(p)] = gp_
         grads = tuple(by_id.get(pid) for pid in ctx.param_ids)

@@ -153,6 +153,21 @@ int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const flo
                      int32_t in_features, int32_t hidden, int32_t num_blocks, int32_t activation,
                      float activation_param, void* stream);
 
+/* Backward of fc_resnet_hidden (what torch.autograd yields for resnet.py:39-53, 93-99): the activations are recomputed
+ * from x; grad_h [n, 64] in -> grad_x_id [n, 32 K0S] (gradient wrt x[:, id_cols], K0S = 1 for in_features <= 32 else 2),
+ * and, ACCUMULATED with atomics (zero them first): grad_w0 [64][32 K0S], grad_wb [2 num_blocks][64][64], grad_b [L][64],
+ * L = 1 + 2 num_blocks.  hidden == 64, num_blocks <= 2, ReLU, no context, n % 128 == 0.  The weight gradients contract
+ * over samples on the exact-f32 matrix instruction (v_mfma_f32_16x16x4_f32).
+ *   w_frag   forward fragments, f16: layer 0 [K0S][4][2][64][8], then per layer [2][4][2][64][8]; rows of tile t in
+ *            accumulator order: row rho <-> feature 32 (t >> 1) + 8 (rho >> 2) + 4 (t & 1) + (rho & 3)
+ *   wt_frag  fragments of the transposed weights: per hidden layer [2][4][2][64][8] (rows = in-features in the same order,
+ *            k = out-features), last: W0^T [2][2 K0S][2][64][8] (rows = identity features, natural order)
+ *   w_unscale [L];  bias_acc [L][4][16]: bias_acc[l][g][4 t + r] = bias_l[32 (t >> 1) + 8 g + 4 (t & 1) + r] */
+int fc_resnet_hidden_backward(const float* x, const float* grad_h, const int32_t* id_cols, const void* w_frag,
+                              const void* wt_frag, const float* w_unscale, const float* bias_acc, float* grad_x_id,
+                              float* grad_w0, float* grad_wb, float* grad_b, int64_t n, int32_t d, int32_t in_features,
+                              int32_t hidden, int32_t num_blocks, int32_t activation, void* stream);
+
 /* The same stack for WIDE conditioners: hidden in {128, 256} (hidden_features is a free constructor argument,
  * resnet.py:62; narrower widths zero-padded by the host), any num_blocks <= 16, no context.  The activations of a
  * 64-sample tile live in LDS as matrix-core B operands shared by the workgroup's 8 waves; wave w owns the output
@@ -341,6 +356,30 @@ int fc_sylvester_mm(const float* x, float* y, float* logabsdet, const float* w1,
  * LULinear / Linear forward with W = L U (lu.py:56-68, linear.py:45-60), a HouseholderSequence folded into its
  * orthogonal matrix (orthogonal.py:63-85).  bias may be NULL.  d % 32 == 0, d <= 128, n % 16 == 0. */
 int fc_dense_mm(const float* x, float* y, const float* w, const float* bias, int64_t n, int32_t d, void* stream);
+
+/* ---- weight packing on the device ------------------------------------------------------------------------- */
+/* f32 nn.Linear tensors -> the scaled two-piece f16 matrix-core fragments the kernels above take (w_frag / wt_frag),
+ * their power-of-two unscale factors and the packed biases: one workgroup per scale group, one launch per weight set
+ * (training re-packs every step).  `jobs` is a DEVICE array of fc_pack_job. */
+#define FC_PACK_FINAL 0      /* fc_rq_spline_fused_general w_frag + bias_pad of one group of 4 dims */
+#define FC_PACK_FINAL_T 1    /* fc_rq_fused_linear_backward wt_frag of one group */
+#define FC_PACK_HIDDEN 2     /* fc_resnet_hidden_backward w_frag + bias_acc of one layer */
+#define FC_PACK_HIDDEN_T 3   /* its wt_frag of one hidden layer */
+#define FC_PACK_HIDDEN_T0 4  /* its wt_frag of the initial layer (W0^T) */
+typedef struct fc_pack_job {
+  const float* w;       /* source matrix [rows, cols], row-major */
+  const float* b;       /* source bias or NULL */
+  void* frag;           /* f16 fragments of this group: [nks * nt][2 pieces][64 lanes][8] */
+  float* unscale;       /* 2^-S of this group */
+  float* bias_out;      /* packed bias or NULL */
+  int32_t rows, cols;   /* valid extent of w (everything outside reads as 0) */
+  int32_t mode;         /* FC_PACK_* */
+  int32_t p, pp;        /* FINAL*: parameters per dim P and its padding 4T */
+  int32_t nks, nt;      /* fragment image [nks][nt] (FINAL_T: [nt hidden tiles][nks k-steps]) */
+  int32_t group;        /* FINAL*: group of 4 dims */
+} fc_pack_job;
+int fc_pack_fragments(const void* jobs, int32_t num_jobs, void* stream);
+int fc_pack_job_bytes(void);
 
 /* ---- multi-GPU: the one collective of the path ------------------------------------------------------ */
 /* Batch-sharded log_prob (one process per GPU, contiguous row shards, replicated weights) exchanges

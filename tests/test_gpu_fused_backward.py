@@ -138,3 +138,69 @@ def test_flow_trains_on_the_fused_path_like_the_unfused_one(device):
         opt.step()
         losses.append(float(loss.detach()))
     assert losses[-1] < losses[0] and all(l == l for l in losses)
+
+
+@pytest.mark.parametrize("hidden,in_f,blocks,d,n", [(64, 32, 2, 64, 256), (64, 32, 2, 64, 128 * 9), (32, 16, 1, 32, 128),
+                                                   (64, 64, 2, 128, 384), (20, 7, 2, 15, 128), (64, 6, 0, 12, 128)])
+def test_hidden_backward_kernel_vs_float64_autograd(hidden, in_f, blocks, d, n, device):
+    """fc_resnet_hidden_backward: gradients wrt the identity inputs and every weight / bias of the hidden stack against
+    float64 autograd through the same nn.Module (activations recomputed in the kernel, nothing saved but x)."""
+    torch.manual_seed(hidden + in_f + blocks)
+    net = nets.ResidualNet(in_f, 8, hidden_features=hidden, num_blocks=blocks)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    ids = torch.randperm(d)[:in_f].sort().values
+    x = torch.randn(n, d) * torch.logspace(-1, 0.5, n).unsqueeze(1)
+    gh = torch.randn(n, 64) * torch.logspace(-2, 1, n).flip(0).unsqueeze(1)
+    gh[:, hidden:] = 0
+    net64 = copy.deepcopy(net).double()
+    xid = x[:, ids].double().requires_grad_(True)
+    h = net64.hidden(xid)
+    params = [net64.initial_layer.weight, net64.initial_layer.bias] + [p for b in net64.blocks for l in b.linear_layers
+                                                                      for p in (l.weight, l.bias)]
+    ref = torch.autograd.grad(h, [xid] + params, gh[:, :hidden].double())
+    netd = net.to(device)
+    assert netd.hip_hidden_backward_supported()
+    gxid, gw0, gwb, gb = ops.resnet_hidden_backward(x.to(device), gh.to(device), ids.to(device), netd.hidden_backward_packed(),
+                                                    in_f, blocks)
+    assert _relerr(gxid, ref[0]) <= 2e-4
+    assert _relerr(gw0[:hidden], ref[1]) <= 2e-4 and _relerr(gb[0, :hidden], ref[2]) <= 2e-4
+    for i in range(2 * blocks):
+        assert _relerr(gwb[i, :hidden, :hidden], ref[3 + 2 * i]) <= 2e-4, i
+        assert _relerr(gb[1 + i, :hidden], ref[4 + 2 * i]) <= 2e-4, i
+    if hidden < 64:      # zero-padded units: no gradient leaks into them
+        assert float(gw0[hidden:].abs().max()) == 0.0 and float(gb[:, hidden:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("k,tails,d_t,hidden", [(8, "linear", 32, 64), (10, "linear", 70, 64), (10, None, 5, 20), (4, "linear", 3, 64)])
+def test_device_pack_equals_the_tensor_op_packers(k, tails, d_t, hidden, device):
+    """fc_pack_fragments (one launch; training re-packs every step) against the torch packers the inference path caches:
+    bit-identical fragments, scales and biases, for the final layer (forward + W^T) and the hidden stack."""
+    torch.manual_seed(k + d_t)
+    p = 3 * k - 1 if tails == "linear" else 3 * k + 1
+    w = (torch.randn(d_t * p, hidden) * torch.logspace(-3, 1, d_t * p).unsqueeze(1)).to(device)
+    b = torch.randn(d_t * p, device=device)
+    spec = [(slice(lo * p, min(lo + 32, d_t) * p), torch.arange(lo, min(lo + 32, d_t), dtype=torch.int32, device=device))
+            for lo in range(0, d_t, 32)]
+    pack, chunks = ops.device_pack_final_layer(w, b, k, tails, spec)
+    pack.run()
+    for (w_frag, w_un, bias_pad, wt_frag, _, rows) in chunks:
+        ref_f, ref_un, ref_b = ops.pack_final_layer_general(w[rows], b[rows], k, tails, 64)
+        ref_t = ops.pack_final_layer_transposed(w[rows], k, tails)
+        assert torch.equal(w_frag, ref_f) and torch.equal(w_un, ref_un) and torch.equal(bias_pad, ref_b)
+        assert torch.equal(wt_frag, ref_t)
+    net = nets.ResidualNet(min(d_t, 60), 8, hidden_features=hidden, num_blocks=2).to(device)
+    pack2, packed = ops.device_pack_resnet_hidden_backward(net)
+    pack2.run()
+    ref = ops.pack_resnet_hidden_backward(net)
+    for got, want in zip(packed[:4], ref[:4]):
+        assert torch.equal(got.reshape(-1), want.reshape(-1))
+    assert packed[4] == ref[4]
+    with torch.no_grad():       # optimizers update in place: a re-run picks the new values up
+        for prm in net.parameters():
+            prm.mul_(0.5)
+    pack2.run()
+    ref = ops.pack_resnet_hidden_backward(net)
+    for got, want in zip(packed[:4], ref[:4]):
+        assert torch.equal(got.reshape(-1), want.reshape(-1))

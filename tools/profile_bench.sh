@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT $R/profiles
-ARGS="--steps 3 --warmup 3 --no-cpu-baseline"   # 3 warm-up steps: the first two run 5-10 % slower under the profiler
+ARGS="--steps 3 --warmup 3 --no-cpu-baseline --no-configs"   # 3 warm-up steps: the first two run 5-10 % slower under the profiler
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 echo "trace exit $?"
@@ -16,5 +16,16 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -- python3 $R/bench.py $ARGS > $OUT/bench_$C.json 2> $OUT/bench_$C.err
   echo "$C exit $?"
 done
+# the secondary configurations (bench.py's `configs` block) and the training step: kernel-trace stats only
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_configs -- python3 $R/tools/bench_configs.py > $OUT/configs.jsonl 2> $OUT/configs.err
+echo "configs trace exit $?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python3 $R/tools/probe/bench_train.py 19 --json > $OUT/train.json 2> $OUT/train.err
+echo "train trace exit $?"
 cd $R
 python3 tools/summarize_profile.py $OUT $TAG
+for what in configs train; do
+  f=$(ls $OUT/trace_$what/*/*kernel_stats.csv 2>/dev/null | head -1)
+  [ -n "$f" ] && cp $f profiles/${TAG}_${what}_kernel_stats.csv
+done
+cp $OUT/configs.jsonl profiles/${TAG}_configs_under_rocprof.jsonl 2>/dev/null
+cp $OUT/train.json profiles/${TAG}_train_under_rocprof.json 2>/dev/null
