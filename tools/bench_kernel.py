@@ -1,5 +1,5 @@
 """Times one bijector kernel in isolation on the BASELINE.json cfg-3 layer shape and prints achieved
-algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [--lib path.so] [--log2n 20] [rq|rq_inv|rq_bwd|affine|fused|fused_inv|hidden]"""
+algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [--lib path.so] [--log2n 20] [rq|rq_inv|rq_bwd|affine|fused|fused_inv|hidden|general|general_k10|general_h256|fused_bwd|fused_bwd_k10|hidden_bwd|hidden_wide|hidden_wide128]"""
 import os
 import sys
 
@@ -51,6 +51,46 @@ def main():
         kw = dict(num_bins=k, tails="linear", tail_bound=3.0, wh_divisor=8.0)
         fn = lambda: ops.rq_spline_backward(x, params, cols, gy, gl, **kw)  # noqa: E731
         name = "fc_rq_spline_backward"
+    elif which in ("general", "general_k10", "general_h256"):
+        # the general fused final-layer kernel: K = 8 / hidden 64 (the headline shape on the general structure),
+        # K = 10 / hidden 64, K = 10 / hidden 256
+        kk, hid = (8, 64) if which == "general" else (10, 64) if which == "general_k10" else (10, 256)
+        p = 3 * kk - 1
+        h = torch.randn(n, hid, device=dev)
+        w = torch.randn(d_t * p, hid, device=dev) * (1.0 / hid ** 0.5)
+        b = torch.randn(d_t * p, device=dev) * 0.1
+        packed = ops.pack_final_layer_general(w, b, kk, "linear", hid)
+        fn = lambda: ops.rq_spline_fused_general(x, h, *packed, cols, num_bins=kk, tails="linear", tail_bound=3.0,  # noqa: E731
+                                                 wh_divisor=float(hid) ** 0.5)
+        name = "fc_rq_spline_fused_general"
+    elif which in ("fused_bwd", "fused_bwd_k10"):
+        kk = 8 if which == "fused_bwd" else 10
+        p = 3 * kk - 1
+        h = torch.randn(n, 64, device=dev)
+        w = torch.randn(d_t * p, 64, device=dev) * 0.125
+        b = torch.randn(d_t * p, device=dev) * 0.1
+        packed = ops.pack_final_layer_general(w, b, kk, "linear", 64)
+        packed_t = ops.pack_final_layer_transposed(w, kk, "linear")
+        gy, gl = torch.randn(n, d, device=dev), torch.randn(n, device=dev)
+        fn = lambda: ops.rq_fused_linear_backward(x, h, gy, gl, packed, packed_t, cols, num_bins=kk, tails="linear",  # noqa: E731
+                                                  tail_bound=3.0, wh_divisor=8.0)
+        name = "fc_rq_fused_linear_backward"
+    elif which == "hidden_bwd":
+        from flowconductor_amd.nn import nets
+        p = 0
+        net = nets.ResidualNet(32, 8, hidden_features=64, num_blocks=2).to(dev)
+        ids = torch.arange(1, d, 2, device=dev)
+        gh = torch.randn(n, 64, device=dev)
+        packed = net.hidden_backward_packed()
+        fn = lambda: ops.resnet_hidden_backward(x, gh, ids, packed, 32, 2)  # noqa: E731
+        name = "fc_resnet_hidden_backward"
+    elif which in ("hidden_wide", "hidden_wide128"):
+        from flowconductor_amd.nn import nets
+        p = 0
+        net = nets.ResidualNet(32, 8, hidden_features=256 if which == "hidden_wide" else 128, num_blocks=2).eval().to(dev)
+        ids = torch.arange(1, d, 2, device=dev)
+        fn = lambda: net.hidden_hip_wide(x, ids)  # noqa: E731
+        name = "fc_resnet_hidden_wide"
     elif which == "hidden":
         from flowconductor_amd.nn import nets
         p = 0
@@ -75,6 +115,11 @@ def main():
         torch.cuda.synchronize()
     ms = sorted(timer.durations_ms())
     med = ms[len(ms) // 2]
+    if which.startswith("fused_bwd"):      # two launches per call: role 0 (dx), role 1 (dw), in that order
+        d_ms = timer.durations_ms()
+        r0, r1 = sorted(d_ms[0::2]), sorted(d_ms[1::2])
+        print("%s N=2^%d: role 0 (gx, gh, gb) median %.4f ms, role 1 (gW) median %.4f ms"
+              % (which, n.bit_length() - 1, r0[len(r0) // 2], r1[len(r1) // 2]))
     print("%s N=2^%d: median %.4f ms  min %.4f  max %.4f  -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s), "
           "actual bytes/alg = %.3f" % (which, n.bit_length() - 1, med, ms[0], ms[-1], alg / med / 1e6,
                                        alg / med / 1e6 / 80.0, (4 * (d_t * p + 2 * d + 1)) / (4 * d_t * (p + 2) + 8)))
