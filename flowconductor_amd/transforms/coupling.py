@@ -514,9 +514,17 @@ class _FusedRQCouplingFunction(torch.autograd.Function):
             hidden = layer._hidden_for_fused(x, None, None, 64)
             kw = layer._fused_kw(net)
             rows, lad = x, None
-            for w_frag, w_un, bias_pad, _, cols, _ in layer._train_chunks(x.device):
-                rows, lad = ops.rq_spline_fused_general(rows, hidden, w_frag, w_un, bias_pad, cols, tails=layer.tails,
-                                                        logabsdet_accum=lad, inverse=False, **kw)
+            k8 = ops.fused_linear_supported(x.shape[0], x.shape[1], min(layer.num_transform_features, ops.FUSED_DT),
+                                            net.hidden_features, layer.num_bins, layer.tails)
+            lin = net.final_layer
+            for w_frag, w_un, bias_pad, _, cols, rows_slice in layer._train_chunks(x.device):
+                if k8:    # the hand-scheduled north-star kernel takes the f32 weights (rows padded 23 -> 24)
+                    w_pad, b_pad = ops.pack_final_layer(lin.weight[rows_slice], lin.bias[rows_slice], layer.num_bins)
+                    rows, lad = ops.rq_spline_fused_linear(rows, hidden, w_pad, b_pad, cols, logabsdet_accum=lad,
+                                                           inverse=False, **kw)
+                else:
+                    rows, lad = ops.rq_spline_fused_general(rows, hidden, w_frag, w_un, bias_pad, cols,
+                                                            tails=layer.tails, logabsdet_accum=lad, inverse=False, **kw)
         ctx.layer, ctx.n = layer, n
         ctx.save_for_backward(x, hidden)
         ctx.param_ids = [id(p) for p in net_params]

@@ -95,10 +95,12 @@ def test_coupling_layer_trains_through_fused_kernels(d, hidden, k, tails, n, dev
     xd = x.to(device).requires_grad_(True)
     groups = -(-t_gpu.num_transform_features // 32)
     with ops.KernelTimer("fc_rq_fused_linear_backward") as tb, ops.KernelTimer("fc_rq_spline_fused_general") as tf, \
-            ops.KernelTimer("fc_rq_spline_backward") as told:
+            ops.KernelTimer("fc_rq_spline_fused_linear") as tf8, ops.KernelTimer("fc_rq_spline_backward") as told:
         y, lad = t_gpu(xd)
         ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
-    assert len(tb.pairs) == 2 * groups and len(tf.pairs) == groups and not told.pairs
+    # forward: the hand-scheduled K = 8 kernel for the north-star shape, the general one otherwise
+    assert len(tb.pairs) == 2 * groups and len(tf.pairs) + len(tf8.pairs) == groups and not told.pairs
+    assert bool(tf8.pairs) == (k == 8 and tails == "linear")
     assert maxdiff(y.detach(), y_ref.detach()) <= 2e-5 * max(1.0, float(y_ref.detach().abs().max()))
     assert maxdiff(lad.detach(), lad_ref.detach()) <= 3e-4
     assert _relerr(xd.grad, x64.grad) <= 2e-4

@@ -315,3 +315,22 @@ def test_narrow_householder_rows(d, k, n, per_sample, reverse, device):
         y = ops.householder(x.to(device), q.to(device), reverse=reverse)
     assert y.shape == (n, d)
     assert maxdiff(y, v) <= 2e-5 * max(1.0, float(v.abs().max()))
+
+
+@pytest.mark.parametrize("scale", [1.0, 40.0])
+def test_sum_of_sigmoids_inverse_residual_and_bisection_agreement(scale, device):
+    """The inverse is a safeguarded Newton search (5-9 evaluations) instead of the reference's 50 bisection steps
+    (no_analytic_inv/base.py:23-103): |f(x^) - z| <= 1e-5 (relative to max(1, |z|)) on random parameters, also far from the
+    origin, and the same root as the plain bisection (negative `iterations` = the A/B switch of the C ABI)."""
+    torch.manual_seed(4)
+    n, d, s = 4096, 5, 30
+    params = torch.randn(n, d * (3 * s + 1), device=device) * 1.5
+    z = torch.randn(n, d, device=device) * scale
+    z[0, 0], z[1, 1] = 200.0, -180.0
+    x_newton, lad_n = ops.sum_of_sigmoids(z, params, s, inverse=True)
+    x_bisect, lad_b = ops.sum_of_sigmoids(z, params, s, inverse=True, iterations=-50)
+    z_back, lad_f = ops.sum_of_sigmoids(x_newton, params, s)
+    tol = 1e-5 * z.abs().clamp_min(1.0)
+    assert bool(((z_back - z).abs() <= tol).all()), float(((z_back - z).abs() / tol).max())
+    assert maxdiff(x_newton, x_bisect) <= 2e-5 * max(1.0, float(x_bisect.abs().max()))
+    assert maxdiff(lad_n, lad_b) <= 1e-4 and maxdiff(lad_n + lad_f, torch.zeros(n)) <= 1e-4

@@ -91,6 +91,15 @@ def main():
         ids = torch.arange(1, d, 2, device=dev)
         fn = lambda: net.hidden_hip_wide(x, ids)  # noqa: E731
         name = "fc_resnet_hidden_wide"
+    elif which in ("sos_inv", "sos_inv_bisect", "sos_fwd"):
+        # sum-of-sigmoids (S = 30: 91 raw values per dim), D = 8 all transformed: numerical inverse / forward
+        d, d_t, ns = 8, 8, 30
+        p = 3 * ns + 1
+        x = torch.randn(n, d, device=dev) * 2.0
+        params = torch.randn(n, d * p, device=dev)
+        iters = -50 if which == "sos_inv_bisect" else 50
+        fn = lambda: ops.sum_of_sigmoids(x, params, ns, inverse=which != "sos_fwd", iterations=iters)  # noqa: E731
+        name = "fc_sum_of_sigmoids"
     elif which == "hidden":
         from flowconductor_amd.nn import nets
         p = 0
