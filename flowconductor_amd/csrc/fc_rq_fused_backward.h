@@ -65,7 +65,8 @@ inline size_t bwd_lds_bytes(int d, int role) {
   b += 2 * kBwdR * 4 * 2;                                   // hscale, gl  [buf][row]
   b += 32 * 4 + (size_t)32 * 52 * 4;                        // cols, bias image
   if (role == 0) b += (size_t)8 * kBwdR * (kBwdH + 4) * 4;  // partial gh tiles of the 8 waves
-  else b += (size_t)2 * 2 * kBwdH * kBwdTS * 2 + (size_t)8 * 2 * 16 * kBwdTS * 2;   // h^T [buf][piece][64][40], G^T strips
+  if (role == 2) b += (size_t)2 * kBwdR * kBwdH * 4;        // merged: gh tiles summed by LDS atomics, ring of two
+  if (role != 0) b += (size_t)2 * 2 * kBwdH * kBwdTS * 2 + (size_t)8 * 2 * 16 * kBwdTS * 2;   // h^T [buf][piece][64][40], G^T strips
   return b;
 }
 
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   constexpr int P = S::P, PP = S::PP, T = S::T;
   constexpr int PP8 = (PP + 7) / 8 * 8, KK = PP8 / 8;       // role 0: k-steps of the W^T product (8 parameters per lane)
   constexpr int R = kBwdR, H = kBwdH, HB = kBwdHB, KS = 2, TS = kBwdTS;
+  constexpr bool kDx = kRole != 1, kDw = kRole != 0, kMerged = kRole == 2;    // role 2: both products from one G
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   const int D = a.D;
   const bool pad_x = (D & 3) == 0;
@@ -86,9 +88,9 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   float* glb = hscale + 2 * R;                                                    // [2][R]
   int* cs = reinterpret_cast<int*>(glb + 2 * R);                                  // [32]
   float* bias_lds = reinterpret_cast<float*>(cs + 32);                            // [8][4][PP] (<= 32 * 52)
-  float* part = bias_lds + 32 * 52;                                               // role 0: [8][R][H + 4]
-  _Float16* htbuf = reinterpret_cast<_Float16*>(bias_lds + 32 * 52);              // role 1: [2][2][H][TS]
-  _Float16* strips = htbuf + (size_t)2 * 2 * H * TS;                              // role 1: [8 waves][2][16][TS]
+  float* part = bias_lds + 32 * 52;                                               // role 0: [8][R][H + 4]; role 2: [2][R][H]
+  _Float16* htbuf = reinterpret_cast<_Float16*>(bias_lds + 32 * 52 + (kMerged ? 2 * R * H : 0));   // roles 1, 2: [2][2][H][TS]
+  _Float16* strips = htbuf + (size_t)2 * 2 * H * TS;                              // roles 1, 2: [8 waves][2][16][TS]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s16 = lane & 15, g = lane >> 4;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
       _Float16* dst = hbuf + ((size_t)(buf * 2) * R + r) * HB + c;
       *reinterpret_cast<f16x4*>(dst) = p0;
       *reinterpret_cast<f16x4*>(dst + (size_t)R * HB) = p1;
-      if constexpr (kRole == 1) {   // the same scaled pieces, transposed: [hidden][sample]
+      if constexpr (kDw) {   // the same scaled pieces, transposed: [hidden][sample]
         _Float16* dt = htbuf + ((size_t)(buf * 2) * H + c) * TS + r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -165,19 +167,23 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   };
 
   // role 0: sums of G over this lane's samples (the bias gradient); role 1: the wave's slice of gW
-  float gbacc[kRole == 0 ? PP : 1];
-  f32x4 dw[kRole == 1 ? T : 1][4];
-  int fshift[kRole == 1 ? PP : 1];     // role 1: per feature, the accumulators hold sum G' 2^fshift (1000 = nothing yet)
+  float gbacc[kDx ? PP : 1];
+  f32x4 dw[kDw ? T : 1][4];
+  int fshift[kDw ? PP : 1];     // per feature, the gW accumulators hold sum G' 2^fshift (1000 = nothing yet)
 #pragma unroll
-  for (int i = 0; i < (kRole == 1 ? PP : 1); ++i) fshift[i] = 1000;
-  if constexpr (kRole == 0) {
+  for (int i = 0; i < (kDw ? PP : 1); ++i) fshift[i] = 1000;
+  if constexpr (kDx) {
 #pragma unroll
     for (int i = 0; i < PP; ++i) gbacc[i] = 0.f;
-  } else {
+  }
+  if constexpr (kDw) {
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int ht = 0; ht < 4; ++ht) dw[t][ht] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (kMerged) {
+    for (int i = tid; i < 2 * R * H; i += kGenThreads) part[i] = 0.f;
   }
 
   fetch(tile0);
@@ -188,88 +194,113 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
     const bool has_next = tile + stride < a.tiles;
     if (has_next) fetch(tile + stride);
     if (active) {
-      // ---- per 16-sample block: recompute its parameters (the forward kernel's product), spline backward -> G ------
-      float gp[kRole == 1 ? 2 : 1][PP8];
-#pragma unroll(kRole == 1 ? 2 : 1)
+      // ---- recompute the parameters of both blocks against each weight fragment (the forward kernel's product: one
+      // pass over the wave's 24 KB of fragments per tile -- they stream from L2, whose bandwidth bounds this kernel when
+      // every block fetches them again) -----------------------------------------------------------------------------
+      f32x4 acc[2][T];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const f16x8 bh0 = hfrag(buf, 0, 0, ks), bl0 = hfrag(buf, 0, 1, ks);
+        const f16x8 bh1 = hfrag(buf, 1, 0, ks), bl1 = hfrag(buf, 1, 1, ks);
+        const f16x8* wk = wsrc + (size_t)ks * T * 2 * 64;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const f16x8 ah = wk[(t * 2 + 0) * 64], al = wk[(t * 2 + 1) * 64];
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh1, acc[1][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl1, acc[1][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, acc[1][t], 0, 0, 0);
+        }
+      }
+      // ---- spline backward of this lane's two elements -> G in registers ------------------------------------------
+      float gp[2][PP8];
+#pragma unroll
       for (int b = 0; b < 2; ++b) {
         __builtin_amdgcn_sched_barrier(0);     // the two blocks' register-hungry spline code must not interleave
-        f32x4 acc[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const f16x8 bh0 = hfrag(buf, b, 0, ks), bl0 = hfrag(buf, b, 1, ks);
-          const f16x8* wk = wsrc + (size_t)ks * T * 2 * 64;
-#pragma unroll
-          for (int t = 0; t < T; ++t) {
-            const f16x8 ah = wk[(t * 2 + 0) * 64], al = wk[(t * 2 + 1) * 64];
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, acc[t], 0, 0, 0);
-          }
-        }
-        float (&gpb)[PP8] = gp[kRole == 1 ? b : 0];
         const int row = 16 * b + s16;
         const int col = cs[(4 * wave + g) & 31];
         const float xin = xbuf[buf * R * (D + 4) + row * XS + col];
         float* gslot = gbuf + buf * R * (D + 4) + row * XS + col;
         const float gyv = *gslot, glr = glb[buf * R + row];
         const float c = hscale[buf * R + row] * w_un;
-        {
-          float p[PP];
+        float p[PP];
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
-            const f32x4 bt = bw[t];
+        for (int t = 0; t < T; ++t) {
+          const f32x4 bt = bw[t];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p[4 * t + r] = __builtin_fmaf(acc[t][r], c, bt[r]);
-          }
-          float gxv, gpe[3 * K + 1];
-          rq_backward_element<K>(q, inv_div, K, P, p, xin, gyv, glr, gxv, gpe);
-#pragma unroll
-          for (int i = 0; i < PP8; ++i) gpb[i] = (i < P && dim_ok) ? gpe[i < P ? i : 0] : 0.f;
-          if constexpr (kRole == 0) {
-            if (dim_ok) *gslot = gxv;
-          }
+          for (int r = 0; r < 4; ++r) p[4 * t + r] = __builtin_fmaf(acc[b][t][r], c, bt[r]);
         }
-        if constexpr (kRole == 0) {
+        float gxv, gpe[3 * K + 1];
+        rq_backward_element_fast<K, kTails>(q, inv_div, p, xin, gyv, glr, gxv, gpe);
 #pragma unroll
-          for (int i = 0; i < PP; ++i) gbacc[i] += gpb[i];
-          // ---- gh^T partial of this wave: W^T (this wave's rows) x G, the lane's gradients as its own B operand -----
+        for (int i = 0; i < PP8; ++i) gp[b][i] = (i < P && dim_ok) ? gpe[i < P ? i : 0] : 0.f;
+        if constexpr (kDx) {
+          if (dim_ok) *gslot = gxv;
+#pragma unroll
+          for (int i = 0; i < PP; ++i) gbacc[i] += gp[b][i];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (kDx) {
+        // ---- gh^T partial of this wave: W^T (this wave's rows) x G, the lane's gradients as its own B operand; both
+        // blocks against each W^T fragment ---------------------------------------------------------------------------
+        f16x8 bh[2][KK], bl[2][KK];
+        float cc[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
           float m = 0.f;
 #pragma unroll
-          for (int i = 0; i < PP; ++i) m = fmaxf(m, fabsf(gpb[i]));
+          for (int i = 0; i < PP; ++i) m = fmaxf(m, fabsf(gp[b][i]));
           m = rows4_allmax(m, lane);
           float sc, un;
           pow2_scale(m, sc, un);
-          f16x8 bh[KK], bl[KK];
+          cc[b] = un * w_un;
 #pragma unroll
           for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               _Float16 ph, pl;
-              split2(gpb[8 * kk + j] * sc, ph, pl);
-              bh[kk][j] = ph;
-              bl[kk][j] = pl;
+              split2(gp[b][8 * kk + j] * sc, ph, pl);
+              bh[b][kk][j] = ph;
+              bl[b][kk][j] = pl;
             }
-          const float cc = un * w_un;
-          const f16x8* wt = a.wtfrag + (size_t)grp * 4 * KK * 2 * 64 + lane;
+        }
+        const f16x8* wt = a.wtfrag + (size_t)grp * 4 * KK * 2 * 64 + lane;
 #pragma unroll
-          for (int ht = 0; ht < 4; ++ht) {
-            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ht = 0; ht < 4; ++ht) {
+          f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-              const f16x8 ah = wt[((size_t)(ht * KK + kk) * 2 + 0) * 64], al = wt[((size_t)(ht * KK + kk) * 2 + 1) * 64];
-              o = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[kk], o, 0, 0, 0);
-              o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[kk], o, 0, 0, 0);
-              o = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[kk], o, 0, 0, 0);
+          for (int kk = 0; kk < KK; ++kk) {
+            const f16x8 ah = wt[((size_t)(ht * KK + kk) * 2 + 0) * 64], al = wt[((size_t)(ht * KK + kk) * 2 + 1) * 64];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              o[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[b][kk], o[b], 0, 0, 0);
+              o[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[b][kk], o[b], 0, 0, 0);
+              o[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[b][kk], o[b], 0, 0, 0);
             }
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
             // lane (sample s16, hidden 16 ht + 4 g + r)
-            *reinterpret_cast<float4*>(part + ((size_t)wave * R + 16 * b + s16) * (H + 4) + 16 * ht + 4 * g) =
-                float4{o[0] * cc, o[1] * cc, o[2] * cc, o[3] * cc};
+            if constexpr (kMerged) {     // the 8 waves add into one tile (order of the additions not fixed)
+              float* dst = part + ((size_t)buf * R + 16 * b + s16) * H + 16 * ht + 4 * g;
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                __hip_atomic_fetch_add(dst + r, o[b][r] * cc[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              *reinterpret_cast<float4*>(part + ((size_t)wave * R + 16 * b + s16) * (H + 4) + 16 * ht + 4 * g) =
+                  float4{o[b][0] * cc[b], o[b][1] * cc[b], o[b][2] * cc[b], o[b][3] * cc[b]};
+            }
           }
         }
       }
-      if constexpr (kRole == 1) {
+      if constexpr (kDw) {
         // ---- gW slice of this wave: (G 2^-T_s)^T x (h 2^T_s), contraction over the tile's 32 samples ---------------
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -327,6 +358,15 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
     }
     if (has_next) park(buf ^ 1);
     __syncthreads();
+    if constexpr (kMerged) {
+      float4* og = reinterpret_cast<float4*>(a.gx + tile * R * D);
+      if (tid < xvec) og[tid] = *slot(gbuf, buf, tid);
+      if (tid + kGenThreads < xvec) og[tid + kGenThreads] = *slot(gbuf, buf, tid + kGenThreads);
+      // gh tile: complete since every wave passed the barrier; read it, clear it for the tile after next
+      float4* pt = reinterpret_cast<float4*>(part + (size_t)buf * R * H) + tid;
+      reinterpret_cast<float4*>(a.gh + tile * R * H)[tid] = *pt;
+      *pt = float4{0.f, 0.f, 0.f, 0.f};
+    }
     if constexpr (kRole == 0) {
       // gx tile (gy with the transformed columns overwritten) and gh tile (the waves' partials in wave order)
       float4* og = reinterpret_cast<float4*>(a.gx + tile * R * D);
@@ -344,14 +384,15 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
     buf ^= 1;
   }
   if (!active) return;
-  if constexpr (kRole == 0) {
+  if constexpr (kDx) {
     // gb: sum over the 16 sample lanes of a row, one atomic per (dim, parameter) and workgroup
 #pragma unroll
     for (int i = 0; i < PP; ++i) {
       const float v = row16_allsum(gbacc[i]);
       if (s16 == 0 && i < P && dim_ok) atomicAdd(a.gb + (size_t)(grp * 4 + g) * PP + i, v);
     }
-  } else {
+  }
+  if constexpr (kDw) {
     // lane (hidden 16 ht + s16, feature rho = 4 g + r of tile t) = gW[(dim 4 grp + g), param 4 t + r][hidden]
     if (dim_ok) {
 #pragma unroll
@@ -390,7 +431,9 @@ template <int K, bool kTails>
 hipError_t launch_backward(int role, const RQParams& q, const BwdArgs& a, hipStream_t stream) {
   if constexpr (GenShape<K, kTails>::T > 8) return hipErrorInvalidValue;
   else
-    return role == 0 ? launch_backward_role<K, kTails, 0>(q, a, stream) : launch_backward_role<K, kTails, 1>(q, a, stream);
+    return role == 0   ? launch_backward_role<K, kTails, 0>(q, a, stream)
+           : role == 1 ? launch_backward_role<K, kTails, 1>(q, a, stream)
+                       : launch_backward_role<K, kTails, 2>(q, a, stream);
 }
 
 }  // namespace fc

@@ -847,10 +847,13 @@ def pack_final_layer_transposed(weight, num_bins, tails):
 def rq_fused_linear_backward(inputs, hidden, grad_outputs, grad_logabsdet, packed, packed_t, cols, *, num_bins, tails,
                              tail_bound=1.0, left=0.0, right=1.0, bottom=0.0, top=1.0,
                              min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
-                             min_derivative=DEFAULT_MIN_DERIVATIVE, wh_divisor=1.0, enable_identity_init=False):
+                             min_derivative=DEFAULT_MIN_DERIVATIVE, wh_divisor=1.0, enable_identity_init=False,
+                             merged=None):
     """Gradients of ``rq_spline_fused_general(inputs, hidden, *packed, cols, ...)`` (forward direction, hidden width
     64, rows a multiple of 32): returns ``(grad_inputs [N, D], grad_hidden [N, 64], grad_weight [d_t * P, 64],
-    grad_bias [d_t * P])`` for the <= 32 dims of ``cols`` -- two launches of ``fc_rq_fused_linear_backward``."""
+    grad_bias [d_t * P])`` for the <= 32 dims of ``cols``.  ``merged``: one launch of ``fc_rq_fused_linear_backward``
+    (role 2: both products from one evaluation of the spline backward) instead of two (roles 0 and 1); default: the
+    ``fused_backward_merged`` option."""
     lib = _hip.load()
     x = _prep_2d(inputs.detach(), align16=True)
     h = _aligned16(_hip.dev_f32(hidden.detach(), "hidden"))
@@ -875,8 +878,11 @@ def rq_fused_linear_backward(inputs, hidden, grad_outputs, grad_logabsdet, packe
     args = (_hip.ptr(x), _hip.ptr(h), _hip.ptr(gy), _hip.ptr(gl), _hip.ptr(w_frag), _hip.ptr(w_un),
             _hip.ptr(bias_pad), _hip.ptr(packed_t), _hip.ptr(cols), _hip.ptr(gx), _hip.ptr(gh), _hip.ptr(gb),
             _hip.ptr(gw), n, d, d_t, cfg, _hip.stream_ptr(x.device))
-    _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 0, *args)
-    _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 1, *args)
+    if options.get("fused_backward_merged") if merged is None else merged:
+        _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 2, *args)
+    else:
+        _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 0, *args)
+        _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 1, *args)
     grad_w = gw.reshape(groups * 4, pp, 64)[:d_t, :p].reshape(d_t * p, 64)
     grad_b = gb.reshape(groups * 4, pp)[:d_t, :p].reshape(d_t * p)
     return gx, gh, grad_w, grad_b

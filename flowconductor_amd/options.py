@@ -27,6 +27,9 @@ _DEFAULTS = {
     # training: conditioner forward / backward in the HIP kernels (fc_resnet_hidden_backward, fused final-layer
     # backward) instead of PyTorch autograd through library GEMMs
     "fused_training": True,
+    # fc_rq_fused_linear_backward: one launch computing gx, gh, gb and gW from one evaluation of the spline backward
+    # (role 2) instead of two launches (roles 0 and 1) that each recompute it
+    "fused_backward_merged": False,
 }
 
 _values = dict(_DEFAULTS)

@@ -19,9 +19,10 @@ def _relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+@pytest.mark.parametrize("merged", [False, True])
 @pytest.mark.parametrize("k,tails,d,d_t,n", [(8, "linear", 64, 32, 256), (10, "linear", 64, 32, 160), (10, None, 16, 8, 96),
                                             (4, "linear", 12, 6, 64), (8, "linear", 63, 31, 96), (5, None, 10, 3, 32)])
-def test_fused_linear_backward_operator_vs_float64_autograd(k, tails, d, d_t, n, device):
+def test_fused_linear_backward_operator_vs_float64_autograd(k, tails, d, d_t, n, merged, device):
     torch.manual_seed(7 * k + d)
     hidden = 64
     p = 3 * k - 1 if tails == "linear" else 3 * k + 1
@@ -48,7 +49,7 @@ def test_fused_linear_backward_operator_vs_float64_autograd(k, tails, d, d_t, n,
     packed_t = ops.pack_final_layer_transposed(w.to(device), k, tails)
     gx, gh, gw, gb = ops.rq_fused_linear_backward(x.to(device), h.to(device), gy.to(device), gl.to(device), packed,
                                                   packed_t, cols.to(device), num_bins=k, tails=tails, tail_bound=3.0,
-                                                  **kw)
+                                                  merged=merged, **kw)
     # f32 arithmetic against a float64 reference: relative to the largest entry of each gradient
     assert _relerr(gx, gx_ref) <= 2e-4
     assert _relerr(gh, gh_ref) <= 2e-4

@@ -63,8 +63,8 @@ def main():
         fn = lambda: ops.rq_spline_fused_general(x, h, *packed, cols, num_bins=kk, tails="linear", tail_bound=3.0,  # noqa: E731
                                                  wh_divisor=float(hid) ** 0.5)
         name = "fc_rq_spline_fused_general"
-    elif which in ("fused_bwd", "fused_bwd_k10"):
-        kk = 8 if which == "fused_bwd" else 10
+    elif which in ("fused_bwd", "fused_bwd_k10", "fused_bwd_merged"):
+        kk = 10 if which == "fused_bwd_k10" else 8
         p = 3 * kk - 1
         h = torch.randn(n, 64, device=dev)
         w = torch.randn(d_t * p, 64, device=dev) * 0.125
@@ -73,7 +73,7 @@ def main():
         packed_t = ops.pack_final_layer_transposed(w, kk, "linear")
         gy, gl = torch.randn(n, d, device=dev), torch.randn(n, device=dev)
         fn = lambda: ops.rq_fused_linear_backward(x, h, gy, gl, packed, packed_t, cols, num_bins=kk, tails="linear",  # noqa: E731
-                                                  tail_bound=3.0, wh_divisor=8.0)
+                                                  tail_bound=3.0, wh_divisor=8.0, merged=which == "fused_bwd_merged")
         name = "fc_rq_fused_linear_backward"
     elif which == "hidden_bwd":
         from flowconductor_amd.nn import nets
@@ -124,7 +124,7 @@ def main():
         torch.cuda.synchronize()
     ms = sorted(timer.durations_ms())
     med = ms[len(ms) // 2]
-    if which.startswith("fused_bwd"):      # two launches per call: role 0 (dx), role 1 (dw), in that order
+    if which in ("fused_bwd", "fused_bwd_k10"):      # two launches per call: role 0 (dx), role 1 (dw), in that order
         d_ms = timer.durations_ms()
         r0, r1 = sorted(d_ms[0::2]), sorted(d_ms[1::2])
         print("%s N=2^%d: role 0 (gx, gh, gb) median %.4f ms, role 1 (gW) median %.4f ms"
