@@ -61,6 +61,11 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
   float* aT = gT + 64 * kHbLd;                                                     // [64][kHbLd]  a^T
   float* biasl = aT + 64 * kHbLd;                                                  // [L][64]
   int* ids = reinterpret_cast<int*>(biasl + L * 64);                               // [32 K0S]
+  // One layer's W^T fragments (16 KB), brought in by LDS-DMA while the layer's (g^T, a^T) images are being written:
+  // one L2 read per workgroup instead of one per wave, its latency behind the staging.  (With 64 identity features the
+  // forward fragments need the space: the W^T fragments then stream from L2 per wave.)
+  constexpr bool kWtLds = K0S == 1;
+  f16x8* wts = reinterpret_cast<f16x8*>(ids + 32 * K0S);                           // [16 fragments][64 lanes]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s16 = lane & 15, g = lane >> 4;
@@ -125,9 +130,15 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
   for (int l = 0; l < L; ++l) dbacc[l] = 0.f;
 
   // (g, a) of this wave's 16 samples -> the shared [feature][sample] images; barrier; this wave's tiles of gW_l
-  auto weight_grad = [&](auto Lc, const f32x4 (&gv)[4], const f32x4 (&av)[4]) __attribute__((always_inline)) {
+  auto weight_grad = [&](auto Lc, const f32x4 (&gv)[4], const f32x4 (&av)[4], int wt_off, int wt_frags) __attribute__((always_inline)) {
     constexpr int l = decltype(Lc)::value;
-    __syncthreads();        // the previous layer's tiles have been read
+    __syncthreads();        // the previous layer's tiles have been read, the previous W^T product is done
+    if constexpr (kWtLds) {
+      // fragments wt_off .. wt_off + wt_frags of the transposed image -> wts; wave w moves fragments w, w + 8
+      for (int f = wave; f < wt_frags; f += kHbThreads / 64)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wt + (size_t)(wt_off + f) * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(wts + f * 64), 16, 0, 0);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -136,6 +147,7 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
         gT[f * kHbLd + 16 * wave + s16] = gv[t][r];
         aT[f * kHbLd + 16 * wave + s16] = av[t][r];
       }
+    if constexpr (kWtLds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the W^T fragments landed
     __syncthreads();
     // contraction index k = sample: chunk c (4 samples per instruction), slot g' = lane >> 4  <->  sample 32 g' + c
     constexpr int kInTiles = l == 0 ? 2 * K0S : 4;
@@ -246,9 +258,9 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) act[t][r] = fmaxf(t1[b][t][r], 0.f);
-      weight_grad(L2c{}, gh, act);
+      weight_grad(L2c{}, gh, act, (2 * b + 1) * kFragL, kFragL);
       float ug = make_operand(gh, bh, bl);
-      product(wtl + (size_t)((2 * b + 1) * kFragL) * 64, 2, I4{}, bh, bl, acc);      // W2^T gh
+      product(kWtLds ? wts + lane : wtl + (size_t)((2 * b + 1) * kFragL) * 64, 2, I4{}, bh, bl, acc);      // W2^T gh
       {
         const float c = ug * wun[2 + 2 * b];
 #pragma unroll
@@ -260,9 +272,9 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) act[t][r] = fmaxf(hin[b][t][r], 0.f);
-      weight_grad(L1c{}, g1, act);
+      weight_grad(L1c{}, g1, act, (2 * b) * kFragL, kFragL);
       ug = make_operand(g1, bh, bl);
-      product(wtl + (size_t)((2 * b) * kFragL) * 64, 2, I4{}, bh, bl, acc);          // W1^T g1
+      product(kWtLds ? wts + lane : wtl + (size_t)((2 * b) * kFragL) * 64, 2, I4{}, bh, bl, acc);          // W1^T g1
       {
         const float c = ug * wun[1 + 2 * b];
 #pragma unroll
@@ -276,10 +288,10 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
     if constexpr (NB >= 2) step_back(B1{});
     if constexpr (NB >= 1) step_back(B0{});
     using L0c = std::integral_constant<int, 0>;
-    weight_grad(L0c{}, gh, xin);
+    weight_grad(L0c{}, gh, xin, 2 * NB * kFragL, 2 * (2 * K0S) * 2);
     {
       const float ug = make_operand(gh, bh, bl);
-      product(wtl + (size_t)(2 * NB * kFragL) * 64, 2, I2K{}, bh, bl, acc);          // W0^T gh: rows = identity features
+      product(kWtLds ? wts + lane : wtl + (size_t)(2 * NB * kFragL) * 64, 2, I2K{}, bh, bl, acc);          // W0^T gh: rows = identity features
       const float c = ug * wun[0];
       float4* out = reinterpret_cast<float4*>(a.gxid + row * (32 * K0S));
 #pragma unroll
@@ -306,7 +318,8 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
 template <int NB, int K0S>
 static hipError_t launch_hid_bwd(const HidBwdArgs& a, hipStream_t s) {
   constexpr int L = 1 + 2 * NB;
-  const size_t lds = (size_t)(K0S * 8 + 2 * NB * 16) * 64 * 16 + (size_t)2 * 64 * kHbLd * 4 + L * 64 * 4 + 32 * K0S * 4;
+  const size_t lds = (size_t)(K0S * 8 + 2 * NB * 16) * 64 * 16 + (size_t)2 * 64 * kHbLd * 4 + L * 64 * 4 + 32 * K0S * 4 +
+                     (K0S == 1 ? 16 * 1024 : 0);
   static PerDeviceOnce attr;
   const hipError_t ea = ensure_max_dynamic_lds(attr, reinterpret_cast<const void*>(&resnet_hidden_backward_kernel<NB, K0S>),
                                                160 * 1024);
