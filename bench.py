@@ -50,7 +50,7 @@ def build_flow():
     return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([FEATURES])).eval()
 
 
-TRAFFIC_PROFILE = "profiles/r02a_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r02b_hbm_traffic.json"
 # kernel symbol (substring) each C-ABI entry launches in this flow: the committed PMC profile must have counted THAT
 # kernel, or its number does not belong in this line
 EXPECTED_KERNELS = {"fc_rq_spline_fused_linear": "rq_fused_linear_kernel3", "fc_resnet_hidden": "resnet_hidden_kernel",
