@@ -98,6 +98,9 @@ SIGNATURES = {
     "fc_sylvester": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "fc_sum_of_sigmoids": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _F, _F, _F,
                            _I32, _I32, _P],
+    "fc_sum_of_sigmoids_backward": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P],
+    "fc_planar_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
+    "fc_householder_backward": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "fc_elementwise": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _F, _P],
     "fc_piecewise_spline": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32,
                             ctypes.POINTER(SplineConfig), _P],

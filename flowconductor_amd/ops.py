@@ -1348,24 +1348,74 @@ def _householder_expression(reverse):
     return expr
 
 
+class _HouseholderFunction(torch.autograd.Function):
+    """``householder`` with batch-shared q-vectors and its HIP backward kernel (``fc_householder_backward``: the
+    reflections are involutions, so the saved OUTPUT is walked back to every intermediate)."""
+
+    @staticmethod
+    def forward(ctx, inputs, q_vectors, reverse):
+        with torch.no_grad():
+            outputs = householder(inputs, q_vectors, reverse=reverse)
+        ctx.save_for_backward(outputs, q_vectors)
+        ctx.reverse = reverse
+        return outputs
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        outputs, q_vectors = ctx.saved_tensors
+        lib = _hip.load()
+        y = _hip.dev_f32(outputs, "outputs")
+        q = _hip.dev_f32(q_vectors.detach(), "q_vectors")
+        gy = _hip.dev_f32(grad_outputs, "grad_outputs")
+        n, d = y.shape
+        gx = torch.empty_like(y)
+        gq = torch.zeros_like(q)
+        _call("fc_householder_backward", lib.fc_householder_backward, y.device, _hip.ptr(y), _hip.ptr(gy), _hip.ptr(q),
+              _hip.ptr(gx), _hip.ptr(gq), n, d, q.shape[0], 1 if ctx.reverse else 0, _hip.stream_ptr(y.device))
+        return gx, gq, None
+
+
 def householder_autograd(inputs, q_vectors, reverse=False):
-    """``householder`` (shared q-vectors) -> (outputs, zeros); under autograd the kernel sits behind a node whose
-    gradients come from the reflections in torch ops."""
+    """``householder`` -> (outputs, zeros); under autograd the shared-q form sits behind ``_HouseholderFunction``."""
     if torch.is_grad_enabled() and (inputs.requires_grad or q_vectors.requires_grad) and q_vectors.dim() == 2:
-        return _TorchGradFunction.apply(lambda x, q: (householder(x, q, reverse=reverse), x.new_zeros(x.shape[0])),
-                                        _householder_expression(reverse), _prep_2d(inputs), q_vectors)
+        x = _prep_2d(inputs)
+        return _HouseholderFunction.apply(x, q_vectors, bool(reverse)), x.new_zeros(x.shape[0])
     return householder(inputs, q_vectors, reverse=reverse), inputs.new_zeros(inputs.shape[0])
+
+
+class _PlanarFunction(torch.autograd.Function):
+    """Shared-parameter ``planar`` with its HIP backward kernel (``fc_planar_backward``)."""
+
+    @staticmethod
+    def forward(ctx, inputs, w, u_hat, b):
+        with torch.no_grad():
+            outputs, logabsdet = planar(inputs, w, u_hat, b)
+        ctx.save_for_backward(inputs, w, u_hat, b)
+        return outputs, logabsdet
+
+    @staticmethod
+    def backward(ctx, grad_outputs, grad_logabsdet):
+        inputs, w, u_hat, b = ctx.saved_tensors
+        lib = _hip.load()
+        x = _hip.dev_f32(inputs.detach(), "inputs")
+        n, d = x.shape
+        wv = _hip.dev_f32(w.detach().reshape(-1), "w")
+        uv = _hip.dev_f32(u_hat.detach().reshape(-1), "u")
+        bv = _hip.dev_f32(b.detach().reshape(-1), "b")
+        gy = _hip.dev_f32(grad_outputs if grad_outputs is not None else torch.zeros_like(x), "grad_outputs")
+        gl = None if grad_logabsdet is None else _hip.dev_f32(grad_logabsdet, "grad_logabsdet")
+        gx = torch.empty_like(x)
+        gpar = torch.zeros(2 * d + 1, dtype=torch.float32, device=x.device)      # gw | gu | gb, one zero fill
+        _call("fc_planar_backward", lib.fc_planar_backward, x.device, _hip.ptr(x), _hip.ptr(gy), _hip.ptr(gl),
+              _hip.ptr(wv), _hip.ptr(uv), _hip.ptr(bv), _hip.ptr(gx), _hip.ptr(gpar[:d]), _hip.ptr(gpar[d:2 * d]),
+              _hip.ptr(gpar[2 * d:]), n, d, _hip.stream_ptr(x.device))
+        return gx, gpar[:d].view_as(w), gpar[d:2 * d].view_as(u_hat), gpar[2 * d:].view_as(b)
 
 
 def planar_autograd(inputs, w, u_hat, b):
     """Shared-parameter planar flow (no_analytic_inv/planar.py:30-49) with an autograd node when needed."""
-    def expr(x, w_, u_, b_):
-        a = x @ w_.T + b_
-        t = torch.tanh(a)
-        lad = torch.log(1e-7 + (1 + (u_ @ ((1 - t ** 2) * w_).T)).abs())
-        return x + u_ * t, lad.reshape(-1)
     if torch.is_grad_enabled() and any(t.requires_grad for t in (inputs, w, u_hat, b)):
-        return _TorchGradFunction.apply(lambda x, w_, u_, b_: planar(x, w_, u_, b_), expr, _prep_2d(inputs), w, u_hat, b)
+        return _PlanarFunction.apply(_prep_2d(inputs), w, u_hat, b)
     return planar(inputs, w, u_hat, b)
 
 
@@ -1546,50 +1596,56 @@ class _TorchGradFunction(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
-def _sos_expression(n_sigmoids, offset, log_scale_postact=0.0, eps=1e-6):
-    """Sum of sigmoids + extended softplus in torch ops (adaptive_sigmoids.py:108-142, nonlinearities.py:519-552) on
-    ``x [N, D]`` and raw parameters ``[N or 1, D, 3S+1]`` = [shift | log-scale | softmax logits | softplus shift]."""
-    from torch.nn import functional as F
+class _SoSFunction(torch.autograd.Function):
+    """``sum_of_sigmoids`` (forward direction, per-sample raw parameters) with its HIP backward kernel
+    (``fc_sum_of_sigmoids_backward``: closed-form derivatives of adaptive_sigmoids.py:108-142)."""
 
-    def expr(x, raw):
-        raw = raw.reshape(-1, x.shape[1], 3 * n_sigmoids + 1)
-        shift_pre, log_scale_pre, raw_softmax, esp_raw = torch.split(raw, [n_sigmoids] * 3 + [1], dim=-1)
-        soft_max = F.softmax(raw_softmax, dim=-1) + eps
-        soft_max = soft_max / soft_max.sum(-1, keepdim=True)
-        post = math.exp(log_scale_postact) * soft_max
-        scale = torch.sigmoid(log_scale_pre) * (10.0 - 0.1) + 0.1
-        pre = scale * (x.unsqueeze(-1) - torch.tanh(shift_pre) * 10)
-        y_sos = (post * torch.sigmoid(pre)).sum(-1) / post.sum(-1)
-        lj_sos = torch.logsumexp(torch.log(post) + torch.log(scale) + (pre - 2 * F.softplus(pre)), -1)
-        s = F.softplus(esp_raw[..., 0]) + 1e-1
-        y_esp = F.softplus(x - s) - F.softplus(-(x + s))
-        lj_esp = torch.logaddexp(x - torch.logaddexp(s, x), -F.softplus(s + x))
-        return y_sos + y_esp - offset, torch.logaddexp(lj_sos, lj_esp).sum(-1)
+    @staticmethod
+    def forward(ctx, inputs, raw_params, n_sigmoids, offset, log_scale_postact):
+        with torch.no_grad():
+            outputs, logabsdet = sum_of_sigmoids(inputs, raw_params, n_sigmoids, offset=offset,
+                                                 log_scale_postact=log_scale_postact)
+        ctx.save_for_backward(inputs, raw_params)
+        ctx.n_sigmoids, ctx.log_post = n_sigmoids, log_scale_postact
+        return outputs, logabsdet
 
-    return expr
+    @staticmethod
+    def backward(ctx, grad_outputs, grad_logabsdet):
+        inputs, raw_params = ctx.saved_tensors
+        lib = _hip.load()
+        x = _prep_2d(inputs.detach())
+        p = _hip.dev_f32(raw_params.detach(), "raw_params")
+        gy = _hip.dev_f32(grad_outputs if grad_outputs is not None else torch.zeros_like(x), "grad_outputs")
+        gl = None if grad_logabsdet is None else _hip.dev_f32(grad_logabsdet, "grad_logabsdet")
+        n, d = x.shape
+        gx = torch.empty_like(x)
+        gp = torch.empty_like(p)
+        _call("fc_sum_of_sigmoids_backward", lib.fc_sum_of_sigmoids_backward, x.device, _hip.ptr(x), _hip.ptr(p),
+              _hip.ptr(gy), _hip.ptr(gl), _hip.ptr(gx), _hip.ptr(gp), n, d, ctx.n_sigmoids, float(ctx.log_post),
+              _hip.stream_ptr(x.device))
+        return gx, gp.view_as(raw_params), None, None, None
 
 
 def sum_of_sigmoids_autograd(inputs, raw_params, n_sigmoids, inverse=False, offset=0.0, iterations=50, lim=120.0,
                              shared_params=False):
-    """``sum_of_sigmoids``; with autograd on, the kernel's forward sits behind a node whose gradients come from the
-    same map in torch ops, and the inverse goes through ``_inverse_through_forward``."""
+    """``sum_of_sigmoids``; with autograd on, the forward kernel sits behind ``_SoSFunction`` (HIP backward kernel; a
+    batch-shared parameter row is expanded to per-sample rows, autograd sums its gradient), and the inverse goes through
+    ``_inverse_through_forward``."""
     if not (torch.is_grad_enabled() and (inputs.requires_grad or raw_params.requires_grad)):
         return sum_of_sigmoids(inputs, raw_params, n_sigmoids, inverse=inverse, offset=offset, iterations=iterations,
                                lim=lim, shared_params=shared_params)
-    expr = _sos_expression(n_sigmoids, offset)
+    x = _prep_2d(inputs)
 
-    def hip_forward(x, raw):
-        return sum_of_sigmoids(x, raw, n_sigmoids, offset=offset, shared_params=shared_params)
-
-    def forward_fn(x, raw):
-        return _TorchGradFunction.apply(hip_forward, expr, x, raw)
+    def forward_fn(v, raw):
+        rows = raw.reshape(1, -1).expand(v.shape[0], -1) if shared_params else raw.reshape(v.shape[0], -1)
+        return _SoSFunction.apply(v, rows.contiguous(), n_sigmoids, offset, 0.0)
 
     if not inverse:
-        return forward_fn(_prep_2d(inputs), raw_params)
+        return forward_fn(x, raw_params)
     return _inverse_through_forward(
-        forward_fn, lambda x, raw: sum_of_sigmoids(x, raw, n_sigmoids, inverse=True, offset=offset,
+        forward_fn, lambda v, raw: sum_of_sigmoids(v, raw, n_sigmoids, inverse=True, offset=offset,
                                                    iterations=iterations, lim=lim, shared_params=shared_params),
-        _prep_2d(inputs), raw_params)
+        x, raw_params)
 
 
 def sum_of_sigmoids(inputs, raw_params, n_sigmoids, inverse=False, offset=0.0, iterations=50, lim=120.0,

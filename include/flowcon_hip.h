@@ -306,6 +306,14 @@ int fc_sum_of_sigmoids(const float* x, float* y, const float* params, const int3
                        float bisection_lim, float offset, float log_scale_postact,
                        int32_t shared_params, int32_t lad_mode, void* stream);
 
+/* Backward of fc_sum_of_sigmoids in the forward direction, all d columns transformed, per-sample rows (what
+ * torch.autograd yields for adaptive_sigmoids.py:108-142 + nonlinearities.py:519-552): grad_x [n, d] and grad_params
+ * [n, d * (3S + 1)] from grad_y [n, d] and grad_logabsdet [n] (NULL = zeros); closed-form derivatives, the chain through
+ * tanh / sigmoid / the renormalised softmax / softplus included. */
+int fc_sum_of_sigmoids_backward(const float* x, const float* params, const float* grad_y,
+                                const float* grad_logabsdet, float* grad_x, float* grad_params, int64_t n, int32_t d,
+                                int32_t n_sigmoids, float log_scale_postact, void* stream);
+
 /* ---- row-per-wavefront bijectors with dense parameters (d <= 512) ------------------------------ */
 /* K Householder reflections out -= (out.q_k)(2/|q_k|^2) q_k, k = 0..K-1 (reverse != 0: K-1..0).
  * q: [K, d] shared, or [n, K, d] when per_sample != 0.  logabsdet is identically 0.
@@ -320,6 +328,21 @@ int fc_householder(const float* x, float* y, const float* q, int64_t n, int32_t 
  * Replaces PlanarTransform.forward / forward_logabsdet (no_analytic_inv/planar.py:30-49). */
 int fc_planar(const float* x, float* y, float* logabsdet, const float* w, const float* u_hat,
               const float* b, int64_t n, int32_t d, int32_t per_sample, void* stream);
+
+/* Backward of fc_planar with batch-shared parameters (per_sample == 0): grad_x [n, d] is written, grad_w [d],
+ * grad_u_hat [d] and grad_b [1] are ACCUMULATED (atomic adds of per-wave partial sums: zero them first).
+ * grad_logabsdet may be NULL (zeros).  What torch.autograd yields for no_analytic_inv/planar.py:30-49 from u_hat on;
+ * the constraint u -> u_hat stays a host-side torch expression on [1, d]. */
+int fc_planar_backward(const float* x, const float* grad_y, const float* grad_logabsdet, const float* w,
+                       const float* u_hat, const float* b, float* grad_x, float* grad_w, float* grad_u_hat,
+                       float* grad_b, int64_t n, int32_t d, void* stream);
+
+/* Backward of fc_householder with batch-shared q [K, d] (per_sample == 0), from the saved OUTPUT y of the forward
+ * call (each reflection is its own inverse, so the intermediates are recovered by walking back): grad_x [n, d] is
+ * written, grad_q [K, d] is ACCUMULATED (zero it first).  `reverse` as in the forward call.
+ * What torch.autograd yields for orthogonal.py:144-194. */
+int fc_householder_backward(const float* y, const float* grad_y, const float* q, float* grad_x, float* grad_q,
+                            int64_t n, int32_t d, int32_t num_transforms, int32_t reverse, void* stream);
 
 /* Dense linear maps with batch-shared [d, d] matrices given TRANSPOSED (a_t[j*d + i] = A[i][j]).
  * mode 0: y = A x + bias                        (linear.py:45-52 cached weight; bias may be NULL)

@@ -605,3 +605,71 @@ def test_hyper_network_transforms_train(kind, device):
         assert p.grad is not None and maxdiff(p.grad.cpu().double(), p_ref.grad) <= 2e-3 * scale + 1e-6, name
         checked += 1
     assert checked > 0
+
+
+@pytest.mark.parametrize("d,k,reverse", [(6, 3, False), (64, 8, True), (100, 11, False), (200, 17, True), (384, 2, False)])
+def test_householder_backward_kernel_matches_float64_autograd(d, k, reverse, device):
+    """fc_householder_backward (shared q, walks the saved output back through the involutions, more reflections than one
+    register chunk holds) against float64 autograd through the oracle's reflections."""
+    torch.manual_seed(71 + d)
+    n = 777
+    x, q, gy = torch.randn(n, d), torch.randn(k, d), torch.randn(n, d)
+    x64 = x.double().requires_grad_(True)
+    q64 = q.double().requires_grad_(True)
+    y_ref = O.householder_apply(x64, q64.flip(0) if reverse else q64)
+    (y_ref * gy.double()).sum().backward()
+    xg, qg = x.to(device).requires_grad_(True), q.to(device).requires_grad_(True)
+    y, lad = ops.householder_autograd(xg, qg, reverse=reverse)
+    assert type(y.grad_fn).__name__ == "_HouseholderFunctionBackward"
+    (y * gy.to(device)).sum().backward()
+    assert maxdiff(y.detach(), y_ref.detach()) <= 1e-5 * float(y_ref.detach().abs().max()) * k
+    assert float(lad.abs().max()) == 0.0
+    assert maxdiff(xg.grad, x64.grad) <= 2e-5 * float(x64.grad.abs().max()) * k
+    assert maxdiff(qg.grad, q64.grad) <= 2e-5 * float(q64.grad.abs().max()) * k + 1e-5
+
+
+@pytest.mark.parametrize("d", [3, 64, 130, 500])
+def test_planar_backward_kernel_matches_float64_autograd(d, device):
+    """fc_planar_backward against float64 autograd on planar.py:30-49 written out (u_hat given)."""
+    torch.manual_seed(73 + d)
+    n = 1001
+    x = torch.randn(n, d)
+    w, u, b = torch.randn(1, d) / d ** 0.5, torch.randn(1, d) / d ** 0.5, torch.randn(1)
+    gy, gl = torch.randn(n, d), torch.randn(n)
+    leaves = [t.double().clone().requires_grad_(True) for t in (x, w, u, b)]
+    x64, w64, u64, b64 = leaves
+    t = torch.tanh(x64 @ w64.T + b64)
+    y_ref = x64 + u64 * t
+    lad_ref = torch.log(1e-7 + (1 + (u64 @ ((1 - t ** 2) * w64).T)).abs()).reshape(-1)
+    ((y_ref * gy.double()).sum() + (lad_ref * gl.double()).sum()).backward()
+    dev = [t.to(device).requires_grad_(True) for t in (x, w, u, b)]
+    y, lad = ops.planar_autograd(*dev)
+    assert type(y.grad_fn).__name__ == "_PlanarFunctionBackward"
+    ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
+    assert maxdiff(y.detach(), y_ref.detach()) <= 1e-5 * float(y_ref.detach().abs().max())
+    for got, ref, name in zip(dev, leaves, "xwub"):
+        scale = max(1e-5, float(ref.grad.abs().max()))
+        assert maxdiff(got.grad.reshape(ref.grad.shape), ref.grad) <= 1e-4 * scale + 1e-5, name
+    # grad_logabsdet absent (only the outputs feed the loss)
+    dev2 = [t.to(device).requires_grad_(True) for t in (x, w, u, b)]
+    y2, _ = ops.planar_autograd(*dev2)
+    (y2 * gy.to(device)).sum().backward()
+    assert torch.isfinite(dev2[1].grad).all()
+
+
+@pytest.mark.parametrize("s_,d", [(1, 1), (6, 5), (30, 3)])
+def test_sos_backward_kernel_matches_float64_autograd(s_, d, device):
+    """fc_sum_of_sigmoids_backward, per-sample raw rows, against float64 autograd on the oracle's formula."""
+    torch.manual_seed(79 + s_)
+    n = 515
+    x, raw = torch.randn(n, d) * 3, torch.randn(n, d, 3 * s_ + 1)
+    gy, gl = torch.randn(n, d), torch.randn(n)
+    x64, r64 = x.double().requires_grad_(True), raw.double().requires_grad_(True)
+    y_ref, lad_ref = O.sos_forward(x64, r64[..., :s_], r64[..., s_:2 * s_], r64[..., 2 * s_:3 * s_], r64[..., 3 * s_])
+    ((y_ref * gy.double()).sum() + (lad_ref * gl.double()).sum()).backward()
+    xg, rg = x.to(device).requires_grad_(True), raw.to(device).reshape(n, -1).requires_grad_(True)
+    y, lad = ops.sum_of_sigmoids_autograd(xg, rg, s_)
+    ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
+    assert maxdiff(y.detach(), y_ref.detach()) <= 2e-5 * max(1.0, float(y_ref.detach().abs().max()))
+    assert maxdiff(xg.grad, x64.grad) <= 2e-4 * float(x64.grad.abs().max()) + 1e-6
+    assert maxdiff(rg.grad.reshape(r64.grad.shape), r64.grad) <= 2e-4 * float(r64.grad.abs().max()) + 1e-6
