@@ -51,9 +51,6 @@ namespace fc {
 #ifndef FC_HOOK_MASK
 #define FC_HOOK_MASK 0   // sched_barrier mask at each MFMA hook: 0 pins everything
 #endif
-#ifndef FC_CUM_T
-#define FC_CUM_T double   // at::cumsum on the CPU accumulates f32 in double
-#endif
 #define FC_F2 f2
 
 constexpr int kCt3 = 6;                       // 16-feature tiles per wave: 4 dims x 24 padded params
@@ -150,15 +147,32 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
         }
   }
   // bias of lane (s, g), register r of tile t: feature (dim 4w + g, param 4t + r), resident (24 registers).
-  // The width / height logits are divided by sqrt(hidden_features) (coupling.py:565-566); the division is
-  // folded into the fma that also undoes the scaling, so their bias is kept pre-divided.
+  // The width / height logits are divided by sqrt(hidden_features) (coupling.py:565-566) and only ever feed a
+  // softmax, evaluated as exp2 of differences: division and log2(e) are folded into the fma that also undoes the
+  // scaling, so their bias is kept pre-multiplied by log2(e) / sqrt(hidden_features).
+  const float wh_mul = (float)((double)inv_div * 1.4426950408889634);
   f32x4 bw[kCt3];
 #pragma unroll
   for (int t = 0; t < kCt3; ++t) {
     const float* bsrc = a.bias + (4 * (active ? wave : 0) + g) * kPP + 4 * t;
-    const float m = t < 4 ? inv_div : 1.f;   // params 0..15 are widths and heights
+    const float m = t < 4 ? wh_mul : 1.f;   // params 0..15 are widths and heights
     bw[t] = f32x4{bsrc[0] * m, bsrc[1] * m, bsrc[2] * m, bsrc[3] * m};
   }
+  // Knot constants of fc_rq_fused3_eval.inc (x: widths axis, y: heights axis), formed in double once per kernel:
+  // knot_{i+1} = kc_i + (sum of the first i + 1 softmax numerators) * (sc1 / their total) for the lower half, and
+  // kc_i - (sum of the last K - 1 - i numerators) * (sc1 / total) for the upper half.
+  const double span_x = (double)op.q.right - (double)op.q.left, span_y = (double)op.q.top - (double)op.q.bottom;
+  const f2 sc1 = {(float)(span_x * (double)op.q.cw), (float)(span_y * (double)op.q.ch)};
+  auto knot_const = [&](int i) {
+    if (i < kK / 2)
+      return f2{(float)((double)op.q.left + span_x * (double)op.q.min_w * (double)(i + 1)),
+                (float)((double)op.q.bottom + span_y * (double)op.q.min_h * (double)(i + 1))};
+    return f2{(float)((double)op.q.right - span_x * (double)op.q.min_w * (double)(kK - 1 - i)),
+              (float)((double)op.q.top - span_y * (double)op.q.min_h * (double)(kK - 1 - i))};
+  };
+  const f2 kc0 = knot_const(0), kc1 = knot_const(1), kc2 = knot_const(2), kc3 = knot_const(3), kc4 = knot_const(4),
+           kc5 = knot_const(5), kc6 = knot_const(6);
+  static_assert(kK == 8, "kc0 .. kc6: the generated evaluation is for 8 bins");
 
   // Lane-private bin tables (fc_rq_fused3_eval.inc): slots 0 and K are the interval ends / the linear-tail
   // derivative constant (rational_quadratic.py:33-36) and never change; slots 1..K-1 are rewritten per element.
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     float* xr = xbuf + (xb * R + 16 * cblk + s16) * XS + cs[(4 * wave + g) & (kDt - 1)];
     const float x = *xr;
     const float c_d = hscale[xb * R + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
-    const float c_wh = c_d * inv_div;
+    const float c_wh = c_d * wh_mul;        // (c_d is a power of two: the product is exact)
     // h^T fragments are read one group of 6 MFMAs ahead of their use
     f16x8 bcur, bnext = hfrag(hb, pblk, term_h(0), 0);
     auto hook = [&](auto N) {

@@ -1,7 +1,7 @@
 """Generates flowconductor_amd/csrc/fc_rq_fused3_eval.inc: the straight-line RQ-spline evaluation of one
 element in the fused final-Linear + spline kernel (K = 8 bins, linear tails), with the element's 23 raw
 parameters read from the lane's own MFMA accumulators (macros FC_WH(i): width / height logit i < 16, already
-divided by sqrt(hidden_features); FC_UD(j): derivative logit j < 7) and 36 MFMA hook points spread evenly
+divided by sqrt(hidden_features) and multiplied by log2(e); FC_UD(j): derivative logit j < 7) and 36 MFMA hook points spread evenly
 over its instruction stream.  hipcc's sched_group_barrier pipeline clusters about half of the MFMAs,
 so the interleave is explicit in the source: FC_HOOK(n) issues MFMA number n of the NEXT block and pins its
 position with a sched_barrier.
@@ -25,53 +25,48 @@ def add(code, w):
 
 
 add("const bool inside = (x >= q.left) && (x <= q.right);\nconst float xc = inside ? x : q.left;", 3)
-add("const FC_F2 minb = {q.min_w, q.min_h}, c1 = {q.cw, q.ch};\nconst FC_F2 lo = {q.left, q.bottom}, hi = {q.right, q.top};\n"
-    "const FC_F2 span = hi - lo;\nfloat mx = -INFINITY, my = -INFINITY;", 1)
+add("float mx = -INFINITY, my = -INFINITY;", 1)
+# FC_WH(i) hands out the width / height logits in LOG2 units (the kernel folds log2(e) into the constants of the
+# fma that undoes the operand scaling), so exp_softmax(d) is a bare v_exp_f32 of the difference.
 for i in range(K):
     add("FC_F2 t%d = FC_F2{FC_WH(%d), FC_WH(%d)};\nmx = fmaxf(mx, t%d.x);\nmy = fmaxf(my, t%d.y);" % (i, i, K + i, i, i), 3)
 # the derivative logits leave the accumulators early, so the next block's MFMAs can reuse those registers
 for j in range(K - 1):
     add("FC_DER_ST(%d, FC_UD(%d));" % (j + 1, j), 1)
-add("const FC_F2 m = {mx, my};\nFC_F2 sum = {0.f, 0.f};", 0)
-# Software scheduling (the hooks pin the order, so independent work is laid out by hand): all subtractions /
-# multiplications first, then the 16 exponentials, then the running sum -- a dependent instruction is never the
-# next one issued (packed f32 results need a wait state, transcendentals several).
+add("const FC_F2 m = {mx, my};", 0)
+# Software scheduling (the hooks pin the order, so independent work is laid out by hand): all subtractions first,
+# then the 16 exponentials, then the running sum -- a dependent instruction is never the next one issued (packed
+# f32 results need a wait state, transcendentals several).
 for i in range(K):
-    # exp_softmax(d) = exp2(d * log2e): the multiply as one packed op for both axes
     add("t%d = t%d - m;" % (i, i), 1)
 for i in range(K):
-    add("t%d = t%d * FC_F2{1.4426950408889634f, 1.4426950408889634f};" % (i, i), 1)
-for i in range(K):
     add("t%d = FC_F2{__builtin_amdgcn_exp2f(t%d.x), __builtin_amdgcn_exp2f(t%d.y)};" % (i, i, i), 4)
-for i in range(K):
-    add("sum += t%d;" % i, 1)
-add("const float rsx = div_lean(1.f, sum.x);", 5)
-add("const float rsy = div_lean(1.f, sum.y);\nconst FC_F2 rs = {rsx, rsy};", 5)
+# Partial sums of the exponentials, from the left for the lower knots and from the right for the upper ones:
+# l_i = e_0 + .. + e_i (i < K/2), r_i = e_{i+1} + .. + e_{K-1} (i >= K/2), total = l_{K/2-1} + r_{K/2-1}.  The knots
+# are affine in them:
+#   knot_{i+1} = lo + span sum_{j<=i} (min + c1 e_j / total) = kc_i + l_i (span c1 / total)          (i <  K/2)
+#              = hi - span sum_{j>i}  (min + c1 e_j / total) = kc_i - r_i (span c1 / total)          (i >= K/2)
+# with kc_i = lo + span min (i + 1) resp. hi - span min (K - 1 - i) and sc1 = span c1 formed once per kernel (in
+# double): one packed fma per knot pair instead of normalising, offsetting, accumulating and scaling each bin, and
+# every partial sum is at most K/2 - 1 float additions deep and about half of the total in size.  (ATen's cumsum
+# accumulates in double on the CPU and in float on the GPU.)
+H = K // 2
+add("const FC_F2 l0 = t0, r%d = t%d;" % (K - 2, K - 1), 0)
+for i in range(1, H):
+    add("const FC_F2 l%d = l%d + t%d;" % (i, i - 1, i), 1)
+    add("const FC_F2 r%d = r%d + t%d;" % (K - 2 - i, K - 1 - i, K - 1 - i), 1)
+add("const FC_F2 tot = l%d + r%d;" % (H - 1, H - 1), 1)
+add("const float rsx = div_lean(1.f, tot.x);", 5)
+add("const float rsy = div_lean(1.f, tot.y);\nconst FC_F2 gk = sc1 * FC_F2{rsx, rsy};\nint idx = 0;", 6)
 # Bin search without per-knot selects: the interior knots go to a lane-private LDS table as they are produced
 # (slots 0 and K hold the interval ends, written once per kernel), the bin index is a count of compares, and
 # the two knots / two derivative logits of the bin come back with four LDS reads.
-add("FC_CUM_T cx = 0, cy = 0;\nint idx = 0;", 1)
-# bin widths / heights of bins 0..K-2 (the last knot is pinned to the interval end: bin K-1 is never summed),
-# then their conversions, then the two running sums with the knot of step i-1 finished while step i adds
 for i in range(K - 1):
-    add("const FC_F2 pr%d = t%d * rs;" % (i, i), 1)
-for i in range(K - 1):
-    add("const FC_F2 w%d = minb + c1 * pr%d;" % (i, i), 2)
-for i in range(K - 1):
-    add("const FC_CUM_T wx%d = (FC_CUM_T)w%d.x, wy%d = (FC_CUM_T)w%d.y;" % (i, i, i, i), 2)
-
-
-def finish_knot(i):
-    add("const FC_F2 next%d = span * FC_F2{cfx%d, cfy%d} + lo;\nFC_KNOT_ST(%d, next%d);" % (i, i, i, i + 1, i), 2)
+    if i < H:
+        add("const FC_F2 next%d = __builtin_elementwise_fma(l%d, gk, kc%d);\nFC_KNOT_ST(%d, next%d);" % (i, i, i, i + 1, i), 2)
+    else:
+        add("const FC_F2 next%d = __builtin_elementwise_fma(r%d, -gk, kc%d);\nFC_KNOT_ST(%d, next%d);" % (i, i, i, i + 1, i), 2)
     add("idx += (xc >= (kInv ? next%d.y : next%d.x)) ? 1 : 0;" % (i, i), 2)
-
-
-for i in range(K - 1):
-    add("cx += wx%d;\ncy += wy%d;" % (i, i), 2)
-    add("const float cfx%d = (float)cx, cfy%d = (float)cy;" % (i, i), 2)
-    if i > 0:
-        finish_knot(i - 1)
-finish_knot(K - 2)
 add("const FC_F2 sel_lo = FC_KNOT_LD(idx, 0), sel_hi = FC_KNOT_LD(idx, 1);\n"
     "const float u0 = FC_DER_LD(idx, 0), u1 = FC_DER_LD(idx, 1);", 3)
 add("const float xk = sel_lo.x, yk = sel_lo.y;\nconst float wk = sel_hi.x - sel_lo.x, hk = sel_hi.y - sel_lo.y;", 2)
@@ -125,8 +120,9 @@ total = sum(w for _, w in chunks)
 out = ["// GENERATED by tools/gen_fused_eval.py -- do not edit by hand.",
        "// Straight-line RQ-spline evaluation (K = %d, linear tails) of one element with %d MFMA hook points." % (K, HOOKS),
        "// Expects in scope: FC_WH(i) / FC_UD(j) (logits of the element), FC_KNOT_ST / FC_KNOT_LD / FC_DER_ST / FC_DER_LD",
-       "// (lane-private LDS tables of K + 1 knots and K + 1 derivative logits), FC_F2, FC_CUM_T, x, q, inv_beta, err,",
-       "// kInv (constexpr bool), outputs y / lad, and FC_HOOK(n)."]
+       "// (lane-private LDS tables of K + 1 knots and K + 1 derivative logits), FC_F2, x, q, inv_beta, err, the knot",
+       "// constants sc1, kc0 .. kc%d (FC_F2: x = widths axis, y = heights axis), kInv (constexpr bool), outputs y / lad," % (K - 2),
+       "// and FC_HOOK(n).  FC_WH(i) is expected in log2 units (logit * log2(e))."]
 # hook placement: hook k sits where the accumulated weight passes (k + 1 - SHIFT) / HOOKS of the total
 # (FC_GEN_SHIFT: probe knob for tools/probe/search_hooks.sh; the committed file uses 0)
 SHIFT = float(os.environ.get("FC_GEN_SHIFT", "0"))
