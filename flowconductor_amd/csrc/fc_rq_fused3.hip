@@ -110,6 +110,10 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   // ---- resident weights ---------------------------------------------------------------------------------
   // A operand of tile t, k-step ks: lane holds W[row(t, lane & 15)][k = 32 ks + 8 (lane >> 4) + j], j < 8,
   // where row(t, rho) = padded feature (dim 4w + (rho >> 2)) * 24 + 4t + (rho & 3).
+  // Accumulator slot 4t + r of a lane holds parameter slot_param(4t + r) of its element: width and height logit i sit
+  // in the adjacent slots 2i, 2i + 1, so the packed (width, height) arithmetic of the evaluation reads register pairs
+  // as they are (with the natural order the compiler assembles every pair with two moves).
+  constexpr auto slot_param = [](int s) { return s < 16 ? ((s & 1) ? 8 + (s >> 1) : (s >> 1)) : s; };
   f16x8 wh[kCt3][2], wl[kCt3][2];
   float w_unscale;
   {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     float wmax = 0.f;
 #pragma unroll
     for (int t = 0; t < kCt3; ++t) {
-      const int row = (4 * (active ? wave : 0) + (s16 >> 2)) * kPP + 4 * t + (s16 & 3);
+      const int row = (4 * (active ? wave : 0) + (s16 >> 2)) * kPP + slot_param(4 * t + (s16 & 3));
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const float4* src = reinterpret_cast<const float4*>(a.wpad + (int64_t)row * kH + 32 * ks + 8 * g);
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   for (int t = 0; t < kCt3; ++t) {
     const float* bsrc = a.bias + (4 * (active ? wave : 0) + g) * kPP + 4 * t;
     const float m = t < 4 ? wh_mul : 1.f;   // params 0..15 are widths and heights
-    bw[t] = f32x4{bsrc[0] * m, bsrc[1] * m, bsrc[2] * m, bsrc[3] * m};
+    bw[t] = f32x4{bsrc[slot_param(4 * t) - 4 * t] * m, bsrc[slot_param(4 * t + 1) - 4 * t] * m,
+                  bsrc[slot_param(4 * t + 2) - 4 * t] * m, bsrc[slot_param(4 * t + 3) - 4 * t] * m};
   }
   // Knot constants of fc_rq_fused3_eval.inc (x: widths axis, y: heights axis), formed in double once per kernel:
   // knot_{i+1} = kc_i + (sum of the first i + 1 softmax numerators) * (sc1 / their total) for the lower half, and
@@ -294,7 +299,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     __builtin_amdgcn_s_setprio(3);
     __builtin_amdgcn_sched_barrier(0);
 #define FC_HOOK(n) hook(std::integral_constant<int, n>{});
-#define FC_WH(i) __builtin_fmaf(pa[(i) >> 2][(i) & 3], c_wh, bw[(i) >> 2][(i) & 3])
+#define FC_WH_SLOT(i) ((i) < 8 ? 2 * (i) : 2 * ((i) - 8) + 1)
+#define FC_WH(i) __builtin_fmaf(pa[FC_WH_SLOT(i) >> 2][FC_WH_SLOT(i) & 3], c_wh, bw[FC_WH_SLOT(i) >> 2][FC_WH_SLOT(i) & 3])
 #define FC_UD(j) __builtin_fmaf(pa[((j) + 16) >> 2][((j) + 16) & 3], c_d, bw[((j) + 16) >> 2][((j) + 16) & 3])
 #define FC_KNOT_ST(slot, v) *reinterpret_cast<f2*>(ktab + (slot) * 128) = (v)
 #define FC_KNOT_LD(i, off) *reinterpret_cast<const f2*>(ktab + ((i) + (off)) * 128)
@@ -313,6 +319,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #undef FC_KNOT_ST
 #undef FC_UD
 #undef FC_WH
+#undef FC_WH_SLOT
 #undef FC_HOOK
     if (dim_ok) *xr = y;
     // logabsdet partial of this wave's 4 dims: lanes s, s+16, s+32, s+48 hold the same sample

@@ -1,5 +1,5 @@
 """In-kernel clock of the fused kernel: needs a probe build with FC_ABL & 16
-(tools/probe/build_fused_variants.sh 16; FLOWCON_HIP_LIB=tools/probe/build/libfc_abl16.so)."""
+(tools/probe/build_fused_variants.sh 16; python tools/probe/fused_clock.py --lib tools/probe/build/libfc_abl16.so)."""
 import os
 import sys
 import time
@@ -8,7 +8,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from flowconductor_amd import ops  # noqa: E402
+from flowconductor_amd import ops, _hip  # noqa: E402
+
+if "--lib" in sys.argv:
+    _hip.use_library(sys.argv[sys.argv.index("--lib") + 1])
 
 n, d, d_t, k = 1 << 20, 64, 32, 8
 dev = torch.device("cuda:0")
