@@ -6,13 +6,19 @@
 namespace fc {
 
 // max over the 16 lanes of a DPP row (lanes 16r .. 16r+15); every lane of the row gets the result
+// (v_max_f32 with a DPP operand, one instruction per step; written as asm because the builtin route costs a zeroing
+// move, a DPP move, a canonicalising max and the max itself per step.  The s_nop 1 is the VALU-write -> DPP-read
+// hazard the compiler cannot see inside an asm block.)
 __device__ __forceinline__ float row16_allmax(float m) {
-#define FC_ROR(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x120 + (n), 0xf, 0xf, false))
-  m = fmaxf(m, FC_ROR(8));
-  m = fmaxf(m, FC_ROR(4));
-  m = fmaxf(m, FC_ROR(2));
-  m = fmaxf(m, FC_ROR(1));
-#undef FC_ROR
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf"
+      : "+v"(m));
   return m;
 }
 

@@ -52,6 +52,9 @@ namespace fc {
 #define FC_HOOK_MASK 0   // sched_barrier mask at each MFMA hook: 0 pins everything
 #endif
 #define FC_F2 f2
+#ifndef FC_PRIO_PERIOD
+#define FC_PRIO_PERIOD 36   // hooks per priority sawtooth of 4 levels (measured: 4, 8 slower; 12 +1.2 %; 36 = 72; 144 slower)
+#endif
 
 constexpr int kCt3 = 6;                       // 16-feature tiles per wave: 4 dims x 24 padded params
 constexpr int kHB = kH + 8;                   // f16 per h row in LDS (144 B: conflict-free b128 reads)
@@ -290,7 +293,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
       // wave: left alone, waves 0-3 run each step unimpeded, wait ~3700 cycles per tile at the barriers, and
       // waves 4-7 finish alone at single-wave issue rate.  A priority that falls as a wave advances (a
       // sawtooth over 12 hooks) always favours the wave that is behind, so both reach the barrier together.
-      if constexpr (n % 3 == 2) __builtin_amdgcn_s_setprio(3 - ((n + 1) % 12) / 3);
+      if constexpr (n % (FC_PRIO_PERIOD / 4) == FC_PRIO_PERIOD / 4 - 1)
+        __builtin_amdgcn_s_setprio(3 - ((n + 1) % FC_PRIO_PERIOD) / (FC_PRIO_PERIOD / 4));
       __builtin_amdgcn_sched_barrier(FC_HOOK_MASK);
     };
     const RQParams& q = op.q;

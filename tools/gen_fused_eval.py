@@ -75,19 +75,18 @@ add("const float rwk = __builtin_amdgcn_rcpf(wk);\nconst float dq = hk * rwk;\n"
     "const float delta = __builtin_fmaf(__builtin_fmaf(-wk, dq, hk), rwk, dq);", 5)
 add("float theta;\nif constexpr (!kInv) {\n  const float tq = (xc - xk) * rwk;\n"
     "  theta = __builtin_fmaf(__builtin_fmaf(-wk, tq, xc - xk), rwk, tq);\n}", 4)
-# two softplus evaluations (softplus_lean_sel of fc_math.h), written out so hooks can sit inside them
+# Two softplus evaluations, written out so hooks can sit inside them.  exp(x) = exp2(x log2e) and log(u) = log2(u) ln2
+# without the hi / lo compensation of exp_lean / log_lean: the relative error of the derivative grows by <= 4e-8 |x|
+# (<= 2e-7 over the range where the softplus is not yet linear), measured effect on the kernel's logabsdet error
+# against float64 in tools/probe/fused_accuracy.py.
 for n in (0, 1):
-    add("const float xb%d = u%d * q.beta;\nconst float xm%d = fminf(xb%d, 20.f);\nconst float e%d_hi = xm%d * 1.4426950216293335f;"
-        % (n, n, n, n, n, n), 3)
-    add("float e%d_lo = __builtin_fmaf(xm%d, 1.4426950216293335f, -e%d_hi);\n"
-        "e%d_lo = __builtin_fmaf(xm%d, 1.925963033500011e-8f, e%d_lo);" % (n, n, n, n, n, n), 2)
-    add("const float ex%d_0 = __builtin_amdgcn_exp2f(e%d_hi);\nconst float ex%d = __builtin_fmaf(ex%d_0, e%d_lo * 0.6931471805599453f, ex%d_0);"
-        % (n, n, n, n, n, n), 4)
+    add("const float xb%d = u%d * q.beta;\nconst float xm%d = fminf(xb%d, 20.f);\n"
+        "const float ex%d = __builtin_amdgcn_exp2f(xm%d * 1.4426950408889634f);" % (n, n, n, n, n, n), 7)
     # log1p(e) = log(u) + (e - (u - 1)) / u with u = fl(1 + e): the second term restores what the rounding of
     # 1 + e lost (|.| <= 2^-24, so a plain v_rcp is accurate enough for it); no special case for tiny e
     add("const float up%d = 1.f + ex%d;\nconst float rr%d = ex%d - (up%d - 1.f);" % (n, n, n, n, n), 3)
-    add("const float lg%d = log_lean(up%d);" % (n, n), 5)
-    add("const float l1p%d = lg%d + rr%d * __builtin_amdgcn_rcpf(up%d);" % (n, n, n, n), 3)
+    add("const float l1p%d = __builtin_fmaf(__builtin_amdgcn_logf(up%d), 0.6931471805599453f, rr%d * __builtin_amdgcn_rcpf(up%d));"
+        % (n, n, n, n), 10)
     add("const float d%d = q.min_d + (xb%d > 20.f ? u%d : l1p%d * inv_beta);" % (n, n, n, n), 3)
 add("const float dsum = d0 + d1 - 2.f * delta;", 3)
 add("""if constexpr (kInv) {
@@ -102,11 +101,9 @@ add("""if constexpr (kInv) {
 add("const float t1mt = theta * (1.f - theta);\nconst float den = delta + dsum * t1mt;", 4)
 add("const float omt = 1.f - theta;\nconst float dn1 = d1 * (theta * theta) + 2.f * delta * t1mt;", 5)
 add("const float dnum = (delta * delta) * (dn1 + d0 * (omt * omt));", 4)
-# log(dnum) - 2 log(den) = ln2 (log2 dnum - 2 log2 den): one compensated multiplication by ln2 (hi / lo split as
-# in log_lean) instead of two
+# log(dnum) - 2 log(den) = ln2 (log2 dnum - 2 log2 den)
 add("const float l2v = __builtin_fmaf(-2.f, __builtin_amdgcn_logf(den), __builtin_amdgcn_logf(dnum));", 3)
-add("const float l2h = l2v * 0.6931471824645996f;\n"
-    "const float lval = l2h + __builtin_fmaf(l2v, -1.904654323148236e-9f, __builtin_fmaf(l2v, 0.6931471824645996f, -l2h));", 4)
+add("const float lval = l2v * 0.6931471805599453f;", 1)
 add("""float ys;
 if constexpr (!kInv) {
   const float num = hk * (delta * (theta * theta) + d0 * t1mt);
