@@ -64,6 +64,10 @@ struct HiddenArgs {
   int C;                  // context features (<= 32), 0 without context
   int act;                // FC_ACT_* (kAct == 1 kernels only; kAct == 0 is ReLU)
   float act_param;        // ELU alpha / LeakyReLU negative slope
+  // fc_resnet_hidden_packed: the LDS weight image made ahead of time (fc_pack_fragments, FC_PACK_HIDDEN jobs), or null
+  const f16x8* image;     // [layer][ks][t][piece][lane] fragments = the layout of `wfrag` below
+  const float* image_un;  // [layers] 2^-S of every layer
+  const float* image_bias; // [layers][64] biases in accumulator order
 };
 
 // feature held by accumulator tile t, register r of a lane in group g
@@ -86,10 +90,13 @@ struct HiddenLds {
 };
 
 // kAct: 0 = ReLU (the north-star conditioner; nothing but a v_max), 1 = the activation named by a.act
-template <int NB, int K0S, int kCtx, int kAct>
-__global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(HiddenArgs a) {
+// BPW: 16-sample blocks a wave pushes through the layers together.  Every layer's weight fragments (16 KB per wave) come
+// from LDS once per group of BPW blocks; at one block per wave the 16 waves of a CU ask the LDS pipe for as many cycles
+// as their matrix and vector instructions take to issue, and the reads sit right before the MFMAs that need them.
+template <int NB, int K0S, int kCtx, int kAct, int BPW>
+__global__ __launch_bounds__(512, (kCtx || BPW > 1) ? 2 : 4) void resnet_hidden_kernel(HiddenArgs a) {
   using L = HiddenLds<NB, K0S, kCtx>;
-  constexpr bool kPrefetchX = FC_HIDDEN_PREFETCH_X && (K0S == 1 || kCtx != 0);   // (16 more live registers spill in the 64-input kernels without a context: 128-register budget)
+  constexpr bool kPrefetchX = FC_HIDDEN_PREFETCH_X && (K0S == 1 || kCtx != 0 || BPW > 1);   // (16 more live registers spill in the 64-input kernels without a context at one block per wave: 128-register budget)
   extern __shared__ __attribute__((aligned(16))) unsigned char hsmem[];
   f16x8* wfrag = reinterpret_cast<f16x8*>(hsmem);
   float* bias = reinterpret_cast<float*>(hsmem + (size_t)L::kFrags * 64 * 16);   // [layer][g][16]
@@ -100,11 +107,25 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s16 = lane & 15, g = lane >> 4;
   const int k0 = a.k0, D = a.D, C = kCtx ? a.C : 0;
+#ifdef FC_HID_STAMP
+  const uint64_t stamp_entry = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- once per workgroup: scale, split and lay out the weights -----------------------------------
   // operand column i of the initial layer: identity column of x (>= 0), context feature -2 - j, or padding (-1)
   const int C0 = kCtx == 1 ? C : 0;   // context features concatenated into the initial layer (ResidualNet form only)
   for (int i = tid; i < 32 * K0S; i += kHidThreads) ids[i] = i < k0 ? a.id_cols[i] : (i < k0 + C0 ? -2 - (i - k0) : -1);
+  if (kCtx == 0 && a.image) {
+    // ready-made image: straight into LDS (1 KiB per wave instruction), no arithmetic, one barrier.  Building it
+    // here from the f32 weights costs ~34 000 cycles per launch (two rounds of loads, the split, two barriers).
+    for (int f = wave; f < L::kFrags; f += kHidThreads / 64)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.image + (size_t)f * 64 + lane),
+                                       (__attribute__((address_space(3))) void*)(wfrag + f * 64), 16, 0, 0);
+    for (int i = tid; i < L::kLayers * 64; i += kHidThreads) bias[i] = a.image_bias[i];
+    if (tid < L::kLayers) wun[tid] = a.image_un[tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else {
   // Two rounds of global loads for ALL layers together (maxima, then fragments) with one barrier pair between them:
   // layer by layer the dependent load latencies and barriers of 5-13 layers cost ~15 us per launch.
   auto layer_src = [&](int l, const float*& w, const float*& b, int& kin, int& nks, int& base) {
@@ -194,6 +215,7 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
     }
   }
   __syncthreads();
+  }   // weights built in the kernel
 
   // the blocks' activation (resnet.py:42,46) on a lane's 16 values: ReLU, or what the module was built with (one
   // uniform switch per site, a straight 16-element loop inside each case)
@@ -239,10 +261,13 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
       }
     return un;
   };
-  // acc = (scaled W_l) (scaled act)^T : three split terms, small ones first
-  auto layer = [&](int base, int nks, const f16x8 (&bh)[2], const f16x8 (&bl)[2], f32x4 (&acc)[4]) {
+  // acc[b] = (scaled W_l) (scaled act_b)^T for the BPW sample blocks of this wave: three split terms, small ones
+  // first; every weight fragment is read from LDS once and serves all blocks
+  auto layer = [&](int base, int nks, const f16x8 (&bh)[BPW][2], const f16x8 (&bl)[BPW][2], f32x4 (&acc)[BPW][4]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < BPW; ++b)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f16x8* wf = wfrag + base * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -251,7 +276,9 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
 #pragma unroll
         for (int t = 0; t < 4; ++t) wl[t] = wf[((ks * 4 + t) * 2 + 1) * 64];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh[ks], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int b = 0; b < BPW; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh[b][ks], acc[b][t], 0, 0, 0);
       }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -261,9 +288,13 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
         for (int t = 0; t < 4; ++t) wh[t] = wf[((ks * 4 + t) * 2 + 0) * 64];
         // consecutive MFMAs go to different accumulators
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl[ks], acc[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh[ks], acc[t], 0, 0, 0);
+          for (int b = 0; b < BPW; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl[b][ks], acc[b][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int b = 0; b < BPW; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh[b][ks], acc[b][t], 0, 0, 0);
       }
   };
   // Linear output of layer l: undo both scalings and add the bias in one fma (one rounding, as the GEMM's
@@ -307,125 +338,173 @@ __global__ __launch_bounds__(512, kCtx ? 2 : 4) void resnet_hidden_kernel(Hidden
         xv[t][r] = v;
       }
   };
-  const int64_t blk0 = (int64_t)blockIdx.x * (kHidThreads / 64) + wave;
-  f32x4 xpre[kPrefetchX ? 4 : 1];       // the next block's rows, one iteration ahead
+  // A wave walks groups of BPW consecutive 16-sample blocks; a group that reaches past the end repeats the last
+  // block (computed twice, stored once).
+  const int64_t groups = (a.blocks16 + BPW - 1) / BPW;
+  const int64_t grp0 = (int64_t)blockIdx.x * (kHidThreads / 64) + wave;
+  auto block_of = [&](int64_t grp, int b) {
+    const int64_t blk = grp * BPW + b;
+    return blk < a.blocks16 ? blk : a.blocks16 - 1;
+  };
+  f32x4 xpre[kPrefetchX ? BPW : 1][kPrefetchX ? 4 : 1];       // the next group's rows, one iteration ahead
   if constexpr (kPrefetchX) {
-    if (blk0 < a.blocks16) gather(blk0, xpre);
+    if (grp0 < groups) {
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) gather(block_of(grp0, b), xpre[b]);
+    }
   }
-  for (int64_t blk = blk0; blk < a.blocks16; blk += nwaves) {
+#define FC_EACH_BLOCK _Pragma("unroll") for (int b = 0; b < BPW; ++b)
+#ifdef FC_HID_STAMP   // probe builds only (tools/probe/hidden_clock.py): cycles a wave spends in its loop
+  const uint64_t stamp0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int64_t grp = grp0; grp < groups; grp += nwaves) {
     // the weight fragments are loop-invariant LDS loads: without this fence the compiler hoists all of them
     // out of the loop and spills
     asm volatile("" ::: "memory");
-    const float* crow = kCtx ? a.ctx + (blk * 16 + s16) * C : nullptr;
-    f32x4 xin[4];
-    if constexpr (kPrefetchX) {
+    f32x4 xin[BPW][4];
+    FC_EACH_BLOCK {
+      if constexpr (kPrefetchX) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) xin[t] = xpre[t];
-    } else {
-      gather(blk, xin);
+        for (int t = 0; t < 4; ++t) xin[b][t] = xpre[b][t];
+      } else {
+        gather(block_of(grp, b), xin[b]);
+      }
     }
-    f16x8 bh[2], bl[2];
-    f32x4 acc[4], h[4], tmid[4];
+    f16x8 bh[BPW][2], bl[BPW][2];
+    f32x4 acc[BPW][4], h[BPW][4], tmid[BPW][4];
+    float un[BPW];
     // context row as the B operand of the gate products: lane (s, g) supplies features 8g..8g+7 of sample s; split
     // once per 16-sample block, used by every residual block.  (With a context the weight image, 96 KB at 2 blocks,
     // allows one 8-wave workgroup per CU: 256 registers per wave, these 9 stay live for free.  12- and 16-wave
     // workgroups sharing the image were tried: the compiler spills at 168 / 128 registers and they run 15 % slower.)
-    f16x8 ch[2] = {}, cl[2] = {};
-    float unc = 1.f;
+    f16x8 ch[BPW][2] = {}, cl[BPW][2] = {};
+    float unc[BPW];
+    FC_EACH_BLOCK unc[b] = 1.f;
     if constexpr (kCtx) {
-      float cv[8], m = 0.f;
+      FC_EACH_BLOCK {
+        const float* crow = a.ctx + (block_of(grp, b) * 16 + s16) * C;
+        float cv[8], m = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = 8 * g + j;
-        cv[j] = crow[k < C ? k : 0];
-        cv[j] = k < C ? cv[j] : 0.f;
-        m = fmaxf(m, fabsf(cv[j]));
-      }
-      m = rows4_allmax(m, lane);
-      float sc;
-      pow2_scale(m, sc, unc);
+        for (int j = 0; j < 8; ++j) {
+          const int k = 8 * g + j;
+          cv[j] = crow[k < C ? k : 0];
+          cv[j] = k < C ? cv[j] : 0.f;
+          m = fmaxf(m, fabsf(cv[j]));
+        }
+        m = rows4_allmax(m, lane);
+        float sc;
+        pow2_scale(m, sc, unc[b]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        _Float16 ph, pl;
-        split2(cv[j] * sc, ph, pl);
-        ch[0][j] = ph;
-        cl[0][j] = pl;
+        for (int j = 0; j < 8; ++j) {
+          _Float16 ph, pl;
+          split2(cv[j] * sc, ph, pl);
+          ch[b][0][j] = ph;
+          cl[b][0][j] = pl;
+        }
       }
     }
-    float un = make_operand(xin, bh, bl);
-    // the next block's rows are requested now and consumed an iteration later (a wave otherwise starts every block
+    FC_EACH_BLOCK un[b] = make_operand(xin[b], bh[b], bl[b]);
+    // the next group's rows are requested now and consumed an iteration later (a wave otherwise starts every group
     // with an exposed memory latency)
     if constexpr (kPrefetchX) {
-      const int64_t nxt = blk + nwaves < a.blocks16 ? blk + nwaves : blk;
-      gather(nxt, xpre);
+      const int64_t nxt = grp + nwaves < groups ? grp + nwaves : grp;
+      FC_EACH_BLOCK gather(block_of(nxt, b), xpre[b]);
     }
     layer(0, K0S, bh, bl, acc);
-    finish(0, un, acc, h);
+    FC_EACH_BLOCK finish(0, un[b], acc[b], h[b]);
     if constexpr (kCtx == 2) {
       // made.py:243-244: temps = initial_layer(inputs) + activation(context_layer(context))
-      f32x4 cpre[4], cact[4];
       layer(L::kFragsMain, 1, ch, cl, acc);
-      finish(L::kMain, unc, acc, cpre);
-      activate16(cpre, cact);
+      FC_EACH_BLOCK {
+        f32x4 cpre[4], cact[4];
+        finish(L::kMain, unc[b], acc[b], cpre);
+        activate16(cpre, cact);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[t][r] += cact[t][r];
+          for (int r = 0; r < 4; ++r) h[b][t][r] += cact[t][r];
+      }
     }
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      f32x4 act[4];
-      activate16(h, act);
-      un = make_operand(act, bh, bl);
-      layer(L::kFrag0 + (2 * b) * L::kFragL, 2, bh, bl, acc);
-      finish(1 + 2 * b, un, acc, tmid);
+    for (int nb = 0; nb < NB; ++nb) {
+      FC_EACH_BLOCK {
+        f32x4 act[4];
+        activate16(h[b], act);
+        un[b] = make_operand(act, bh[b], bl[b]);
+      }
+      layer(L::kFrag0 + (2 * nb) * L::kFragL, 2, bh, bl, acc);
+      FC_EACH_BLOCK finish(1 + 2 * nb, un[b], acc[b], tmid[b]);
       if constexpr (kCtx == 2) {
         // made.py:131-132: temps = linear_layers[0](...) + context_layer(context)
-        f32x4 cpre[4];
-        layer(L::kFragsMain + (1 + b) * L::kFragG, 1, ch, cl, acc);
-        finish(L::kMain + 1 + b, unc, acc, cpre);
+        layer(L::kFragsMain + (1 + nb) * L::kFragG, 1, ch, cl, acc);
+        FC_EACH_BLOCK {
+          f32x4 cpre[4];
+          finish(L::kMain + 1 + nb, unc[b], acc[b], cpre);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+          for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) tmid[t][r] += cpre[t][r];
+            for (int r = 0; r < 4; ++r) tmid[b][t][r] += cpre[t][r];
+        }
       }
-      activate16(tmid, act);
-      un = make_operand(act, bh, bl);
-      layer(L::kFrag0 + (2 * b + 1) * L::kFragL, 2, bh, bl, acc);
-      finish(2 + 2 * b, un, acc, tmid);
+      FC_EACH_BLOCK {
+        f32x4 act[4];
+        activate16(tmid[b], act);
+        un[b] = make_operand(act, bh[b], bl[b]);
+      }
+      layer(L::kFrag0 + (2 * nb + 1) * L::kFragL, 2, bh, bl, acc);
+      FC_EACH_BLOCK finish(2 + 2 * nb, un[b], acc[b], tmid[b]);
       if constexpr (kCtx == 1) {
         // resnet.py:48-49: temps = glu(cat(temps, context_layer(context))) = temps * sigmoid(Wc c + bc)
-        f32x4 gpre[4];
-        layer(L::kFragsMain + b * L::kFragG, 1, ch, cl, acc);
-        finish(L::kMain + b, unc, acc, gpre);
+        layer(L::kFragsMain + nb * L::kFragG, 1, ch, cl, acc);
+        FC_EACH_BLOCK {
+          f32x4 gpre[4];
+          finish(L::kMain + nb, unc[b], acc[b], gpre);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              tmid[b][t][r] *= __builtin_amdgcn_rcpf(1.f + exp_lean(fminf(-gpre[t][r], 87.f)));   // sigmoid, ~1 ulp
+        }
+      }
+      FC_EACH_BLOCK {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            tmid[t][r] *= __builtin_amdgcn_rcpf(1.f + exp_lean(fminf(-gpre[t][r], 87.f)));   // sigmoid, ~1 ulp
+          for (int r = 0; r < 4; ++r) h[b][t][r] += tmid[b][t][r];   // resnet.py:52 `inputs + temps`
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[t][r] += tmid[t][r];   // resnet.py:52 `inputs + temps`
     }
     // lane (s, g) holds features 8g..8g+7 (tiles 0, 1) and 32+8g..32+8g+7 (tiles 2, 3) of sample s
-    float4* hrow = reinterpret_cast<float4*>(a.h + (blk * 16 + s16) * kHid);
-    hrow[2 * g] = float4{h[0][0], h[0][1], h[0][2], h[0][3]};
-    hrow[2 * g + 1] = float4{h[1][0], h[1][1], h[1][2], h[1][3]};
-    hrow[8 + 2 * g] = float4{h[2][0], h[2][1], h[2][2], h[2][3]};
-    hrow[8 + 2 * g + 1] = float4{h[3][0], h[3][1], h[3][2], h[3][3]};
+    FC_EACH_BLOCK {
+      const int64_t blk = grp * BPW + b;
+      if (blk < a.blocks16) {
+        float4* hrow = reinterpret_cast<float4*>(a.h + (blk * 16 + s16) * kHid);
+        hrow[2 * g] = float4{h[b][0][0], h[b][0][1], h[b][0][2], h[b][0][3]};
+        hrow[2 * g + 1] = float4{h[b][1][0], h[b][1][1], h[b][1][2], h[b][1][3]};
+        hrow[8 + 2 * g] = float4{h[b][2][0], h[b][2][1], h[b][2][2], h[b][2][3]};
+        hrow[8 + 2 * g + 1] = float4{h[b][3][0], h[b][3][1], h[b][3][2], h[b][3][3]};
+      }
+    }
   }
+#ifdef FC_HID_STAMP
+  if (lane == 0 && grp0 < groups) {
+    float* dst = a.h + (grp0 * BPW * 16) * kHid;
+    dst[0] = (float)(__builtin_amdgcn_s_memtime() - stamp0);
+    dst[1] = (float)((groups - grp0 + nwaves - 1) / nwaves * BPW);   // blocks this wave walked
+    dst[2] = (float)(stamp0 - stamp_entry);                          // prologue, cycles
+    dst[3] = (float)(__builtin_amdgcn_s_memrealtime() - stamp_r0);   // the loop in 10 ns ticks
+  }
+#endif
+#undef FC_EACH_BLOCK
 }
 
-template <int NB, int K0S, int kCtx, int kAct>
+template <int NB, int K0S, int kCtx, int kAct, int BPW>
 hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
   using L = HiddenLds<NB, K0S, kCtx>;
   static PerDeviceOnce attr;
   const hipError_t ea = ensure_max_dynamic_lds(
-      attr, reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx, kAct>), 160 * 1024);
+      attr, reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx, kAct, BPW>), 160 * 1024);
   if (ea != hipSuccess) return ea;
-  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S, kCtx, kAct>), dim3((unsigned)grid), dim3(kHidThreads), L::kBytes,
+  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S, kCtx, kAct, BPW>), dim3((unsigned)grid), dim3(kHidThreads), L::kBytes,
                      s, a);
   return hipGetLastError();
 }
@@ -433,28 +512,48 @@ hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
 template <int kCtx, int kAct>
 hipError_t dispatch_hidden(const HiddenArgs& a, int num_blocks, hipStream_t s) {
   const int cus = device_cu_count();
-  // two 512-thread workgroups per CU when two weight images fit in LDS (<= 2 blocks at <= 32 inputs, no
-  // context), else one
   const bool wide = a.k0 + (kCtx == 1 ? a.C : 0) > 32;
+  // One block per wave, two 512-thread workgroups per CU when two weight images fit in LDS (<= 2 blocks at <= 32
+  // inputs, no context).  Two blocks per wave (BPW = 2: one workgroup per CU, 206 registers, half the LDS fragment
+  // reads) measured slower in the loop -- 7 110 cycles per block and wave at two waves per SIMD against 12 510 at four,
+  // i.e. 3 555 against 3 128 per SIMD (tools/probe/hidden_clock.py) -- so it is built for probes only.
+#ifdef FC_HID_FORCE_BPW
+  constexpr bool kPairs = kCtx == 0 && kAct == 0;
+  const bool pairs = kPairs && FC_HID_FORCE_BPW == 2;
+#else
+  const bool pairs = false;
+#endif
   const size_t frags = (size_t)(wide ? 16 : 8) + (size_t)num_blocks * (2 * 16 + (kCtx ? 8 : 0));   // 1 KB each
-  int64_t grid = (int64_t)cus * (!kCtx && frags * 1024 + 2048 <= 80 * 1024 ? 2 : 1);
-  const int64_t need = (a.blocks16 + 7) / 8;
+  int64_t grid = (int64_t)cus * (!pairs && !kCtx && frags * 1024 + 2048 <= 80 * 1024 ? 2 : 1);
+  const int64_t need = ((pairs ? (a.blocks16 + 1) / 2 : a.blocks16) + 7) / 8;
   if (grid > need) grid = need;
+#ifdef FC_HID_FORCE_BPW
+#define FC_HIDDEN_CASE(NB_, K0S_)                                                            \
+  do {                                                                                       \
+    if constexpr (kPairs) {                                                                  \
+      if (pairs) return launch_hidden<NB_, K0S_, kCtx, kAct, 2>(a, grid, s);                 \
+    }                                                                                        \
+    return launch_hidden<NB_, K0S_, kCtx, kAct, 1>(a, grid, s);                              \
+  } while (0)
+#else
+#define FC_HIDDEN_CASE(NB_, K0S_) return launch_hidden<NB_, K0S_, kCtx, kAct, 1>(a, grid, s)
+#endif
   switch (num_blocks * 2 + (wide ? 1 : 0)) {
-    case 0: return launch_hidden<0, 1, kCtx, kAct>(a, grid, s);
-    case 1: return launch_hidden<0, 2, kCtx, kAct>(a, grid, s);
-    case 2: return launch_hidden<1, 1, kCtx, kAct>(a, grid, s);
-    case 3: return launch_hidden<1, 2, kCtx, kAct>(a, grid, s);
-    case 4: return launch_hidden<2, 1, kCtx, kAct>(a, grid, s);
-    case 5: return launch_hidden<2, 2, kCtx, kAct>(a, grid, s);
-    case 6: return launch_hidden<3, 1, kCtx, kAct>(a, grid, s);
-    case 7: return launch_hidden<3, 2, kCtx, kAct>(a, grid, s);
+    case 0: FC_HIDDEN_CASE(0, 1);
+    case 1: FC_HIDDEN_CASE(0, 2);
+    case 2: FC_HIDDEN_CASE(1, 1);
+    case 3: FC_HIDDEN_CASE(1, 2);
+    case 4: FC_HIDDEN_CASE(2, 1);
+    case 5: FC_HIDDEN_CASE(2, 2);
+    case 6: FC_HIDDEN_CASE(3, 1);
+    case 7: FC_HIDDEN_CASE(3, 2);
     default: break;
   }
   if constexpr (!kCtx) {
-    if (wide) return launch_hidden<4, 2, 0, kAct>(a, grid, s);
-    return launch_hidden<4, 1, 0, kAct>(a, grid, s);
+    if (wide) FC_HIDDEN_CASE(4, 2);
+    FC_HIDDEN_CASE(4, 1);
   }
+#undef FC_HIDDEN_CASE
   return hipErrorInvalidValue;
 }
 
@@ -472,7 +571,24 @@ extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols
   if (!x || !h || !id_cols || !w0 || !b0 || (num_blocks > 0 && (!wb || !bb))) return hipErrorInvalidValue;
   if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)wb & 15u) != 0) return hipErrorInvalidValue;
   fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, nullptr, nullptr, nullptr, 0,
-                   activation, activation_param};
+                   activation, activation_param, nullptr, nullptr, nullptr};
+  if (activation == FC_ACT_RELU) return fc::dispatch_hidden<0, 0>(a, num_blocks, static_cast<hipStream_t>(stream));
+  return fc::dispatch_hidden<0, 1>(a, num_blocks, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fc_resnet_hidden_packed(const float* x, float* h, const int32_t* id_cols, const void* w_frag,
+                                       const float* w_unscale, const float* bias_acc, int64_t n, int32_t d,
+                                       int32_t in_features, int32_t hidden, int32_t num_blocks, int32_t activation,
+                                       float activation_param, void* stream) {
+  if (n < 0 || d <= 0 || hidden != fc::kHid || num_blocks < 0 || num_blocks > 4) return hipErrorInvalidValue;
+  if (activation < FC_ACT_RELU || activation > FC_ACT_SIGMOID) return hipErrorInvalidValue;
+  if (in_features <= 0 || in_features > 64 || in_features > d) return hipErrorInvalidValue;
+  if (n % 16 != 0) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!x || !h || !id_cols || !w_frag || !w_unscale || !bias_acc) return hipErrorInvalidValue;
+  if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)w_frag & 15u) != 0) return hipErrorInvalidValue;
+  fc::HiddenArgs a{x, h, id_cols, nullptr, nullptr, nullptr, nullptr, n / 16, d, in_features, nullptr, nullptr, nullptr, 0,
+                   activation, activation_param, static_cast<const fc::f16x8*>(w_frag), w_unscale, bias_acc};
   if (activation == FC_ACT_RELU) return fc::dispatch_hidden<0, 0>(a, num_blocks, static_cast<hipStream_t>(stream));
   return fc::dispatch_hidden<0, 1>(a, num_blocks, static_cast<hipStream_t>(stream));
 }
@@ -497,7 +613,7 @@ extern "C" int fc_resnet_hidden_context(const float* x, const float* context, fl
   if (context_mode == FC_CONTEXT_ADDITIVE && (!wc || !bc)) return hipErrorInvalidValue;
   if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)wb & 15u) != 0) return hipErrorInvalidValue;
   fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, context, wc, bc, context_features,
-                   activation, activation_param};
+                   activation, activation_param, nullptr, nullptr, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (context_mode == FC_CONTEXT_GLU)
     return activation == FC_ACT_RELU ? fc::dispatch_hidden<1, 0>(a, num_blocks, s) : fc::dispatch_hidden<1, 1>(a, num_blocks, s);

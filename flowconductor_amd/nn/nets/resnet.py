@@ -191,15 +191,19 @@ class ResidualNet(nn.Module):
                 return False
         return True
 
+    def _storage_key(self):
+        """Where the parameters live (a device pack plan holds raw pointers to these storages)."""
+        return tuple((p.data_ptr(), p.device) for p in self.parameters())
+
     def hidden_backward_packed(self):
         from flowconductor_amd import ops
 
         # persistent device-side pack plan (one launch per refresh); rebuilt when the parameter storages moved
-        w0 = self.initial_layer.weight
+        where = self._storage_key()
         plan = getattr(self, "_hip_packed_bwd", None)
-        if plan is None or plan[0] != (w0.data_ptr(), w0.device):
+        if plan is None or plan[0] != where:
             pack, packed = ops.device_pack_resnet_hidden_backward(self)
-            plan = self._hip_packed_bwd = [(w0.data_ptr(), w0.device), pack, packed, None]
+            plan = self._hip_packed_bwd = [where, pack, packed, None]
         key = ops.cache_key(*self.parameters())
         if plan[3] != key:
             plan[1].run()
@@ -229,8 +233,19 @@ class ResidualNet(nn.Module):
         from flowconductor_amd import ops
 
         key = ops.cache_key(*self.parameters())
-        if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
-            self._hip_packed = (key, ops.pack_resnet_hidden(self))
         in_features = self.initial_layer.in_features - (self.context_features or 0)
         act = ops.activation_code(self.blocks[0].activation) if len(self.blocks) else (ops.ACT_RELU, 0.0)
+        if context is None:
+            # weight image made once on the device (one launch per refresh), copied into LDS by every launch
+            where = self._storage_key()
+            plan = getattr(self, "_hip_image", None)
+            if plan is None or plan[0] != where:
+                pack, packed = ops.device_pack_resnet_hidden_forward(self)
+                plan = self._hip_image = [where, pack, packed, None]
+            if plan[3] != key:
+                plan[1].run()
+                plan[3] = key
+            return ops.resnet_hidden_packed(rows, id_cols, plan[2], in_features, len(self.blocks), act)
+        if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
+            self._hip_packed = (key, ops.pack_resnet_hidden(self))
         return ops.resnet_hidden(rows, id_cols, self._hip_packed[1], in_features, len(self.blocks), context, act)

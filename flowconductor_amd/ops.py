@@ -591,6 +591,47 @@ def device_pack_resnet_hidden_backward(net):
     return pack, (w_frag, wt_frag, w_un, bias_acc, k0s)
 
 
+def device_pack_resnet_hidden_forward(net):
+    """The LDS weight image of ``fc_resnet_hidden_packed`` for a ResidualNet with hidden <= 64, <= 4 blocks, no context,
+    made on the device: returns ``(pack, (w_frag, w_unscale [L], bias_acc [L, 64]))``; ``pack.run()`` refreshes it."""
+    dev = net.initial_layer.weight.device
+    k0s = 1 if net.initial_layer.in_features <= 32 else 2
+    layers = [net.initial_layer] + [lin for block in net.blocks for lin in block.linear_layers]
+    frag0, frag_l = k0s * 4 * 2 * 64 * 8, 2 * 4 * 2 * 64 * 8
+    w_frag = torch.empty(frag0 + (len(layers) - 1) * frag_l, dtype=torch.float16, device=dev)
+    w_un = torch.empty(len(layers), dtype=torch.float32, device=dev)
+    bias_acc = torch.empty(len(layers), 64, dtype=torch.float32, device=dev)
+    pack = DevicePack(dev)
+    off = 0
+    for i, lin in enumerate(layers):
+        size = frag0 if i == 0 else frag_l
+        pack.add(PACK_HIDDEN, lin.weight, lin.bias, w_frag[off:off + size], w_un[i:i + 1], bias_acc[i],
+                 nks=k0s if i == 0 else 2, nt=4)
+        off += size
+    return pack, (w_frag, w_un, bias_acc)
+
+
+def resnet_hidden_packed(inputs, id_cols, packed, in_features, num_blocks, activation=(ACT_RELU, 0.0)):
+    """``resnet_hidden`` (no context) from a ready-made weight image (``device_pack_resnet_hidden_forward``)."""
+    lib = _hip.load()
+    x = _prep_2d(inputs)
+    _hip.require_no_grad(inputs)
+    n, d = x.shape
+    if n % HIDDEN_ROWS != 0:
+        raise ValueError("fc_resnet_hidden needs a multiple of %d rows" % HIDDEN_ROWS)
+    w_frag, w_un, bias_acc = packed
+    k0s = 1 if in_features <= 32 else 2
+    if w_frag.numel() != (k0s + 4 * num_blocks) * 4096 or w_un.numel() != 1 + 2 * num_blocks:
+        raise ValueError("weight image does not match in_features = %d, num_blocks = %d" % (in_features, num_blocks))
+    ids = _as_cols(id_cols, x.device)
+    h = torch.empty(n, 64, dtype=torch.float32, device=x.device)
+    # (timed and reported under the name of the kernel it launches: fc_resnet_hidden with a ready-made image)
+    _call("fc_resnet_hidden", lib.fc_resnet_hidden_packed, x.device, _hip.ptr(x), _hip.ptr(h), _hip.ptr(ids),
+          _hip.ptr(w_frag), _hip.ptr(w_un), _hip.ptr(bias_acc), n, d, in_features, 64, num_blocks, int(activation[0]),
+          float(activation[1]), _hip.stream_ptr(x.device))
+    return h
+
+
 def _hb_perm():
     """Feature held by accumulator tile t, row rho of the hidden-layer kernels: 32 (t >> 1) + 8 g + 4 (t & 1) + r with
     g = rho >> 2, r = rho & 3 (the order in which the C layout of one layer is the B operand of the next)."""

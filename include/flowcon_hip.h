@@ -153,6 +153,17 @@ int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols, const flo
                      int32_t in_features, int32_t hidden, int32_t num_blocks, int32_t activation,
                      float activation_param, void* stream);
 
+/* fc_resnet_hidden with the weights prepared ahead of time (same results, bit for bit): w_frag = the layers' f16
+ * fragment images back to back ([layer][k-step][tile][piece][lane][8], FC_PACK_HIDDEN jobs of fc_pack_fragments: the
+ * initial layer with nks = 1 (in_features <= 32) or 2, every block layer with nks = 2, nt = 4), w_unscale [L] and
+ * bias_acc [L][64] from the same jobs, L = 1 + 2 num_blocks.  The kernel then starts with a copy of the image into LDS
+ * instead of two rounds of weight loads, the scaling / splitting arithmetic and two barriers (~19 us per launch at
+ * 2 blocks).  No context. */
+int fc_resnet_hidden_packed(const float* x, float* h, const int32_t* id_cols, const void* w_frag,
+                            const float* w_unscale, const float* bias_acc, int64_t n, int32_t d,
+                            int32_t in_features, int32_t hidden, int32_t num_blocks, int32_t activation,
+                            float activation_param, void* stream);
+
 /* Backward of fc_resnet_hidden (what torch.autograd yields for resnet.py:39-53, 93-99): the activations are recomputed
  * from x; grad_h [n, 64] in -> grad_x_id [n, 32 K0S] (gradient wrt x[:, id_cols], K0S = 1 for in_features <= 32 else 2),
  * and, ACCUMULATED with atomics (zero them first): grad_w0 [64][32 K0S], grad_wb [2 num_blocks][64][64], grad_b [L][64],

@@ -68,6 +68,32 @@ def test_resnet_hidden_kernel_matches_torch(in_f, blocks, d, n, device):
     assert maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("hidden,in_f,blocks,n", [(64, 32, 2, 1 << 17), (64, 5, 0, 48), (48, 33, 1, 4112), (64, 64, 4, 2048),
+                                                  (20, 7, 3, 160)])
+def test_resnet_hidden_packed_image_is_bit_identical(hidden, in_f, blocks, n, device):
+    """fc_resnet_hidden_packed (weight image made by fc_pack_fragments, copied into LDS) against fc_resnet_hidden (image
+    built inside the kernel from the f32 weights): the same bits, on both the one- and two-blocks-per-wave kernels; and
+    the image follows in-place parameter updates."""
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(hidden + in_f)
+    d = 2 * in_f
+    net = nets.ResidualNet(in_f, 8, hidden_features=hidden, num_blocks=blocks).eval().to(device)
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(2.0)
+    ids = torch.arange(0, d, 2, device=device)
+    x = torch.randn(n, d, device=device)
+    with torch.no_grad():
+        a = net.hidden_hip(x, ids)                                         # packed image
+        b = ops.resnet_hidden(x, ids, ops.pack_resnet_hidden(net), in_f, blocks)
+        assert torch.equal(a, b)
+        net.initial_layer.weight.mul_(1.5)                                 # in place: the version counter moves
+        a2 = net.hidden_hip(x, ids)
+        b2 = ops.resnet_hidden(x, ids, ops.pack_resnet_hidden(net), in_f, blocks)
+    assert torch.equal(a2, b2) and not torch.equal(a, a2)
+
+
 @pytest.mark.parametrize("hidden,in_f,blocks,ctx_f", [(32, 16, 2, None), (48, 20, 1, None), (7, 3, 4, None),
                                                      (32, 16, 2, 6), (50, 10, 3, 32)])
 def test_resnet_hidden_kernel_narrow_nets_zero_padded(hidden, in_f, blocks, ctx_f, device):
