@@ -250,15 +250,21 @@ __global__ __launch_bounds__(512, (kCtx || BPW > 1) ? 2 : 4) void resnet_hidden_
     m = rows4_allmax(m, lane);
     float sc, un;
     pow2_scale(m, sc, un);
+    u32x4 hh[2], ll[2];     // f16 pairs: tile t, registers 2p, 2p + 1 -> k-step t >> 1, elements 4 (t & 1) + 2p, + 1
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        _Float16 ph, pl;
-        split2(v[t][r] * sc, ph, pl);
-        bh[t >> 1][4 * (t & 1) + r] = ph;
-        bl[t >> 1][4 * (t & 1) + r] = pl;
+      for (int p = 0; p < 2; ++p) {
+        uint32_t ph, pl;
+        split2_pair(v[t][2 * p], v[t][2 * p + 1], sc, ph, pl);
+        hh[t >> 1][2 * (t & 1) + p] = ph;
+        ll[t >> 1][2 * (t & 1) + p] = pl;
       }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bh[ks] = __builtin_bit_cast(f16x8, hh[ks]);
+      bl[ks] = __builtin_bit_cast(f16x8, ll[ks]);
+    }
     return un;
   };
   // acc[b] = (scaled W_l) (scaled act_b)^T for the BPW sample blocks of this wave: three split terms, small ones

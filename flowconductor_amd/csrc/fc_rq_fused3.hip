@@ -220,16 +220,16 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     const float m = row16_allmax(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     float sc, un;
     pow2_scale(m, sc, un);
-    f16x4 p0, p1;
+    u32x2 p0, p1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      _Float16 ph, pl;
-      split2(v[j] * sc, ph, pl);
+    for (int j = 0; j < 2; ++j) {
+      uint32_t ph, pl;
+      split2_pair(v[2 * j], v[2 * j + 1], sc, ph, pl);
       p0[j] = ph; p1[j] = pl;
     }
     _Float16* dst = hbuf + (buf * 2 * R + r) * kHB + c;
-    *reinterpret_cast<f16x4*>(dst) = p0;
-    *reinterpret_cast<f16x4*>(dst + kHPiece) = p1;
+    *reinterpret_cast<u32x2*>(dst) = p0;
+    *reinterpret_cast<u32x2*>(dst + kHPiece) = p1;
     if ((tid & 15) == 0) hscale[xbuf3 * R + r] = un;
   };
   // h tile -> hbuf[hb2] (ring of 2), its row scales and the x tile -> ring slot x3 (ring of 3)

@@ -15,6 +15,8 @@ namespace fc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // Power-of-two scale that lifts m = max|x| into [2^10, 2^11), and its inverse.  Tiny or zero maxima are left
 // alone (their pieces underflow to an absolute error far below f32 resolution of any O(1) result).
@@ -29,6 +31,26 @@ __device__ __forceinline__ void pow2_scale(float m, float& scale, float& unscale
 __device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
   h = (_Float16)x;
   l = (_Float16)(x - (float)h);
+}
+
+// The same split for two values x0 = v0 * sc, x1 = v1 * sc (sc a power of two: the products are exact), pieces packed
+// as f16 pairs (low half = value 0).  The residual comes from the mixed-precision fma, l = f16(fma(v, sc, -h)) with h
+// read as an f16 operand: no conversion of h back to f32 (five instructions per pair instead of six).  Bit-identical to
+// split2 (tools/probe/split_pair_check.hip).  [v_fma_mixlo / mixhi_f16, which would also absorb the final conversion,
+// issue at the transcendental rate on gfx950 (tools/probe/valu_costs.hip): four of them per pair measured 12 % slower
+// in fc_resnet_hidden than the six plain instructions.]
+__device__ __forceinline__ void split2_pair(float v0, float v1, float sc, uint32_t& h01, uint32_t& l01) {
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+  const f16x2 h = {(_Float16)(v0 * sc), (_Float16)(v1 * sc)};
+  const uint32_t hb = __builtin_bit_cast(uint32_t, h);
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %2, %4, -%5 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mix_f32 %1, %3, %4, -%5 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(r0), "=&v"(r1)
+      : "v"(v0), "v"(v1), "v"(sc), "v"(hb));
+  const f16x2 l = {(_Float16)r0, (_Float16)r1};
+  h01 = hb;
+  l01 = __builtin_bit_cast(uint32_t, l);
 }
 
 }  // namespace fc
