@@ -50,7 +50,7 @@ def build_flow():
     return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([FEATURES])).eval()
 
 
-TRAFFIC_PROFILE = "profiles/r02b_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r02c_hbm_traffic.json"
 # kernel symbol (substring) each C-ABI entry launches in this flow: the committed PMC profile must have counted THAT
 # kernel, or its number does not belong in this line
 EXPECTED_KERNELS = {"fc_rq_spline_fused_linear": "rq_fused_linear_kernel3", "fc_resnet_hidden": "resnet_hidden_kernel",
@@ -428,7 +428,7 @@ def main():
                 out["roofline_hidden"] = {"bound": "hbm", "achieved": h_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": h_gbs / HBM_PEAK_GBS,
                                           "traffic": measured_traffic_per_launch("fc_resnet_hidden", rows_per_launch),
-                                          "kernel": "fc_resnet_hidden -> fc::resnet_hidden_kernel<2, 1, false, 0>",
+                                          "kernel": "fc_resnet_hidden -> fc::resnet_hidden_kernel<2, 1, 0, 0, 1>",
                                           "launches_timed": len(hidden_ms), "avg_launch_ms": h_avg,
                                           "algorithmic_bytes_per_launch": h_bytes,
                                           "share_of_step": sum(hidden_ms) / (1e3 * elapsed / args.steps),

@@ -100,8 +100,10 @@ SIGNATURES = {
                            _I32, _I32, _P],
     "fc_sum_of_sigmoids_backward": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P],
     "fc_planar_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P],
+    "fc_sylvester_mid_backward": [_P, _P, _P, _P, _P, _P, _I64, _I32, _P],
     "fc_householder_backward": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "fc_elementwise": [_P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _F, _F, _F, _F, _P],
+    "fc_piecewise_spline_backward": [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, ctypes.POINTER(SplineConfig), _P],
     "fc_piecewise_spline": [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32,
                             ctypes.POINTER(SplineConfig), _P],
     "fc_rq_spline_fused_linear": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32,

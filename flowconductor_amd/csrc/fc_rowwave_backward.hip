@@ -140,6 +140,49 @@ __global__ __launch_bounds__(256) void householder_backward_kernel(const float* 
   }
 }
 
+// Middle of the Sylvester backward (no_analytic_inv/planar.py:144-166): with pre = R1 Q^T z + b, act = tanh(pre),
+// diag = 1 + (1 - act^2) rd (rd = diag R1 diag R2) and lad = sum_j log diag_j, turn the gradient wrt act (from the
+// R2 / Q product above it) into the gradient wrt pre, adding the log-determinant's share, and reduce the two
+// batch sums the parameter gradients need:
+//   g_act += gl rd (-2 act) / diag;   g_pre = g_act (1 - act^2)   (in place);   g_bias += g_pre;   g_rd += gl (1 - act^2) / diag
+template <int E>
+__global__ __launch_bounds__(256) void sylvester_mid_backward_kernel(const float* __restrict__ pre, float* __restrict__ g,
+                                                                     const float* __restrict__ gl,
+                                                                     const float* __restrict__ rd, float* __restrict__ g_bias,
+                                                                     float* __restrict__ g_rd, int64_t n, int d) {
+  const int lane = threadIdx.x & 63;
+  Row<E> rdv, sb, sr;
+  load_row<E>(rdv, rd, d, lane);
+#pragma unroll
+  for (int e = 0; e < E; ++e) sb.v[e] = sr.v[e] = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t row = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6); row < n; row += stride) {
+    Row<E> p, gv;
+    load_row<E>(p, pre + row * d, d, lane);
+    load_row<E>(gv, g + row * d, d, lane);
+    const float glr = gl ? gl[row] : 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const float act = tanhf(p.v[e]);
+      const float dt = 1.f - act * act;
+      const float gd = glr / (1.f + dt * rdv.v[e]);
+      const float gp = (gv.v[e] + gd * rdv.v[e] * (-2.f * act)) * dt;
+      gv.v[e] = gp;
+      sb.v[e] += gp;
+      sr.v[e] += gd * dt;
+    }
+    store_row<E>(gv, g + row * d, d, lane);
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int i = lane + 64 * e;
+    if (i < d) {
+      atomicAdd(g_bias + i, sb.v[e]);
+      atomicAdd(g_rd + i, sr.v[e]);
+    }
+  }
+}
+
 inline unsigned bwd_row_grid(int64_t n) {
   int64_t g = (n + kWavesPerBlock - 1) / kWavesPerBlock;
   const int64_t cap = 256 * 4;
@@ -178,5 +221,17 @@ extern "C" int fc_householder_backward(const float* y, const float* grad_y, cons
   if (num_transforms == 0) return hipMemcpyAsync(grad_x, grad_y, sizeof(float) * n * d, hipMemcpyDeviceToDevice, s);
   FC_ROW_DISPATCH_B(d, hipLaunchKernelGGL((fc::householder_backward_kernel<E, 8>), dim3(fc::bwd_row_grid(n)), dim3(256), 0,
                                           s, y, grad_y, q, grad_x, grad_q, n, d, num_transforms, reverse));
+  return hipGetLastError();
+}
+
+extern "C" int fc_sylvester_mid_backward(const float* pre, float* grad_act_inout, const float* grad_logabsdet,
+                                         const float* r_diag_prod, float* grad_bias, float* grad_r_diag_prod, int64_t n,
+                                         int32_t d, void* stream) {
+  if (n < 0 || d <= 0 || d > 512) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!pre || !grad_act_inout || !r_diag_prod || !grad_bias || !grad_r_diag_prod) return hipErrorInvalidValue;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  FC_ROW_DISPATCH_B(d, hipLaunchKernelGGL(fc::sylvester_mid_backward_kernel<E>, dim3(fc::bwd_row_grid(n)), dim3(256), 0, s,
+                                          pre, grad_act_inout, grad_logabsdet, r_diag_prod, grad_bias, grad_r_diag_prod, n, d));
   return hipGetLastError();
 }

@@ -1377,18 +1377,6 @@ def linear(inputs, a, b=None, bias=None, mode=LINEAR_DENSE):
     return y
 
 
-def _householder_expression(reverse):
-    """orthogonal.py:144-194 in torch ops: out -= (out . q_i) (2 / |q_i|^2) q_i, shared ``q [K, D]``."""
-    def expr(x, q):
-        out = x
-        order = range(q.shape[0] - 1, -1, -1) if reverse else range(q.shape[0])
-        for i in order:
-            qi = q[i]
-            out = out - (out @ qi).unsqueeze(-1) * (2.0 / (qi @ qi)) * qi
-        return out, x.new_zeros(x.shape[0])
-    return expr
-
-
 class _HouseholderFunction(torch.autograd.Function):
     """``householder`` with batch-shared q-vectors and its HIP backward kernel (``fc_householder_backward``: the
     reflections are involutions, so the saved OUTPUT is walked back to every intermediate)."""
@@ -1460,19 +1448,63 @@ def planar_autograd(inputs, w, u_hat, b):
     return planar(inputs, w, u_hat, b)
 
 
+def _householder_backward(outputs, grad_outputs, q, reverse):
+    """(grad_inputs, grad_q) of ``householder`` with shared q from its saved OUTPUT (``fc_householder_backward``)."""
+    lib = _hip.load()
+    n, d = outputs.shape
+    gx = torch.empty_like(outputs)
+    gq = torch.zeros_like(q)
+    _call("fc_householder_backward", lib.fc_householder_backward, outputs.device, _hip.ptr(outputs), _hip.ptr(grad_outputs),
+          _hip.ptr(q), _hip.ptr(gx), _hip.ptr(gq), n, d, q.shape[0], 1 if reverse else 0, _hip.stream_ptr(outputs.device))
+    return gx, gq
+
+
+class _SylvesterFunction(torch.autograd.Function):
+    """Shared-parameter ``sylvester`` (no_analytic_inv/planar.py:144-166) with an explicit backward: the two Householder
+    sequences through ``fc_householder`` / ``fc_householder_backward``, the products with R1 / R2 as library GEMMs, the
+    tanh / log-determinant middle in ``fc_sylvester_mid_backward``."""
+
+    @staticmethod
+    def forward(ctx, inputs, q_vectors, r1, r2, bias):
+        with torch.no_grad():
+            outputs, logabsdet = sylvester(inputs, q_vectors, r1, r2, bias)
+        ctx.save_for_backward(inputs, q_vectors, r1, r2, bias)
+        return outputs, logabsdet
+
+    @staticmethod
+    def backward(ctx, grad_outputs, grad_logabsdet):
+        inputs, q_vectors, r1, r2, bias = ctx.saved_tensors
+        lib = _hip.load()
+        with torch.no_grad():
+            x = _hip.dev_f32(inputs.detach(), "inputs")
+            q = _hip.dev_f32(q_vectors.detach(), "q_vectors")
+            r1d, r2d, bd = r1.detach().float(), r2.detach().float(), bias.detach().float().reshape(-1)
+            n, d = x.shape
+            gy = _hip.dev_f32(grad_outputs if grad_outputs is not None else torch.zeros_like(x), "grad_outputs")
+            gl = None if grad_logabsdet is None else _hip.dev_f32(grad_logabsdet, "grad_logabsdet")
+            qtz = householder(x, q, reverse=True)                               # Q^T z
+            pre = torch.addmm(bd, qtz, r1d.t())
+            act = torch.tanh(pre)
+            out = householder(act @ r2d.t(), q, reverse=False)                  # Q R2 act (saved output of that sequence)
+            g_mid, gq_a = _householder_backward(out, gy, q, False)
+            g_r2 = g_mid.t() @ act
+            g_act = (g_mid @ r2d).contiguous()
+            rd = (torch.diagonal(r1d) * torch.diagonal(r2d)).contiguous()
+            sums = torch.zeros(2, d, dtype=torch.float32, device=x.device)        # g_bias | g_rd, one zero fill
+            _call("fc_sylvester_mid_backward", lib.fc_sylvester_mid_backward, x.device, _hip.ptr(pre), _hip.ptr(g_act),
+                  _hip.ptr(gl), _hip.ptr(rd), _hip.ptr(sums[0]), _hip.ptr(sums[1]), n, d, _hip.stream_ptr(x.device))
+            g_pre = g_act
+            g_r1 = g_pre.t() @ qtz
+            g_x2, gq_b = _householder_backward(qtz, (g_pre @ r1d).contiguous(), q, True)
+            g_r1.diagonal().add_(sums[1] * torch.diagonal(r2d))
+            g_r2.diagonal().add_(sums[1] * torch.diagonal(r1d))
+            return gy + g_x2, gq_a + gq_b, g_r1, g_r2, sums[0].view_as(bias)
+
+
 def sylvester_autograd(inputs, q_vectors, r1, r2, bias):
     """Shared-parameter Sylvester flow (no_analytic_inv/planar.py:144-166) with an autograd node when needed."""
-    refl_inv, refl_fwd = _householder_expression(True), _householder_expression(False)
-
-    def expr(x, q, r1_, r2_, b_):
-        qtz, _ = refl_inv(x, q)
-        pre = qtz @ r1_.T + b_
-        act = torch.tanh(pre)
-        out, _ = refl_fwd(act @ r2_.T, q)
-        diag = 1 + (1 - act ** 2) * (torch.diag(r1_) * torch.diag(r2_))
-        return x + out, torch.log(diag).sum(-1)
     if torch.is_grad_enabled() and any(t.requires_grad for t in (inputs, q_vectors, r1, r2, bias)):
-        return _TorchGradFunction.apply(lambda *a: sylvester(*a), expr, _prep_2d(inputs), q_vectors, r1, r2, bias)
+        return _SylvesterFunction.apply(_prep_2d(inputs), q_vectors, r1, r2, bias)
     return sylvester(inputs, q_vectors, r1, r2, bias)
 
 
@@ -1611,32 +1643,6 @@ def elementwise(inputs, kind, inverse=False, aux=None, p=(0.0, 0.0, 0.0, 0.0), r
 
 # ---- sum of sigmoids ------------------------------------------------------------------------------
 
-class _TorchGradFunction(torch.autograd.Function):
-    """Forward by a HIP kernel, gradients by torch.autograd walking the same map written in torch ops on the device
-    (for bijectors without a backward kernel; both evaluate f at the same point, so the gradient is f's)."""
-
-    @staticmethod
-    def forward(ctx, hip_fn, expr_fn, *tensors):
-        with torch.no_grad():
-            outputs, logabsdet = hip_fn(*tensors)
-        ctx.expr_fn = expr_fn
-        ctx.save_for_backward(*tensors)
-        return outputs, logabsdet
-
-    @staticmethod
-    def backward(ctx, grad_outputs, grad_logabsdet):
-        with torch.enable_grad():
-            ins = [t.detach().requires_grad_(True) for t in ctx.saved_tensors]
-            outputs, logabsdet = ctx.expr_fn(*ins)
-            if grad_outputs is None:
-                grad_outputs = torch.zeros_like(outputs)
-            if grad_logabsdet is None:
-                grad_logabsdet = torch.zeros_like(logabsdet)
-            pairs = [(o, g) for o, g in ((outputs, grad_outputs), (logabsdet, grad_logabsdet)) if o.requires_grad]
-            grads = torch.autograd.grad([o for o, _ in pairs], ins, [g for _, g in pairs], allow_unused=True)
-        return (None, None) + tuple(grads)
-
-
 class _SoSFunction(torch.autograd.Function):
     """``sum_of_sigmoids`` (forward direction, per-sample raw parameters) with its HIP backward kernel
     (``fc_sum_of_sigmoids_backward``: closed-form derivatives of adaptive_sigmoids.py:108-142)."""
@@ -1727,89 +1733,62 @@ def spline_multiplier(kind, num_bins, tails):
     return num_bins * 2 + 2
 
 
-def _piecewise_expression(cols, *, kind, num_bins, tails=None, tail_bound=1.0, left=0.0, right=1.0, bottom=0.0,
-                          top=1.0, min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
-                          width_divisor=1.0, height_divisor=1.0):
-    """Forward direction of the linear / quadratic / cubic splines in torch ops (splines/linear.py:38-105,
-    quadratic.py:55-159, cubic.py:63-150 with their ``unconstrained_*`` wrappers) on ``x [N, D]`` and per-sample rows
-    ``[N, d_t * P]``: the gradient source for ``fc_piecewise_spline`` under autograd."""
-    from torch.nn import functional as F
-
-    k = num_bins
+def _spline_config(kind, num_bins, tails, tail_bound, box, min_bin_width, min_bin_height, width_divisor,
+                   height_divisor, inverse):
+    cfg = _hip.SplineConfig()
+    cfg.kind, cfg.num_bins = kind, num_bins
+    cfg.tails = 0 if tails is None else 1
+    cfg.inverse = 1 if inverse else 0
     if tails == "linear":
-        left, right, bottom, top = -tail_bound, tail_bound, -tail_bound, tail_bound
+        cfg.left, cfg.right, cfg.bottom, cfg.top = -tail_bound, tail_bound, -tail_bound, tail_bound
+    else:
+        cfg.left, cfg.right, cfg.bottom, cfg.top = box
+    cfg.min_bin_width, cfg.min_bin_height = min_bin_width, min_bin_height
+    cfg.width_divisor, cfg.height_divisor = width_divisor, height_divisor
+    cfg.cubic_eps, cfg.cubic_quadratic_threshold = 1e-5, 1e-3
+    return cfg
 
-    def bin_index(edges, v):
-        edges = edges.clone()
-        edges[..., -1] += 1e-6                    # utils/torchutils.py:147-149
-        return (torch.sum(v[..., None] >= edges, dim=-1) - 1).clamp(0, k - 1)[..., None]
 
-    def cum(v):
-        c = torch.cumsum(v, dim=-1)
-        c = torch.cat((c[..., :-1], torch.ones_like(c[..., -1:])), dim=-1)
-        return F.pad(c, pad=(1, 0), mode="constant", value=0.0)
+class _PiecewiseSplineFunction(torch.autograd.Function):
+    """``piecewise_spline`` (forward direction, per-sample rows) with its HIP backward kernel
+    (``fc_piecewise_spline_backward``: forward-mode derivative of the kernel's own evaluation, one thread per
+    (element, parameter))."""
 
-    def spline(u, rows):
-        if kind == SPLINE_LINEAR:
-            pdf = F.softmax(rows, dim=-1)
-            cdf = cum(pdf)
-            pos = u * k
-            idx = torch.floor(pos).long().clamp(0, k - 1)[..., None]
-            pdf_k = pdf.gather(-1, idx)[..., 0]
-            out = cdf.gather(-1, idx)[..., 0] + (pos - idx[..., 0].to(u.dtype)) * pdf_k
-            return out.clamp(0, 1), torch.log(pdf_k) - math.log(1.0 / k)
-        widths = min_bin_width + (1 - min_bin_width * k) * F.softmax(rows[..., :k] / width_divisor, dim=-1)
-        if kind == SPLINE_QUADRATIC:
-            uh = F.softplus(rows[..., k:] / height_divisor) + 1e-3
-            if uh.shape[-1] == k - 1:
-                fw, lw = 0.5 * widths[..., 0], 0.5 * widths[..., -1]
-                num = (0.5 * fw * uh[..., 0] + 0.5 * lw * uh[..., -1]
-                       + torch.sum(((uh[..., :-1] + uh[..., 1:]) / 2) * widths[..., 1:-1], dim=-1))
-                const = (num / (1 - 0.5 * fw - 0.5 * lw))[..., None]
-                uh = torch.cat([const, uh, const], dim=-1)
-            area = torch.sum(((uh[..., :-1] + uh[..., 1:]) / 2) * widths, dim=-1)[..., None]
-            heights = min_bin_height + (1 - min_bin_height) * (uh / area)
-            left_cdf = cum(((heights[..., :-1] + heights[..., 1:]) / 2) * widths)
-            locations = cum(widths)
-            idx = bin_index(locations, u)
-            w_k = widths.gather(-1, idx)[..., 0]
-            hl, hr = heights.gather(-1, idx)[..., 0], heights.gather(-1, idx + 1)[..., 0]
-            alpha = (u - locations.gather(-1, idx)[..., 0]) / w_k
-            out = 0.5 * (hr - hl) * w_k * alpha ** 2 + hl * w_k * alpha + left_cdf.gather(-1, idx)[..., 0]
-            return out.clamp(0, 1), torch.log(alpha * (hr - hl) + hl)
-        heights = min_bin_height + (1 - min_bin_height * k) * F.softmax(rows[..., k:2 * k] / height_divisor, dim=-1)
-        cumwidths, cumheights = cum(widths), cum(heights)
-        slopes = heights / widths
-        m1 = torch.min(slopes[..., :-1].abs(), slopes[..., 1:].abs())
-        m2 = 0.5 * (widths[..., 1:] * slopes[..., :-1] + widths[..., :-1] * slopes[..., 1:]) / (
-            widths[..., :-1] + widths[..., 1:])
-        d_left = torch.sigmoid(rows[..., 2 * k:2 * k + 1]) * 3 * slopes[..., :1]
-        d_right = torch.sigmoid(rows[..., 2 * k + 1:2 * k + 2]) * 3 * slopes[..., -1:]
-        derivs = torch.cat([d_left, torch.min(m1, m2) * (torch.sign(slopes[..., :-1]) + torch.sign(slopes[..., 1:])),
-                            d_right], dim=-1)
-        a = (derivs[..., :-1] + derivs[..., 1:] - 2 * slopes) / widths ** 2
-        b = (3 * slopes - 2 * derivs[..., :-1] - derivs[..., 1:]) / widths
-        idx = bin_index(cumwidths, u)
-        ia, ib, ic, id_ = (t.gather(-1, idx)[..., 0] for t in (a, b, derivs[..., :-1], cumheights[..., :-1]))
-        sft = u - cumwidths.gather(-1, idx)[..., 0]
-        return ia * sft ** 3 + ib * sft ** 2 + ic * sft + id_, torch.log(3 * ia * sft ** 2 + 2 * ib * sft + ic)
+    @staticmethod
+    def forward(ctx, inputs, params, cols, kw):
+        with torch.no_grad():
+            outputs, logabsdet = piecewise_spline(inputs, params, cols, **kw)
+        ctx.save_for_backward(inputs, params)
+        ctx.cols, ctx.kw = cols, kw
+        return outputs, logabsdet
 
-    def expr(x, params):
-        xt = x if cols is None else x[:, cols.long()]
-        rows = params.reshape(xt.shape[0], xt.shape[1], -1)
-        inside = (xt >= left) & (xt <= right) if tails == "linear" else torch.ones_like(xt, dtype=torch.bool)
-        u = ((xt.clamp(left, right) if tails == "linear" else xt) - left) / (right - left)
-        out, lad = spline(u, rows)
-        out = out * (top - bottom) + bottom
-        out = torch.where(inside, out, xt)
-        lad = torch.where(inside, lad, torch.zeros_like(lad))
-        if cols is None:
-            return out, lad.sum(-1)
-        y = x.clone()
-        y[:, cols.long()] = out
-        return y, lad.sum(-1)
+    @staticmethod
+    def backward(ctx, grad_outputs, grad_logabsdet):
+        inputs, params = ctx.saved_tensors
+        kw = dict(ctx.kw)
+        lib = _hip.load()
+        x = _prep_2d(inputs.detach())
+        p = _hip.dev_f32(params.detach(), "params")
+        n, d = x.shape
+        cols = _as_cols(ctx.cols, x.device)
+        d_t = d if cols is None else cols.numel()
+        gy = _hip.dev_f32(grad_outputs if grad_outputs is not None else torch.zeros_like(x), "grad_outputs")
+        gl = None if grad_logabsdet is None else _hip.dev_f32(grad_logabsdet, "grad_logabsdet")
+        cfg = _spline_config(kw["kind"], kw["num_bins"], kw.get("tails"), kw.get("tail_bound", 1.0),
+                             (kw.get("left", 0.0), kw.get("right", 1.0), kw.get("bottom", 0.0), kw.get("top", 1.0)),
+                             kw.get("min_bin_width", DEFAULT_MIN_BIN_WIDTH), kw.get("min_bin_height", DEFAULT_MIN_BIN_HEIGHT),
+                             kw.get("width_divisor", 1.0), kw.get("height_divisor", 1.0), False)
+        gx = gy.clone() if d_t < d else torch.empty_like(x)       # identity columns pass the gradient through
+        gp = torch.empty_like(p)
+        _call("fc_piecewise_spline_backward", lib.fc_piecewise_spline_backward, x.device, _hip.ptr(x), _hip.ptr(p),
+              _hip.ptr(cols), _hip.ptr(gy), _hip.ptr(gl), _hip.ptr(gx), _hip.ptr(gp), n, d, d_t, cfg,
+              _hip.stream_ptr(x.device))
+        return gx, gp.view_as(params), None, None
 
-    return expr
+
+def piecewise_spline_backward_supported(kind, num_bins, tails):
+    """``fc_piecewise_spline_backward`` keeps an element's parameters as dual numbers in LDS: <= 32 per element."""
+    return spline_multiplier(kind, num_bins, tails) <= 32
 
 
 def piecewise_spline_autograd(inputs, params, cols=None, *, inverse=False, shared_params=False, **kw):
@@ -1818,11 +1797,12 @@ def piecewise_spline_autograd(inputs, params, cols=None, *, inverse=False, share
     if not (torch.is_grad_enabled() and (inputs.requires_grad or params.requires_grad)) or shared_params:
         return piecewise_spline(inputs, params, cols, inverse=inverse, shared_params=shared_params, **kw)
     x = _prep_2d(inputs)
-    cols_dev = _as_cols(cols, x.device)
-    expr = _piecewise_expression(cols_dev, **kw)
+    if not piecewise_spline_backward_supported(kw["kind"], kw["num_bins"], kw.get("tails")):
+        raise NotImplementedError("autograd through piecewise splines needs <= 32 parameters per element "
+                                  "(fc_piecewise_spline_backward); got num_bins = %d" % kw["num_bins"])
 
     def forward_fn(v, p):
-        return _TorchGradFunction.apply(lambda a, b: piecewise_spline(a, b, cols, **kw), expr, v, p)
+        return _PiecewiseSplineFunction.apply(v, p, cols, kw)
 
     if not inverse:
         return forward_fn(x, params)
@@ -1853,17 +1833,8 @@ def piecewise_spline(inputs, params, cols=None, *, kind, num_bins, tails=None, t
     want = rowlen if shared_params else n * rowlen
     if p.numel() != want:
         raise ValueError("params has %d elements, expected %d" % (p.numel(), want))
-    cfg = _hip.SplineConfig()
-    cfg.kind, cfg.num_bins = kind, num_bins
-    cfg.tails = 0 if tails is None else 1
-    cfg.inverse = 1 if inverse else 0
-    if tails == "linear":
-        cfg.left, cfg.right, cfg.bottom, cfg.top = -tail_bound, tail_bound, -tail_bound, tail_bound
-    else:
-        cfg.left, cfg.right, cfg.bottom, cfg.top = left, right, bottom, top
-    cfg.min_bin_width, cfg.min_bin_height = min_bin_width, min_bin_height
-    cfg.width_divisor, cfg.height_divisor = width_divisor, height_divisor
-    cfg.cubic_eps, cfg.cubic_quadratic_threshold = 1e-5, 1e-3
+    cfg = _spline_config(kind, num_bins, tails, tail_bound, (left, right, bottom, top), min_bin_width, min_bin_height,
+                         width_divisor, height_divisor, inverse)
     y = torch.empty_like(x)
     lad = torch.empty(n, dtype=torch.float32, device=x.device)
     err = _err_word(x.device, True)

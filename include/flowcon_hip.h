@@ -235,6 +235,15 @@ int fc_piecewise_spline(const float* x, float* y, const float* params, const int
                         int32_t shared_params, int32_t lad_mode, const fc_spline_config* cfg,
                         void* stream);
 
+/* Backward of fc_piecewise_spline in the forward direction (cfg->inverse == 0), per-sample rows: grad_x [n, d] (the
+ * d_t transformed columns are written; the caller owns the identity columns) and grad_params [n, d_t P] from grad_y
+ * [n, d] and grad_logabsdet [n] (NULL = zeros).  What torch.autograd yields for splines/linear.py:38-105,
+ * quadratic.py:55-159, cubic.py:63-267: the kernel differentiates the forward evaluation in forward mode, one thread per
+ * (element, parameter).  P <= 32 parameters per element. */
+int fc_piecewise_spline_backward(const float* x, const float* params, const int32_t* cols, const float* grad_y,
+                                 const float* grad_logabsdet, float* grad_x, float* grad_params, int64_t n,
+                                 int32_t d, int32_t d_t, const fc_spline_config* cfg, void* stream);
+
 /* ---- affine / additive with per-sample parameters ------------------------------------------ */
 #define FC_AFFINE_SIGMOID_PLUS2 0   /* row [shift d_t | u d_t], s = sigmoid(u+2)+1e-3 (coupling.py:224) */
 #define FC_AFFINE_SOFTPLUS_CLAMP3 1 /* row [shift | u], s = clamp(softplus(u)+1e-3, 0, 3) (coupling.py:225) */
@@ -354,6 +363,16 @@ int fc_planar_backward(const float* x, const float* grad_y, const float* grad_lo
  * What torch.autograd yields for orthogonal.py:144-194. */
 int fc_householder_backward(const float* y, const float* grad_y, const float* q, float* grad_x, float* grad_q,
                             int64_t n, int32_t d, int32_t num_transforms, int32_t reverse, void* stream);
+
+/* Element-wise middle of the backward of fc_sylvester with batch-shared parameters (no_analytic_inv/planar.py:144-166):
+ * pre [n, d] = R1 Q^T z + b (recomputed by the caller), grad_act_inout [n, d] = gradient wrt tanh(pre) coming from the
+ * R2 / Q product, grad_logabsdet [n] or NULL, r_diag_prod [d] = diag R1 * diag R2.  In place: grad_act_inout becomes the
+ * gradient wrt pre including the log-determinant's share; grad_bias [d] and grad_r_diag_prod [d] are ACCUMULATED (zero
+ * them first).  The matrix products around it are plain GEMMs and the two Householder sequences use
+ * fc_householder / fc_householder_backward (flowconductor_amd.ops._SylvesterFunction). */
+int fc_sylvester_mid_backward(const float* pre, float* grad_act_inout, const float* grad_logabsdet,
+                              const float* r_diag_prod, float* grad_bias, float* grad_r_diag_prod, int64_t n, int32_t d,
+                              void* stream);
 
 /* Dense linear maps with batch-shared [d, d] matrices given TRANSPOSED (a_t[j*d + i] = A[i][j]).
  * mode 0: y = A x + bias                        (linear.py:45-52 cached weight; bias may be NULL)

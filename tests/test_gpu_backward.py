@@ -673,3 +673,71 @@ def test_sos_backward_kernel_matches_float64_autograd(s_, d, device):
     assert maxdiff(y.detach(), y_ref.detach()) <= 2e-5 * max(1.0, float(y_ref.detach().abs().max()))
     assert maxdiff(xg.grad, x64.grad) <= 2e-4 * float(x64.grad.abs().max()) + 1e-6
     assert maxdiff(rg.grad.reshape(r64.grad.shape), r64.grad) <= 2e-4 * float(r64.grad.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("d,m", [(6, 2), (64, 4), (130, 3)])
+def test_sylvester_backward_matches_float64_autograd(d, m, device):
+    """ops._SylvesterFunction (fc_householder_backward x 2, fc_sylvester_mid_backward, library GEMMs) against float64
+    autograd on planar.py:144-166 written out with the oracle's reflections."""
+    torch.manual_seed(83 + d)
+    n = 515
+    x, q = torch.randn(n, d), torch.randn(m, d)
+    r1 = torch.triu(torch.randn(d, d)) / d ** 0.5
+    r2 = torch.triu(torch.randn(d, d)) / d ** 0.5
+    r1.diagonal().copy_(torch.rand(d) * 0.5 + 0.2)      # diag R1 diag R2 > -1: invertible map
+    r2.diagonal().copy_(torch.rand(d) * 0.5 + 0.2)
+    b = torch.randn(d) * 0.3
+    gy, gl = torch.randn(n, d), torch.randn(n)
+    leaves = [t.double().clone().requires_grad_(True) for t in (x, q, r1, r2, b)]
+    x64, q64, r164, r264, b64 = leaves
+    qtz = O.householder_apply(x64, q64.flip(0))
+    act = torch.tanh(qtz @ r164.T + b64)
+    y_ref = x64 + O.householder_apply(act @ r264.T, q64)
+    lad_ref = torch.log(1 + (1 - act ** 2) * (torch.diag(r164) * torch.diag(r264))).sum(-1)
+    ((y_ref * gy.double()).sum() + (lad_ref * gl.double()).sum()).backward()
+    dev = [t.to(device).requires_grad_(True) for t in (x, q, r1, r2, b)]
+    y, lad = ops.sylvester_autograd(*dev)
+    assert type(y.grad_fn).__name__ == "_SylvesterFunctionBackward"
+    ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
+    assert maxdiff(y.detach(), y_ref.detach()) <= 2e-5 * float(y_ref.detach().abs().max())
+    assert maxdiff(lad.detach(), lad_ref.detach()) <= 2e-5 * max(1.0, float(lad_ref.detach().abs().max()))
+    for got, ref, name in zip(dev, leaves, ("x", "q", "r1", "r2", "b")):
+        scale = max(1e-5, float(ref.grad.abs().max()))
+        assert maxdiff(got.grad.reshape(ref.grad.shape), ref.grad) <= 2e-4 * scale + 1e-5, name
+
+
+@pytest.mark.parametrize("kind,k,tails", [("linear", 7, None), ("quadratic", 6, None), ("quadratic", 9, "linear"), ("cubic", 8, None),
+                                          ("cubic", 5, "linear")])
+def test_piecewise_spline_backward_kernel_matches_float64_autograd(kind, k, tails, device):
+    """fc_piecewise_spline_backward (forward-mode derivative inside the kernel, one thread per element and parameter)
+    against float64 autograd through the oracle's spline functions, raw per-sample rows, a subset of columns."""
+    torch.manual_seed(89 + k)
+    n, d = 400, 5
+    cols = torch.tensor([0, 2, 3])
+    code = {"linear": ops.SPLINE_LINEAR, "quadratic": ops.SPLINE_QUADRATIC, "cubic": ops.SPLINE_CUBIC}[kind]
+    mult = ops.spline_multiplier(code, k, tails)
+    bound = 2.0
+    x = torch.randn(n, d) * 1.2 if tails else torch.rand(n, d) * 0.96 + 0.02
+    raw = torch.randn(n, len(cols) * mult)
+    gy, gl = torch.randn(n, d), torch.randn(n)
+    kw = dict(kind=code, num_bins=k, tails=tails, tail_bound=bound)
+    x64, r64 = x.double().requires_grad_(True), raw.double().requires_grad_(True)
+    rows = r64.view(n, len(cols), mult)
+    parts = {"linear": [rows], "quadratic": [rows[..., :k], rows[..., k:]],
+             "cubic": [rows[..., :k], rows[..., k:2 * k], rows[..., 2 * k:2 * k + 1], rows[..., 2 * k + 1:]]}[kind]
+    fn = {"linear": O.linear_spline, "quadratic": O.quadratic_spline, "cubic": O.cubic_spline}[kind]
+    if tails:
+        y_ref, lad_ref = O._unconstrained(fn, x64[:, cols], bound, tails, parts)
+    else:
+        y_ref, lad_ref = fn(x64[:, cols], *parts)
+    ((y_ref * gy[:, cols].double()).sum() + (lad_ref.sum(-1) * gl.double()).sum()).backward()
+    xg, rg = x.to(device).requires_grad_(True), raw.to(device).requires_grad_(True)
+    y, lad = ops.piecewise_spline_autograd(xg, rg, cols.to(device), **kw)
+    assert type(y.grad_fn).__name__ == "_PiecewiseSplineFunctionBackward"
+    ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
+    assert maxdiff(y.detach()[:, cols], y_ref.detach()) <= 3e-5 * max(1.0, float(y_ref.detach().abs().max()))
+    ident = [c for c in range(d) if c not in cols.tolist()]
+    assert torch.equal(xg.grad[:, ident].cpu(), gy[:, ident])                      # identity columns pass through
+    gx_ref = x64.grad[:, cols] 
+    assert maxdiff(xg.grad[:, cols], gx_ref) <= 1e-3 * max(1.0, float(gx_ref.abs().max()))
+    assert maxdiff(rg.grad, r64.grad) <= 1e-3 * max(1e-3, float(r64.grad.abs().max()))
