@@ -40,7 +40,9 @@ struct HidBwdArgs {
   const f16x8* wt;         // transposed fragments: per hidden layer [2][4][2][64]; last: W0^T [2][2 K0S][2][64]
   const float* wun;        // [L] 2^-S per layer (shared by both fragment sets)
   const float* bias;       // [L][4][16] accumulator order
-  float* gxid;             // [N, 32 K0S]
+  float* gxid;             // [N, 32 K0S], or null when the gradient is added into gx_full
+  float* gx_full;          // [N, D]: gx_full[:, id_cols] += the gradient wrt the identity columns (every (row, id column) is
+                           // visited by exactly one lane: plain read-modify-write), or null
   float* gw0;              // [64][32 K0S]
   float* gwb;              // [2 blocks][64][64]... flat [(L - 1)][64][64]
   float* gb;               // [L][64]
@@ -79,6 +81,14 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
   float wun[L];
 #pragma unroll
   for (int l = 0; l < L; ++l) wun[l] = a.wun[l];
+  // gx_full mode: are the identity columns every other column of a 16-byte aligned [N, 2 k0] gradient?  (0 / 1 = their
+  // parity, -1 = no: scalar read-modify-writes)
+  int alternating = -1;
+  if (a.gx_full && D == 2 * k0 && k0 == 32 * K0S && (D & 3) == 0 && ((uintptr_t)a.gx_full & 15u) == 0 && (ids[0] == 0 || ids[0] == 1)) {
+    alternating = ids[0];
+    for (int j = 1; j < k0; ++j)
+      if (ids[j] != 2 * j + ids[0]) alternating = -1;
+  }
 
   auto make_operand = [&](const f32x4 (&v)[4], f16x8 (&bh)[2], f16x8 (&bl)[2]) __attribute__((always_inline)) {
     float m = 0.f;
@@ -293,9 +303,37 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
       const float ug = make_operand(gh, bh, bl);
       product(kWtLds ? wts + lane : wtl + (size_t)(2 * NB * kFragL) * 64, 2, I2K{}, bh, bl, acc);          // W0^T gh: rows = identity features
       const float c = ug * wun[0];
-      float4* out = reinterpret_cast<float4*>(a.gxid + row * (32 * K0S));
+      if (a.gx_full) {
+        float* grow = a.gx_full + row * a.D;
+        if (alternating >= 0) {
+          // identity columns 2 j + alternating (the alternating masks of a coupling stack): this lane's four values of
+          // tile t belong to eight consecutive columns -- two 16-byte read-modify-writes instead of four 4-byte ones
 #pragma unroll
-      for (int t = 0; t < 2 * K0S; ++t) out[4 * t + g] = float4{acc[t][0] * c, acc[t][1] * c, acc[t][2] * c, acc[t][3] * c};
+          for (int t = 0; t < 2 * K0S; ++t) {
+            float4* p4 = reinterpret_cast<float4*>(grow + 2 * (16 * t + 4 * g));
+            float4 u = p4[0], v = p4[1];
+            if (alternating == 0) {
+              u.x += acc[t][0] * c; u.z += acc[t][1] * c; v.x += acc[t][2] * c; v.z += acc[t][3] * c;
+            } else {
+              u.y += acc[t][0] * c; u.w += acc[t][1] * c; v.y += acc[t][2] * c; v.w += acc[t][3] * c;
+            }
+            p4[0] = u;
+            p4[1] = v;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 2 * K0S; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = 16 * t + 4 * g + r;
+              if (j < k0) grow[ids[j]] += acc[t][r] * c;
+            }
+        }
+      } else {
+        float4* out = reinterpret_cast<float4*>(a.gxid + row * (32 * K0S));
+#pragma unroll
+        for (int t = 0; t < 2 * K0S; ++t) out[4 * t + g] = float4{acc[t][0] * c, acc[t][1] * c, acc[t][2] * c, acc[t][3] * c};
+      }
     }
   }
   __syncthreads();
@@ -332,21 +370,20 @@ static hipError_t launch_hid_bwd(const HidBwdArgs& a, hipStream_t s) {
 
 }  // namespace fc
 
-extern "C" int fc_resnet_hidden_backward(const float* x, const float* grad_h, const int32_t* id_cols, const void* w_frag,
-                                         const void* wt_frag, const float* w_unscale, const float* bias_acc,
-                                         float* grad_x_id, float* grad_w0, float* grad_wb, float* grad_b, int64_t n,
-                                         int32_t d, int32_t in_features, int32_t hidden, int32_t num_blocks,
-                                         int32_t activation, void* stream) {
+static int hidden_backward_entry(const float* x, const float* grad_h, const int32_t* id_cols, const void* w_frag,
+                                 const void* wt_frag, const float* w_unscale, const float* bias_acc, float* grad_x_id,
+                                 float* grad_x_full, float* grad_w0, float* grad_wb, float* grad_b, int64_t n, int32_t d,
+                                 int32_t in_features, int32_t hidden, int32_t num_blocks, int32_t activation, void* stream) {
   if (n < 0 || d <= 0 || hidden != 64 || num_blocks < 0 || num_blocks > 2 || activation != FC_ACT_RELU) return hipErrorInvalidValue;
   if (in_features <= 0 || in_features > 64 || in_features > d) return hipErrorInvalidValue;
   if (n % fc::kHbS != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
-  if (!x || !grad_h || !id_cols || !w_frag || !wt_frag || !w_unscale || !bias_acc || !grad_x_id || !grad_w0 || !grad_b ||
-      (num_blocks > 0 && !grad_wb))
+  if (!x || !grad_h || !id_cols || !w_frag || !wt_frag || !w_unscale || !bias_acc || (!grad_x_id == !grad_x_full) || !grad_w0 ||
+      !grad_b || (num_blocks > 0 && !grad_wb))
     return hipErrorInvalidValue;
   if ((((uintptr_t)grad_h | (uintptr_t)grad_x_id | (uintptr_t)w_frag | (uintptr_t)wt_frag) & 15u) != 0) return hipErrorInvalidValue;
   fc::HidBwdArgs a{x, grad_h, id_cols, static_cast<const fc::f16x8*>(w_frag), static_cast<const fc::f16x8*>(wt_frag),
-                   w_unscale, bias_acc, grad_x_id, grad_w0, grad_wb, grad_b, n / fc::kHbS, d, in_features};
+                   w_unscale, bias_acc, grad_x_id, grad_x_full, grad_w0, grad_wb, grad_b, n / fc::kHbS, d, in_features};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool wide = in_features > 32;
   switch (num_blocks * 2 + (wide ? 1 : 0)) {
@@ -357,4 +394,22 @@ extern "C" int fc_resnet_hidden_backward(const float* x, const float* grad_h, co
     case 4: return fc::launch_hid_bwd<2, 1>(a, s);
     default: return fc::launch_hid_bwd<2, 2>(a, s);
   }
+}
+
+extern "C" int fc_resnet_hidden_backward(const float* x, const float* grad_h, const int32_t* id_cols, const void* w_frag,
+                                         const void* wt_frag, const float* w_unscale, const float* bias_acc,
+                                         float* grad_x_id, float* grad_w0, float* grad_wb, float* grad_b, int64_t n,
+                                         int32_t d, int32_t in_features, int32_t hidden, int32_t num_blocks,
+                                         int32_t activation, void* stream) {
+  return hidden_backward_entry(x, grad_h, id_cols, w_frag, wt_frag, w_unscale, bias_acc, grad_x_id, nullptr, grad_w0, grad_wb,
+                               grad_b, n, d, in_features, hidden, num_blocks, activation, stream);
+}
+
+extern "C" int fc_resnet_hidden_backward_accum(const float* x, const float* grad_h, const int32_t* id_cols, const void* w_frag,
+                                               const void* wt_frag, const float* w_unscale, const float* bias_acc,
+                                               float* grad_x_full, float* grad_w0, float* grad_wb, float* grad_b, int64_t n,
+                                               int32_t d, int32_t in_features, int32_t hidden, int32_t num_blocks,
+                                               int32_t activation, void* stream) {
+  return hidden_backward_entry(x, grad_h, id_cols, w_frag, wt_frag, w_unscale, bias_acc, nullptr, grad_x_full, grad_w0, grad_wb,
+                               grad_b, n, d, in_features, hidden, num_blocks, activation, stream);
 }

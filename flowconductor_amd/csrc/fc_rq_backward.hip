@@ -220,6 +220,7 @@ extern "C" int fc_rq_spline_backward(const float* x, const float* params, const 
   q.min_d = (float)cfg->min_derivative;
   q.cw = (float)(1.0 - cfg->min_bin_width * q.K);
   q.ch = (float)(1.0 - cfg->min_bin_height * q.K);
+  fc::rq_finish_params(q);
   q.wh_div = cfg->wh_divisor > 0.f ? cfg->wh_divisor : 1.f;
   q.beta = cfg->softplus_beta;
   q.tail_const = cfg->tail_constant;

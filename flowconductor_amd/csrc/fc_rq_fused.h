@@ -26,6 +26,7 @@ struct FusedArgs {
   int D;
   int accumulate;        // logabsdet[n] += instead of = (FC_RQ_ACCUMULATE_LOGABSDET)
   int dt;                // transformed dims, <= 32 (wpad / bias hold ceil(dt / 4) * 4 dims)
+  int wrows;             // rows per dim in wpad / bias: 24 (zero-padded) or 23 (the nn.Linear tensors as they are, dt dims)
 };
 
 size_t fused3_lds_bytes(int d, int rows);

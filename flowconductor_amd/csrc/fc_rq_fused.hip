@@ -44,6 +44,7 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
   q.min_w = (float)cfg->min_bin_width; q.min_h = (float)cfg->min_bin_height; q.min_d = (float)cfg->min_derivative;
   q.cw = (float)(1.0 - cfg->min_bin_width * q.K);
   q.ch = (float)(1.0 - cfg->min_bin_height * q.K);
+  fc::rq_finish_params(q);
   q.wh_div = cfg->wh_divisor > 0.f ? cfg->wh_divisor : 1.f;
   q.beta = cfg->softplus_beta;
   q.tail_const = cfg->tail_constant;
@@ -51,6 +52,7 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
   op.inv_beta = 1.f / q.beta;
 
   const int acc = (cfg->flags & FC_RQ_ACCUMULATE_LOGABSDET) ? 1 : 0;
+  const int wrows = (cfg->flags & FC_RQ_RAW_WEIGHTS) ? fc::kPP - 1 : fc::kPP;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int64_t cus = fc::device_cu_count();   // one persistent 512-thread workgroup per CU
   // 64-row tiles (fewer barriers and tile hand-overs per row) when their LDS image fits, 32-row tiles for very
@@ -58,13 +60,13 @@ extern "C" int fc_rq_spline_fused_linear(const float* x, float* y, const float* 
   const bool wide_ok = fc::fused3_lds_bytes(d, 64) <= 160 * 1024;
   const int64_t n64 = wide_ok ? n - n % 64 : 0;
   if (n64 > 0) {
-    fc::FusedArgs a{x, y, h, w_pad, bias_pad, cols, logabsdet, err_flag, n64 / 64, d, acc, d_t};
+    fc::FusedArgs a{x, y, h, w_pad, bias_pad, cols, logabsdet, err_flag, n64 / 64, d, acc, d_t, wrows};
     const hipError_t e = fc::launch_fused3(op, a, 64, (unsigned)(cus < a.tiles ? cus : a.tiles), s);
     if (e != hipSuccess) return e;
   }
   if (n64 < n) {
     fc::FusedArgs a{x + n64 * d, y + n64 * d, h + n64 * fc::kH, w_pad, bias_pad, cols, logabsdet + n64, err_flag,
-                    (n - n64) / 32, d, acc, d_t};
+                    (n - n64) / 32, d, acc, d_t, wrows};
     return fc::launch_fused3(op, a, 32, (unsigned)(cus < a.tiles ? cus : a.tiles), s);
   }
   return hipSuccess;

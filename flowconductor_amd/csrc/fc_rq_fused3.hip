@@ -124,11 +124,16 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     float wmax = 0.f;
 #pragma unroll
     for (int t = 0; t < kCt3; ++t) {
-      const int row = (4 * (active ? wave : 0) + (s16 >> 2)) * kPP + slot_param(4 * t + (s16 & 3));
+      // (padding rows -- parameter 23 of a dim, dims beyond dt -- are zeros: read as such whether or not the arrays
+      //  carry them, a.wrows = 24 or 23)
+      const int wdim = 4 * (active ? wave : 0) + (s16 >> 2), wprm = slot_param(4 * t + (s16 & 3));
+      const bool wreal = wprm < kPP - 1 && wdim < a.dt;
+      const int row = wreal ? wdim * a.wrows + wprm : 0;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const float4* src = reinterpret_cast<const float4*>(a.wpad + (int64_t)row * kH + 32 * ks + 8 * g);
-        const float4 v0 = src[0], v1 = src[1];
+        const float4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const float4 v0 = wreal ? src[0] : z4, v1 = wreal ? src[1] : z4;
         const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -161,10 +166,14 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   f32x4 bw[kCt3];
 #pragma unroll
   for (int t = 0; t < kCt3; ++t) {
-    const float* bsrc = a.bias + (4 * (active ? wave : 0) + g) * kPP + 4 * t;
+    const int bdim = 4 * (active ? wave : 0) + g;
+    const float* bsrc = a.bias + bdim * a.wrows;
     const float m = t < 4 ? wh_mul : 1.f;   // params 0..15 are widths and heights
-    bw[t] = f32x4{bsrc[slot_param(4 * t) - 4 * t] * m, bsrc[slot_param(4 * t + 1) - 4 * t] * m,
-                  bsrc[slot_param(4 * t + 2) - 4 * t] * m, bsrc[slot_param(4 * t + 3) - 4 * t] * m};
+    auto bias_of = [&](int slot) {
+      const int prm = slot_param(slot);
+      return (prm < kPP - 1 && bdim < a.dt) ? bsrc[prm] * m : 0.f;
+    };
+    bw[t] = f32x4{bias_of(4 * t), bias_of(4 * t + 1), bias_of(4 * t + 2), bias_of(4 * t + 3)};
   }
   // Knot constants of fc_rq_fused3_eval.inc (x: widths axis, y: heights axis), formed in double once per kernel:
   // knot_{i+1} = kc_i + (sum of the first i + 1 softmax numerators) * (sc1 / their total) for the lower half, and

@@ -19,7 +19,31 @@ struct RQParams {
   float wh_div;     // unnormalised widths/heights are divided by this (coupling.py:554-559); 1 = off
   float beta;       // softplus beta: 1, or ln2/(1-min_d) with enable_identity_init
   float tail_const; // (float)log(exp(1 - min_d) - 1): padded end derivatives for linear tails
+  // knot constants of walk_both (static bin counts <= 16), formed in double by rq_finish_params:
+  //   sc1 = span c1;  kc_i = lo + span min (i + 1) for i < K / 2,  hi - span min (K - 1 - i) for K / 2 <= i <= K - 2
+  float sc1x, sc1y;
+  float kcx[15], kcy[15];
 };
+
+// host: call after left .. top, min_w / min_h, cw / ch and K are set
+inline void rq_finish_params(RQParams& q) {
+  const double sx = (double)q.right - (double)q.left, sy = (double)q.top - (double)q.bottom;
+  q.sc1x = (float)(sx * (double)q.cw);
+  q.sc1y = (float)(sy * (double)q.ch);
+  const int K = q.K < 16 ? q.K : 16, H = K / 2;
+  for (int i = 0; i < 15; ++i) {
+    if (i > K - 2) {
+      q.kcx[i] = q.right;
+      q.kcy[i] = q.top;
+    } else if (i < H) {
+      q.kcx[i] = (float)((double)q.left + sx * (double)q.min_w * (double)(i + 1));
+      q.kcy[i] = (float)((double)q.bottom + sy * (double)q.min_h * (double)(i + 1));
+    } else {
+      q.kcx[i] = (float)((double)q.right - sx * (double)q.min_w * (double)(K - 1 - i));
+      q.kcy[i] = (float)((double)q.top - sy * (double)q.min_h * (double)(K - 1 - i));
+    }
+  }
+}
 
 // Walk the K bins of one cumulative axis. u -> LDS pointer to K unnormalised values.
 // search: idx = last bin whose lower knot <= v (== compare-count - 1 for monotone knots).
@@ -110,43 +134,61 @@ __device__ __forceinline__ float exp_softmax(float x) {
   return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
 
-// Both cumulative axes in one pass, widths in .x and heights in .y so that the mul/add chain maps to
-// packed v_pk_{mul,add}_f32 (2 lanes of work per VALU slot).  The bin is searched on one axis
-// (kSearchX: widths, forward; else heights, inverse); knots are monotone, so "last bin whose lower
-// knot <= v" is tracked by one predicate that selects on both axes.
+// Both cumulative axes in one pass, widths in .x and heights in .y (packed v_pk_{add,fma}_f32: two lanes of work per
+// VALU slot).  The knots are affine in partial sums of the softmax NUMERATORS e_i = exp(u_i - max):
+//   knot_{i+1} = lo + span sum_{j<=i} (min + c1 e_j / total) = kc_i + l_i (span c1 / total),  l_i = e_0 + .. + e_i       (i <  K/2)
+//              = hi - span sum_{j>i}  (min + c1 e_j / total) = kc_i - r_i (span c1 / total),  r_i = e_{i+1} + .. + e_{K-1} (i >= K/2)
+// so a knot pair costs one packed fma instead of normalising, offsetting, accumulating (in double) and scaling each bin;
+// summing from the nearer end keeps every partial sum <= K/2 - 1 float additions deep and about half of the total in
+// size (error against float64 below the float32 reference's own: tools/probe/fused_accuracy.py).  The bin is searched on
+// one axis (kSearchX: widths, forward; else heights, inverse); knots are monotone, so "last bin whose lower knot <= v" is
+// tracked by one predicate that selects on both axes.
 template <int KS, bool kSearchX>
 __device__ __forceinline__ void walk_both(const float* __restrict__ uw, const float* __restrict__ uh,
-                                          float inv_scale, f2 minb, f2 c1, f2 lo, f2 hi, float v, int& idx,
+                                          float inv_scale, const RQParams& q, float v, int& idx,
                                           f2& knot_lo, f2& bin_size) {
+  constexpr int H = KS / 2;
   f2 t[KS > 0 ? KS : 1];
   float mx = -INFINITY, my = -INFINITY;
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
-    t[i] = f2{uw[i], uh[i]} * inv_scale;
+    t[i] = f2{uw[i], uh[i]};
     mx = fmaxf(mx, t[i].x);
     my = fmaxf(my, t[i].y);
   }
   const f2 m = {mx, my};
-  f2 sum = {0.f, 0.f};
+  const float c2 = inv_scale * 1.4426950408889634f;      // exp(d / wh_div) = exp2(d c2); inv_scale > 0 keeps the maximum
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
-    const f2 d = t[i] - m;
-    t[i] = f2{exp_softmax(d.x), exp_softmax(d.y)};
-    sum += t[i];
+    const f2 d = (t[i] - m) * c2;
+    t[i] = f2{__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
   }
-  const f2 rs = {div_lean(1.f, sum.x), div_lean(1.f, sum.y)};
-  const f2 span = hi - lo;
-  double cx = 0.0, cy = 0.0;  // at::cumsum on the CPU accumulates f32 in double
+  f2 part[KS > 0 ? KS : 1];       // part[i] = l_i (i < H), r_i (H - 1 <= i <= KS - 2; slot H - 1 holds r until the total is formed)
+  f2 run = t[0];
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    if (i > 0) run += t[i];
+    part[i] = run;
+  }
+  const f2 l_last = run;
+  run = t[KS - 1];
+#pragma unroll
+  for (int i = KS - 2; i >= H; --i) {
+    part[i] = run;
+    run += t[i];
+  }
+  const f2 tot = l_last + run;     // run = e_H + .. + e_{K-1}
+  const f2 g = f2{q.sc1x, q.sc1y} * f2{div_lean(1.f, tot.x), div_lean(1.f, tot.y)};
+  const f2 lo = {q.left, q.bottom}, hi = {q.right, q.top};
   f2 prev = lo, sel_lo = lo, sel_hi = lo;
   int found = 0;
 #pragma unroll
   for (int i = 0; i < KS; ++i) {
-    const f2 p = t[i] * rs;
-    const f2 w = minb + c1 * p;
-    cx += (double)w.x;
-    cy += (double)w.y;
-    const f2 cum = {(float)cx, (float)cy};
-    const f2 next = (i == KS - 1) ? hi : (span * cum + lo);
+    f2 next = hi;
+    if (i < KS - 1) {
+      const f2 kc = {q.kcx[i], q.kcy[i]};
+      next = i < H ? __builtin_elementwise_fma(part[i], g, kc) : __builtin_elementwise_fma(part[i], -g, kc);
+    }
     const bool take = v >= (kSearchX ? prev.x : prev.y);
     sel_lo.x = take ? prev.x : sel_lo.x;
     sel_lo.y = take ? prev.y : sel_lo.y;
@@ -187,11 +229,9 @@ struct RQOp {
     static_assert(KS > 0, "static bin count required");
     const bool inside = (x >= q.left) && (x <= q.right);
     const float xc = inside ? x : q.left;
-    const f2 minb = {q.min_w, q.min_h}, c1 = {q.cw, q.ch};
-    const f2 lo = {q.left, q.bottom}, hi = {q.right, q.top};
     int idx;
     f2 klo, bsz;
-    walk_both<KS, !kInverse>(p, p + KS, inv_div, minb, c1, lo, hi, xc, idx, klo, bsz);
+    walk_both<KS, !kInverse>(p, p + KS, inv_div, q, xc, idx, klo, bsz);
     const float xk = klo.x, yk = klo.y, wk = bsz.x, hk = bsz.y;
     const float* ud = p + 2 * KS;
     const float r0 = ud[idx > 0 ? idx - 1 : 0], r1 = ud[idx < KS - 1 ? idx : KS - 2];
@@ -253,13 +293,11 @@ struct RQOp {
     int idx = 0;
     float xk, wk, yk, hk;
     if constexpr (KS > 0) {
-      const f2 minb = {q.min_w, q.min_h}, c1 = {q.cw, q.ch};
-      const f2 lo = {q.left, q.bottom}, hi = {q.right, q.top};
       f2 klo, bsz;
       if (!q.inverse)
-        walk_both<KS, true>(p, p + K, inv_div, minb, c1, lo, hi, x, idx, klo, bsz);
+        walk_both<KS, true>(p, p + K, inv_div, q, x, idx, klo, bsz);
       else
-        walk_both<KS, false>(p, p + K, inv_div, minb, c1, lo, hi, x, idx, klo, bsz);
+        walk_both<KS, false>(p, p + K, inv_div, q, x, idx, klo, bsz);
       xk = klo.x; yk = klo.y; wk = bsz.x; hk = bsz.y;
     } else if (!q.inverse) {
       walk_axis<KS, true>(p, K, inv_div, q.min_w, q.cw, q.left, q.right, x,

@@ -199,16 +199,20 @@ class ResidualNet(nn.Module):
         from flowconductor_amd import ops
 
         # persistent device-side pack plan (one launch per refresh); rebuilt when the parameter storages moved
+        plan = self.hidden_backward_plan()
+        plan[1].refresh()
+        return plan[2]
+
+    def hidden_backward_plan(self):
+        """[where, DevicePack, packed] of the training-time images (not refreshed here)."""
+        from flowconductor_amd import ops
+
         where = self._storage_key()
         plan = getattr(self, "_hip_packed_bwd", None)
         if plan is None or plan[0] != where:
             pack, packed = ops.device_pack_resnet_hidden_backward(self)
-            plan = self._hip_packed_bwd = [where, pack, packed, None]
-        key = ops.cache_key(*self.parameters())
-        if plan[3] != key:
-            plan[1].run()
-            plan[3] = key
-        return plan[2]
+            plan = self._hip_packed_bwd = [where, pack, packed]
+        return plan
 
     def hidden_padded(self, inputs, context=None):
         """``hidden`` on PyTorch, zero-padded to the kernel's 64 columns (leftover rows next to ``hidden_hip``)."""
@@ -236,15 +240,18 @@ class ResidualNet(nn.Module):
         in_features = self.initial_layer.in_features - (self.context_features or 0)
         act = ops.activation_code(self.blocks[0].activation) if len(self.blocks) else (ops.ACT_RELU, 0.0)
         if context is None:
-            # weight image made once on the device (one launch per refresh), copied into LDS by every launch
+            # weight image made on the device (one launch per refresh), copied into LDS by every launch.  In training
+            # mode the image is the forward part of the backward kernel's images (same layout): one refresh per
+            # optimizer step serves both directions.
+            if self.training and torch.is_grad_enabled() and self.hip_hidden_backward_supported():
+                w_frag, _, w_un, bias_acc, _ = self.hidden_backward_packed()
+                return ops.resnet_hidden_packed(rows, id_cols, (w_frag, w_un, bias_acc), in_features, len(self.blocks), act)
             where = self._storage_key()
             plan = getattr(self, "_hip_image", None)
             if plan is None or plan[0] != where:
                 pack, packed = ops.device_pack_resnet_hidden_forward(self)
-                plan = self._hip_image = [where, pack, packed, None]
-            if plan[3] != key:
-                plan[1].run()
-                plan[3] = key
+                plan = self._hip_image = [where, pack, packed]
+            plan[1].refresh()
             return ops.resnet_hidden_packed(rows, id_cols, plan[2], in_features, len(self.blocks), act)
         if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
             self._hip_packed = (key, ops.pack_resnet_hidden(self))

@@ -512,7 +512,10 @@ class DevicePack:
         self.device = device
         self.jobs = []
         self.keep = []            # tensors the jobs point into
+        self.sources = []         # the parameters the jobs read (their versions say when a refresh is due)
         self._jobs_dev = None
+        self._root = None         # the pack this one was merged into
+        self._key = None
 
     def add(self, mode, weight, bias, frag, unscale, bias_out=None, p=0, pp=0, nks=0, nt=0, group=0):
         if not weight.is_contiguous() or weight.dtype != torch.float32:
@@ -525,16 +528,52 @@ class DevicePack:
         job.mode, job.p, job.pp, job.nks, job.nt, job.group = mode, p, pp, nks, nt, group
         self.jobs.append(job)
         self.keep += [weight, bias, frag, unscale, bias_out]
+        self.sources += [t for t in (weight, bias) if t is not None]
+
+    def root(self):
+        node = self
+        while node._root is not None:
+            node = node._root
+        return node
+
+    def merge(self, other):
+        """Take over ``other``'s jobs: one launch then refreshes both (a coupling layer's final-layer and hidden-stack
+        images change together, once per optimizer step)."""
+        mine, theirs = self.root(), other.root()
+        if mine is theirs:
+            return
+        if theirs.device != mine.device:
+            raise ValueError("DevicePack.merge: packs live on different devices")
+        mine.jobs += theirs.jobs
+        mine.keep += theirs.keep
+        mine.sources += theirs.sources
+        mine._jobs_dev = mine._key = None
+        theirs.jobs, theirs.keep, theirs.sources, theirs._jobs_dev = [], [], [], None
+        theirs._root = mine
 
     def run(self):
+        pack = self.root()
         lib = _hip.load()
-        if self._jobs_dev is None:
+        if pack._jobs_dev is None:
             if lib.fc_pack_job_bytes() != ctypes.sizeof(_hip.PackJob):
                 raise RuntimeError("fc_pack_job layout mismatch between the header and the ctypes mirror")
-            raw = b"".join(bytes(j) for j in self.jobs)
-            self._jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-        _call("fc_pack_fragments", lib.fc_pack_fragments, self.device, _hip.ptr(self._jobs_dev), len(self.jobs),
-              _hip.stream_ptr(self.device))
+            raw = b"".join(bytes(j) for j in pack.jobs)
+            pack._jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(pack.device)
+        _call("fc_pack_fragments", lib.fc_pack_fragments, pack.device, _hip.ptr(pack._jobs_dev), len(pack.jobs),
+              _hip.stream_ptr(pack.device))
+
+    def refresh(self):
+        """``run()`` if any source parameter changed since the last refresh (``cache_key``: versions + cache epoch)."""
+        pack = self.root()
+        seen, srcs = set(), []
+        for t in pack.sources:
+            if id(t) not in seen:
+                seen.add(id(t))
+                srcs.append(t)
+        key = cache_key(*srcs)
+        if pack._key != key:
+            pack.run()
+            pack._key = key
 
 
 def device_pack_final_layer(weight, bias, num_bins, tails, cols_chunks):
@@ -664,10 +703,11 @@ def pack_resnet_hidden_backward(net):
             torch.stack(biases).contiguous(), k0s)
 
 
-def resnet_hidden_backward(inputs, grad_hidden, id_cols, packed, in_features, num_blocks):
+def resnet_hidden_backward(inputs, grad_hidden, id_cols, packed, in_features, num_blocks, grad_inputs_accum=None):
     """Backward of ``resnet_hidden`` (hidden 64, <= 2 ReLU blocks, no context; rows a multiple of 128): returns
     ``(grad_x_id [N, in_features], grad_w0 [64, in_features], grad_wb [2 blocks, 64, 64], grad_b [L, 64])`` with the
-    activations recomputed from ``inputs``."""
+    activations recomputed from ``inputs``.  With ``grad_inputs_accum`` [N, D] the gradient wrt the identity columns is
+    added into it in place (``fc_resnet_hidden_backward_accum``) and the first result is None."""
     lib = _hip.load()
     x = _prep_2d(inputs.detach())
     gh = _aligned16(_hip.dev_f32(grad_hidden, "grad_hidden"))
@@ -677,16 +717,21 @@ def resnet_hidden_backward(inputs, grad_hidden, id_cols, packed, in_features, nu
     w_frag, wt_frag, w_un, bias_acc, k0s = packed
     ids = _as_cols(id_cols, x.device)
     layers = 1 + 2 * num_blocks
-    gxid = torch.empty(n, 32 * k0s, dtype=torch.float32, device=x.device)
+    if grad_inputs_accum is not None and (grad_inputs_accum.shape != x.shape or not grad_inputs_accum.is_contiguous()
+                                          or grad_inputs_accum.dtype != torch.float32):
+        raise ValueError("grad_inputs_accum must be a contiguous float32 [N, D] tensor")
+    gxid = None if grad_inputs_accum is not None else torch.empty(n, 32 * k0s, dtype=torch.float32, device=x.device)
     nb2 = max(1, 2 * num_blocks)
     acc = torch.zeros(64 * 32 * k0s + nb2 * 4096 + layers * 64, dtype=torch.float32, device=x.device)   # one memset
     gw0 = acc[:64 * 32 * k0s].view(64, 32 * k0s)
     gwb = acc[64 * 32 * k0s:64 * 32 * k0s + nb2 * 4096].view(nb2, 64, 64)
     gb = acc[64 * 32 * k0s + nb2 * 4096:].view(layers, 64)
-    _call("fc_resnet_hidden_backward", lib.fc_resnet_hidden_backward, x.device, _hip.ptr(x), _hip.ptr(gh), _hip.ptr(ids),
-          _hip.ptr(w_frag), _hip.ptr(wt_frag), _hip.ptr(w_un), _hip.ptr(bias_acc), _hip.ptr(gxid), _hip.ptr(gw0),
+    fn = lib.fc_resnet_hidden_backward if gxid is not None else lib.fc_resnet_hidden_backward_accum
+    _call("fc_resnet_hidden_backward", fn, x.device, _hip.ptr(x), _hip.ptr(gh), _hip.ptr(ids),
+          _hip.ptr(w_frag), _hip.ptr(wt_frag), _hip.ptr(w_un), _hip.ptr(bias_acc),
+          _hip.ptr(gxid if gxid is not None else grad_inputs_accum), _hip.ptr(gw0),
           _hip.ptr(gwb), _hip.ptr(gb), n, d, in_features, 64, num_blocks, ACT_RELU, _hip.stream_ptr(x.device))
-    return gxid[:, :in_features], gw0[:, :in_features], gwb, gb
+    return (None if gxid is None else gxid[:, :in_features]), gw0[:, :in_features], gwb, gb
 
 
 def resnet_hidden_wide(inputs, id_cols, packed, in_features, num_blocks, width, activation=(ACT_RELU, 0.0)):
@@ -774,9 +819,13 @@ def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, t
     n, d = x.shape
     cols = _as_cols(cols, x.device)
     d_t = cols.numel()
+    raw = w_pad.shape[0] == d_t * 23          # the nn.Linear tensors as they are (FC_RQ_RAW_WEIGHTS)
     if (n % FUSED_ROWS != 0 or h.shape != (n, FUSED_HIDDEN) or not 1 <= d_t <= FUSED_DT
-            or w_pad.shape[0] != -(-d_t // 4) * 4 * 24):
+            or (not raw and w_pad.shape[0] != -(-d_t // 4) * 4 * 24) or w_pad.shape[1] != FUSED_HIDDEN
+            or bias_pad.numel() != w_pad.shape[0]):
         raise ValueError("fused RQ layer: unsupported shapes %s / %s" % (tuple(x.shape), tuple(h.shape)))
+    w_pad = _aligned16(_hip.dev_f32(w_pad.detach(), "weight"))
+    bias_pad = _hip.dev_f32(bias_pad.detach(), "bias")
     cfg = _hip.RQConfig()
     cfg.num_bins, cfg.tails, cfg.inverse = num_bins, 1, 1 if inverse else 0
     cfg.left, cfg.right, cfg.bottom, cfg.top = -tail_bound, tail_bound, -tail_bound, tail_bound
@@ -792,6 +841,8 @@ def rq_spline_fused_linear(inputs, hidden, w_pad, bias_pad, cols, *, num_bins, t
         cfg.flags = 1  # FC_RQ_ACCUMULATE_LOGABSDET
     else:
         lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    if raw:
+        cfg.flags |= 4  # FC_RQ_RAW_WEIGHTS
     err = _err_word(x.device, True)
     _call("fc_rq_spline_fused_linear", lib.fc_rq_spline_fused_linear, x.device, _hip.ptr(x), _hip.ptr(y),
           _hip.ptr(h), _hip.ptr(w_pad), _hip.ptr(bias_pad), _hip.ptr(cols), _hip.ptr(lad), _hip.ptr(err), n, d,

@@ -366,11 +366,11 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
                 spec.append((slice(lo * per_dim, hi * per_dim), cols[lo:hi].contiguous()))
             pack, chunks = ops.device_pack_final_layer(lin.weight.detach(), lin.bias.detach(), self.num_bins, self.tails,
                                                        spec)
-            plan = self._train_pack = [lin.weight, lin.weight.data_ptr(), pack, chunks, None]
-        key = ops.cache_key(lin.weight, lin.bias)
-        if plan[4] != key:
-            plan[2].run()
-            plan[4] = key
+            net = self.transform_net
+            if getattr(net, "hip_hidden_backward_supported", None) is not None and net.hip_hidden_backward_supported():
+                pack.merge(net.hidden_backward_plan()[1])      # the hidden stack's images ride in the same launch
+            plan = self._train_pack = [lin.weight, lin.weight.data_ptr(), pack, chunks]
+        plan[2].refresh()
         return plan[3]
 
     def _apply_accumulate(self, inputs, context, inverse, total):
@@ -518,10 +518,9 @@ class _FusedRQCouplingFunction(torch.autograd.Function):
                                             net.hidden_features, layer.num_bins, layer.tails)
             lin = net.final_layer
             for w_frag, w_un, bias_pad, _, cols, rows_slice in layer._train_chunks(x.device):
-                if k8:    # the hand-scheduled north-star kernel takes the f32 weights (rows padded 23 -> 24)
-                    w_pad, b_pad = ops.pack_final_layer(lin.weight[rows_slice], lin.bias[rows_slice], layer.num_bins)
-                    rows, lad = ops.rq_spline_fused_linear(rows, hidden, w_pad, b_pad, cols, logabsdet_accum=lad,
-                                                           inverse=False, **kw)
+                if k8:    # the hand-scheduled north-star kernel takes the f32 weights as they are
+                    rows, lad = ops.rq_spline_fused_linear(rows, hidden, lin.weight[rows_slice], lin.bias[rows_slice], cols,
+                                                           logabsdet_accum=lad, inverse=False, **kw)
                 else:
                     rows, lad = ops.rq_spline_fused_general(rows, hidden, w_frag, w_un, bias_pad, cols,
                                                             tails=layer.tails, logabsdet_accum=lad, inverse=False, **kw)
@@ -561,9 +560,10 @@ class _FusedRQCouplingFunction(torch.autograd.Function):
         by_id = {id(lin.weight): grad_w, id(lin.bias): grad_b}
         if net.hip_hidden_backward_supported():
             # hidden stack in fc_resnet_hidden_backward: activations recomputed from the identity columns in registers
-            gxid, gw0, gwb, gb = ops.resnet_hidden_backward(x, gh, layer._id_cols(x.device), net.hidden_backward_packed(),
-                                                            net.initial_layer.in_features, len(net.blocks))
-            g.index_add_(1, layer.identity_features, gxid)
+            # (the gradient wrt the identity columns goes straight into g: g owns its storage here -- it is the gx output
+            #  of the fused backward launch above, never the caller's grad_outputs)
+            _, gw0, gwb, gb = ops.resnet_hidden_backward(x, gh, layer._id_cols(x.device), net.hidden_backward_packed(),
+                                                         net.initial_layer.in_features, len(net.blocks), grad_inputs_accum=g)
             hf = net.hidden_features
             by_id[id(net.initial_layer.weight)] = gw0[:hf]
             by_id[id(net.initial_layer.bias)] = gb[0, :hf]

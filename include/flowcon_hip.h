@@ -43,6 +43,8 @@ int fc_abi_version(void);
                                        total of CompositeTransform._cascade, transforms/base.py:45-52) */
 #define FC_RQ_FORCE_TILE 2 /* fc_rq_spline: always the LDS-tile kernel, never the register / wave kernel (A/B
                               measurements; the results are the same) */
+#define FC_RQ_RAW_WEIGHTS 4 /* fc_rq_spline_fused_linear: w_pad / bias_pad are the final nn.Linear's tensors as they
+                               are, [d_t * 23, 64] and [d_t * 23] (no padding rows; same results) */
 
 typedef struct fc_rq_config {
   int32_t num_bins;       /* K */
@@ -71,7 +73,7 @@ int fc_rq_spline(const float* x, float* y, const float* params, const int32_t* c
 /* Final conditioner layer fused with the RQ-spline coupling bijector: the [n, d_t*(3K-1)] parameter
  * tensor  h @ W^T + b  (flowcon/nn/nets/resnet.py:91,99 final_layer) is produced on the matrix cores (three-term
  * scaled f16 splits, f32-GEMM accuracy) straight into the registers of the lanes that evaluate the spline
- * (coupling.py:279-293, 549-582); it never reaches HBM.  cfg->flags: FC_RQ_ACCUMULATE_LOGABSDET.  Specialised: hidden == 64, 1 <= d_t <= 32, K == 8, linear tails, d <= 128,
+ * (coupling.py:279-293, 549-582); it never reaches HBM.  cfg->flags: FC_RQ_ACCUMULATE_LOGABSDET, FC_RQ_RAW_WEIGHTS.  Specialised: hidden == 64, 1 <= d_t <= 32, K == 8, linear tails, d <= 128,
  * n % 32 == 0 (callers route other shapes / the leftover rows through fc_rq_spline).
  *   h        [n, 64]  last hidden activation of the conditioner (input of its final Linear)
  *   w_pad    [dp*24, 64]  the weight, zero-padded from 23 to 24 rows per dim (row j*24+i = W row j*23+i, i < 23)
@@ -178,6 +180,14 @@ int fc_resnet_hidden_backward(const float* x, const float* grad_h, const int32_t
                               const void* wt_frag, const float* w_unscale, const float* bias_acc, float* grad_x_id,
                               float* grad_w0, float* grad_wb, float* grad_b, int64_t n, int32_t d, int32_t in_features,
                               int32_t hidden, int32_t num_blocks, int32_t activation, void* stream);
+
+/* The same, with the gradient wrt the identity columns ADDED into the full-width gradient of the layer input instead of
+ * written to its own [n, 32 K0S] tensor: grad_x_full[:, id_cols] += ... (every (row, identity column) is owned by one
+ * lane).  Saves the index_add pass over [n, d] that follows in a coupling layer's backward. */
+int fc_resnet_hidden_backward_accum(const float* x, const float* grad_h, const int32_t* id_cols, const void* w_frag,
+                                    const void* wt_frag, const float* w_unscale, const float* bias_acc, float* grad_x_full,
+                                    float* grad_w0, float* grad_wb, float* grad_b, int64_t n, int32_t d, int32_t in_features,
+                                    int32_t hidden, int32_t num_blocks, int32_t activation, void* stream);
 
 /* The same stack for WIDE conditioners: hidden in {128, 256} (hidden_features is a free constructor argument,
  * resnet.py:62; narrower widths zero-padded by the host), any num_blocks <= 16, no context.  The activations of a

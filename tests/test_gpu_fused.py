@@ -353,6 +353,25 @@ def test_fused_linear_input_widths(d, n, d_t, inverse, device):
     assert maxdiff(lad, ref_lad) <= tol_l * max(1.0, float(ref_lad.abs().max()) / 10)
 
 
+@pytest.mark.parametrize("d,d_t,n", [(64, 32, 4096), (44, 21, 2080), (12, 3, 96)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fused_linear_raw_weights_equal_padded(d, d_t, n, inverse, device):
+    """FC_RQ_RAW_WEIGHTS: the final Linear's [d_t * 23, 64] weight and bias as they are give the same bits as the
+    zero-padded [ceil(d_t / 4) * 4 * 24, 64] arrays (the kernel reads the padding rows as zeros either way)."""
+    torch.manual_seed(d + d_t)
+    x = torch.randn(n, d, device=device) * 1.5
+    h = torch.randn(n, 64, device=device)
+    w = torch.randn(d_t * 23, 64, device=device) * 0.2
+    b = torch.randn(d_t * 23, device=device) * 0.1
+    cols = torch.randperm(d)[:d_t].sort().values.to(device)
+    kw = dict(num_bins=8, tail_bound=3.0, wh_divisor=8.0, inverse=inverse)
+    wp, bp = ops.pack_final_layer(w, b)
+    with torch.no_grad():
+        y0, l0 = ops.rq_spline_fused_linear(x, h, wp, bp, cols, **kw)
+        y1, l1 = ops.rq_spline_fused_linear(x, h, w, b, cols, **kw)
+    assert torch.equal(y0, y1) and torch.equal(l0, l1)
+
+
 @pytest.mark.parametrize("kind", ["maf", "rq_ar"])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_made_hidden_stack_on_hip_kernel(kind, inverse, device, monkeypatch):
