@@ -75,24 +75,26 @@ def measured_traffic_per_launch(entry, rows_per_launch):
     return rec[entry]["traffic_bytes_per_launch"]
 
 
-def issue_bound(counters_file, launch_ms, rows_per_launch):
+def issue_bound(counters_file, launch_ms, rows_per_launch, valu_cycles):
     """How much of the SIMDs' instruction-issue time a compute-bound kernel uses: wave-level VALU and MFMA instruction
-    counts per launch from the committed SQ-counter passes (tools/probe/pmc_kernel.sh) priced at 4.3 / 8 issue cycles
-    (MI355X_MICROARCH.md: a 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles), against 256 CUs x 4
-    SIMDs x the 2.4 GHz peak clock over this run's launch duration.  None if the profile is absent."""
+    counts per launch from the committed SQ-counter passes (tools/probe/pmc_kernel.sh) priced at `valu_cycles` per VALU
+    instruction (measured, tools/probe/valu_costs.hip: ~3.6 at the fused kernel's two waves per SIMD, ~2.6 at the hidden
+    kernel's four; transcendentals twice that) and 8 per MFMA (MI355X_MICROARCH.md: a 16x16x32 MFMA holds the SIMD's vector
+    issue for 8 of its 16 cycles), against 256 CUs x 4 SIMDs x the 2.4 GHz peak clock over this run's launch duration
+    (the kernels sustain 2.1 / 1.8 GHz, so 1.0 is not reachable).  None if the profile is absent."""
     try:
         if rows_per_launch != (1 << 20):
             return None
         vals = {}
         for line in open(os.path.join(ROOT, counters_file)):
             parts = line.split()
-            if len(parts) >= 3 and parts[0] in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA"):
+            if len(parts) >= 3 and parts[0] in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_TRANS_F32"):
                 vals[parts[0]] = float(parts[2])
-        cycles = 4.3 * vals["SQ_INSTS_VALU"] + 8.0 * vals["SQ_INSTS_MFMA"]
+        cycles = valu_cycles * (vals["SQ_INSTS_VALU"] + vals.get("SQ_INSTS_VALU_TRANS_F32", 0.0)) + 8.0 * vals["SQ_INSTS_MFMA"]
         avail = 256 * 4 * 2.4e9 * launch_ms * 1e-3
         return {"valu_wave_instructions": vals["SQ_INSTS_VALU"], "mfma_wave_instructions": vals["SQ_INSTS_MFMA"],
-                "issue_cycles": cycles, "simd_cycles_at_2.4GHz": avail, "frac": cycles / avail,
-                "source": counters_file}
+                "cycles_per_valu_instruction": valu_cycles, "issue_cycles": cycles, "simd_cycles_at_2.4GHz": avail,
+                "frac": cycles / avail, "source": counters_file}
     except (OSError, ValueError, KeyError):
         return None
 
@@ -402,10 +404,10 @@ def main():
                                "algorithmic_bytes_per_launch": f_bytes,
                                "share_of_step": sum(fused_ms) / (1e3 * elapsed / args.steps),
                                "binding_resource": "valu_issue",
-                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r01h_fused_sq_counters.txt; "
+                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r02c_fused_sq_counters.txt; "
                                           "`frac` is the distance to the HBM roof the contract asks for, "
                                           "`issue_bound.frac` the share of the SIMDs' issue cycles in use",
-                               "issue_bound": issue_bound("profiles/r01h_fused_sq_counters.txt", f_avg, rows_per_launch),
+                               "issue_bound": issue_bound("profiles/r02c_fused_sq_counters.txt", f_avg, rows_per_launch, 3.6),
                                # BASELINE.md section 4 prices a coupling bijector at B = 4 d_t (P + 2) + 8 bytes per
                                # sample and layer (parameters read from HBM).  The fused kernel never moves them; in
                                # that accounting it delivers:
@@ -433,8 +435,8 @@ def main():
                                           "algorithmic_bytes_per_launch": h_bytes,
                                           "share_of_step": sum(hidden_ms) / (1e3 * elapsed / args.steps),
                                           "binding_resource": "mfma_issue / dependent-latency (a wave walks the layers serially)",
-                                          "issue_bound": issue_bound("profiles/r01h_hidden_sq_counters.txt", h_avg,
-                                                                     rows_per_launch),
+                                          "issue_bound": issue_bound("profiles/r02c_hidden_sq_counters.txt", h_avg,
+                                                                     rows_per_launch, 2.6),
                                           "matrix_pipe": {"algorithmic_tflops": hflops / (h_avg * 1e-3) / 1e12,
                                                           "executed_tflops": 3.0 * hflops / (h_avg * 1e-3) / 1e12,
                                                           "peak_f16_dense_tflops": MFMA_F16_PEAK_TFLOPS}}
