@@ -129,12 +129,14 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
       const int wdim = 4 * (active ? wave : 0) + (s16 >> 2), wprm = slot_param(4 * t + (s16 & 3));
       const bool wreal = wprm < kPP - 1 && wdim < a.dt;
       const int row = wreal ? wdim * a.wrows + wprm : 0;
+      const float wmask = wreal ? 1.f : 0.f;     // (a multiplication, not a guarded load: the loads stay two
+                                                 //  unconditional 16-byte requests per fragment, all in flight together)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const float4* src = reinterpret_cast<const float4*>(a.wpad + (int64_t)row * kH + 32 * ks + 8 * g);
-        const float4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const float4 v0 = wreal ? src[0] : z4, v1 = wreal ? src[1] : z4;
-        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const float4 v0 = src[0], v1 = src[1];
+        const float v[8] = {v0.x * wmask, v0.y * wmask, v0.z * wmask, v0.w * wmask,
+                            v1.x * wmask, v1.y * wmask, v1.z * wmask, v1.w * wmask};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           wv[t][ks][j] = v[j];
@@ -169,9 +171,11 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     const int bdim = 4 * (active ? wave : 0) + g;
     const float* bsrc = a.bias + bdim * a.wrows;
     const float m = t < 4 ? wh_mul : 1.f;   // params 0..15 are widths and heights
-    auto bias_of = [&](int slot) {
+    const bool bdim_ok = bdim < a.dt;
+    auto bias_of = [&](int slot) {      // unconditional load from a valid slot, masked by a multiplication
       const int prm = slot_param(slot);
-      return (prm < kPP - 1 && bdim < a.dt) ? bsrc[prm] * m : 0.f;
+      const bool real = prm < kPP - 1 && bdim_ok;
+      return (real ? bsrc[prm] : a.bias[0]) * (real ? m : 0.f);
     };
     bw[t] = f32x4{bias_of(4 * t), bias_of(4 * t + 1), bias_of(4 * t + 2), bias_of(4 * t + 3)};
   }

@@ -39,6 +39,11 @@ pro, entry = yy[:, 2], yy[:, 3]
 print("prologue median %.1f us max %.1f us; entry-time spread over workgroups %.1f us; loop end spread %.1f us"
       % (pro.median() / 100, pro.max() / 100, (entry.max() - entry.min()) / 100,
          ((entry + pro + yy[:, 1]).max() - (entry + pro + yy[:, 1]).min()) / 100))
+fin = entry + pro + yy[:, 1]
+print("workgroup finish times (10 ns ticks after the first entry): mean %.0f  median %.0f  max %.0f -> the last workgroup "
+      "ends %.1f us after the average one (%.1f %% of the kernel)"
+      % (fin.mean() - entry.min(), fin.median() - entry.min(), fin.max() - entry.min(),
+         (fin.max() - fin.mean()) / 100, 100 * (fin.max() - fin.mean()) / (fin.max() - entry.min())))
 cyc, rt = yy[:, 0], yy[:, 1]
 ghz = (cyc / rt * 0.1)
 tiles = n // 64 / cus
