@@ -77,6 +77,19 @@ __device__ __forceinline__ float softplus_lean_sel(float x, float beta) {
   return xb > 20.f ? x : v;
 }
 
+// The same on the bare hardware exp2 / log2 (no hi / lo compensation of the log2(e) / ln(2) products): the relative error
+// of the result grows by <= 4e-8 |x beta| (<= 2e-7 where the softplus is not yet linear), which measured as no change of
+// the RQ kernels' error against float64 (tools/probe/fused_accuracy.py); log1p(e) = log(u) + (e - (u - 1)) / u with
+// u = fl(1 + e) keeps tiny e exact.  11 VALU + 3 transcendental instructions instead of 20 + 3.
+__device__ __forceinline__ float softplus_plain(float x, float beta, float inv_beta) {
+  const float xb = x * beta;
+  const float ex = __builtin_amdgcn_exp2f(fminf(xb, 20.f) * 1.4426950408889634f);
+  const float up = 1.f + ex;
+  const float rr = ex - (up - 1.f);
+  const float l1p = __builtin_fmaf(__builtin_amdgcn_logf(up), 0.6931471805599453f, rr * __builtin_amdgcn_rcpf(up));
+  return xb > 20.f ? x : l1p * inv_beta;
+}
+
 // F.softplus(x, beta, threshold=20): x*beta > 20 ? x : log1p(exp(x*beta)) / beta
 __device__ __forceinline__ float softplus_b(float x, float beta) {
   const float xb = x * beta;

@@ -237,8 +237,8 @@ struct RQOp {
     const float r0 = ud[idx > 0 ? idx - 1 : 0], r1 = ud[idx < KS - 1 ? idx : KS - 2];
     const float u0 = idx == 0 ? q.tail_const : r0;
     const float u1 = idx == KS - 1 ? q.tail_const : r1;
-    const float d0 = q.min_d + softplus_lean_sel(u0, q.beta);
-    const float d1 = q.min_d + softplus_lean_sel(u1, q.beta);
+    const float d0 = q.min_d + softplus_plain(u0, q.beta, inv_beta);
+    const float d1 = q.min_d + softplus_plain(u1, q.beta, inv_beta);
     const float delta = div_lean(hk, wk);
     const float dsum = d0 + d1 - 2.f * delta;
     float theta;
@@ -257,7 +257,7 @@ struct RQOp {
     const float den = delta + dsum * t1mt;
     const float omt = 1.f - theta;
     const float dnum = (delta * delta) * (d1 * (theta * theta) + 2.f * delta * t1mt + d0 * (omt * omt));
-    const float l = log_lean(dnum) - 2.f * log_lean(den);
+    const float l = __builtin_fmaf(-2.f, __builtin_amdgcn_logf(den), __builtin_amdgcn_logf(dnum)) * 0.6931471805599453f;
     float ys;
     if constexpr (!kInverse) {
       const float num = hk * (delta * (theta * theta) + d0 * t1mt);
@@ -332,8 +332,8 @@ struct RQOp {
       u0 = ud[idx];
       u1 = ud[idx + 1];
     }
-    const float d0 = q.min_d + softplus_lean(u0, q.beta);
-    const float d1 = q.min_d + softplus_lean(u1, q.beta);
+    const float d0 = q.min_d + softplus_plain(u0, q.beta, inv_beta);
+    const float d1 = q.min_d + softplus_plain(u1, q.beta, inv_beta);
     const float delta = div_lean(hk, wk);
     const float dsum = d0 + d1 - 2.f * delta;
 
@@ -354,7 +354,7 @@ struct RQOp {
     const float den = delta + dsum * t1mt;
     const float omt = 1.f - theta;
     const float dnum = (delta * delta) * (d1 * (theta * theta) + 2.f * delta * t1mt + d0 * (omt * omt));
-    const float l = log_lean(dnum) - 2.f * log_lean(den);
+    const float l = __builtin_fmaf(-2.f, __builtin_amdgcn_logf(den), __builtin_amdgcn_logf(dnum)) * 0.6931471805599453f;
     if (!q.inverse) {
       const float num = hk * (delta * (theta * theta) + d0 * t1mt);
       y = yk + div_lean(num, den);
