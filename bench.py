@@ -122,22 +122,29 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(flow_cpu, sample, chunk):
-    """Time the CPU oracle (torch-CPU restatement of the reference's op sequence) on host cores."""
+def cpu_baseline(flow_cpu, chunk, repeats=3, budget_s=30.0):
+    """Time the CPU oracle (torch-CPU restatement of the reference's op sequence) on host cores, as BASELINE.md section 3
+    plans it: chunks of 2^16 rows, one warm-up, 3 timed repeats, median (throughput falls with the chunk size on the CPU:
+    mask-gather temporaries).  Bounded: stops repeating once `budget_s` seconds of timed work are spent."""
     from oracle import torch_oracle as O
 
     cores = host_cores()
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(99)
-    x = torch.randn(sample, FEATURES, generator=gen)
+    x = torch.randn(repeats * chunk, FEATURES, generator=gen)
+    times = []
     with torch.no_grad():
-        O.flow_log_prob(flow_cpu, x[: min(chunk, 1024)].clone())  # warm-up
-        t0 = time.perf_counter()
-        for i in range(0, sample, chunk):
-            O.flow_log_prob(flow_cpu, x[i:i + chunk].clone())
-        dt = time.perf_counter() - t0
-    return {"value": sample / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "%d samples in chunks of %d through the 32-layer flow, %.1f s" % (sample, chunk, dt)}
+        O.flow_log_prob(flow_cpu, x[:2048].clone())  # warm-up
+        for r in range(repeats):
+            t0 = time.perf_counter()
+            O.flow_log_prob(flow_cpu, x[r * chunk:(r + 1) * chunk].clone())
+            times.append(time.perf_counter() - t0)
+            if sum(times) > budget_s:
+                break
+    med = sorted(times)[len(times) // 2]
+    return {"value": chunk / med, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "%d chunk(s) of %d samples through the 32-layer flow, median of %s s"
+                      % (len(times), chunk, "/".join("%.1f" % t for t in times))}
 
 
 def parity(flow, flow_cpu, device, rows=2048):
@@ -211,7 +218,7 @@ def main():
     ap.add_argument("--chunk-log2", type=int, default=0, help="log2 rows per pass through the stack (0 = whole shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary `configs` block (cfg 1, 2, 5, K=10)")
-    ap.add_argument("--cpu-sample-log2", type=int, default=17)
+    ap.add_argument("--cpu-sample-log2", type=int, default=16, help="rows per CPU-baseline chunk (BASELINE.md: 2^16)")
     ap.add_argument("--loglik-allreduce", default="abi", choices=["abi", "torch"],
                     help="abi: fc_allreduce_loglik (RCCL through the C ABI); torch: torch.distributed.all_reduce")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -455,7 +462,7 @@ def main():
             del flow_tl
             log("parity (trained-like weights) done: %s" % out["parity_trained_like"])
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(flow_cpu, 1 << args.cpu_sample_log2, 1 << 14)
+                out["cpu_baseline"] = cpu_baseline(flow_cpu, 1 << args.cpu_sample_log2)
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             if not args.no_configs:
                 # the other BASELINE.json configurations + the reference's default layer shape, same instrumentation
