@@ -60,10 +60,10 @@ def test_fused_linear_backward_operator_vs_float64_autograd(k, tails, d, d_t, n,
     assert torch.equal(gx[:, ident].cpu(), gy[:, ident])
 
 
-def _layer(d, hidden, k, tails, seed, blocks=2):
+def _layer(d, hidden, k, tails, seed, blocks=2, mask="alternating"):
     torch.manual_seed(seed)
     t = T.PiecewiseRationalQuadraticCouplingTransform(
-        utils.create_alternating_binary_mask(d, even=True),
+        utils.create_alternating_binary_mask(d, even=True) if mask == "alternating" else utils.create_mid_split_binary_mask(d),
         lambda i, o: nets.ResidualNet(i, o, hidden_features=hidden, num_blocks=blocks),
         num_bins=k, tails=tails, tail_bound=3.0)
     with torch.no_grad():
@@ -75,14 +75,16 @@ def _layer(d, hidden, k, tails, seed, blocks=2):
     return t
 
 
-@pytest.mark.parametrize("d,hidden,k,tails,n", [(64, 64, 8, "linear", 256), (64, 64, 10, "linear", 200),
-                                                (16, 32, 10, None, 77), (128, 64, 8, "linear", 96),
-                                                (10, 20, 5, "linear", 33)])
-def test_coupling_layer_trains_through_fused_kernels(d, hidden, k, tails, n, device):
+@pytest.mark.parametrize("d,hidden,k,tails,n,mask", [(64, 64, 8, "linear", 256, "alternating"), (64, 64, 10, "linear", 200, "alternating"),
+                                                     (16, 32, 10, None, 77, "alternating"), (128, 64, 8, "linear", 96, "alternating"),
+                                                     (10, 20, 5, "linear", 33, "alternating"), (64, 64, 8, "linear", 160, "mid_split")])
+def test_coupling_layer_trains_through_fused_kernels(d, hidden, k, tails, n, mask, device):
     """Parameter and input gradients of one RQ coupling layer on the fused training path (forward: fc_resnet_hidden +
     fc_rq_spline_fused_general; backward: fc_rq_fused_linear_backward twice per 32 transformed dims) against float64
-    autograd on the oracle.  Batches that are not whole 32-row tiles, D = 128 (two groups of 32 dims), narrow nets."""
-    t_cpu = _layer(d, hidden, k, tails, seed=d + k)
+    autograd on the oracle.  Batches that are not whole 32-row tiles, D = 128 (two groups of 32 dims), narrow nets; a
+    contiguous-half mask (the hidden stack's input gradient then takes the scalar path of fc_resnet_hidden_backward_accum,
+    the alternating masks the 16-byte one)."""
+    t_cpu = _layer(d, hidden, k, tails, seed=d + k, mask=mask)
     t_gpu = copy.deepcopy(t_cpu).to(device).train()
     t_cpu = t_cpu.double().train()
     gen = torch.Generator().manual_seed(3)
