@@ -167,7 +167,7 @@ __device__ __forceinline__ void rq_backward_element(const RQParams& q, float inv
 // the matrix-core kernels' tight register budget and VALU-bound loops:
 //   * both cumulative axes walked together in packed f32 pairs (.x widths, .y heights), softmax through v_exp with
 //     the log2(e) factor folded in (as the forward's walk_both);
-//   * plain f32 running sums for the knots (the forward accumulates in double like ATen's CPU cumsum; the gradient does
+//   * plain f32 running sums for the knots (the static-K forward forms its knots from two-sided float partial sums, the run-time-K walk accumulates in double like ATen's CPU cumsum; the gradient does
 //     not need the knots bit for bit -- an input within 1e-7 of a knot may differentiate the neighbouring bin, whose
 //     value and slope agree there);
 //   * softplus and its slope (the sigmoid) of a knot derivative from ONE exponential;
