@@ -1,5 +1,6 @@
-"""Permutation transforms (API of flowcon/transforms/permutations.py:10-64); the gather runs
-in the ``fc_permute`` HIP kernel and is bit-exact."""
+"""Feature permutations (same classes, constructor arguments and ``_permutation`` buffer as
+flowcon/transforms/permutations.py:10-64).  The gather itself is the ``fc_permute`` HIP kernel: bit-exact, zero
+log-determinant."""
 import torch
 
 from flowconductor_amd import ops
@@ -7,51 +8,55 @@ from flowconductor_amd.transforms.base import Transform
 from flowconductor_amd.utils import typechecks as check
 
 
+def _need_feature_count(features):
+    if not check.is_positive_int(features):
+        raise ValueError("Number of features must be a positive integer.")
+    return features
+
+
 class Permutation(Transform):
-    """Permutes inputs on a given dimension using a given permutation."""
+    """Reorders ``inputs`` along ``dim`` by a fixed index vector; the inverse applies the argsort of that vector."""
 
     def __init__(self, permutation, dim=1):
-        if permutation.ndimension() != 1:
+        index = torch.as_tensor(permutation)
+        if index.dim() != 1:
             raise ValueError("Permutation must be a 1D tensor.")
         if not check.is_positive_int(dim):
             raise ValueError("dim must be a positive integer.")
         super().__init__()
         self._dim = dim
-        self.register_buffer("_permutation", permutation)
+        self.register_buffer("_permutation", index)
 
     @property
     def _inverse_permutation(self):
+        # recomputed per call like the reference (:23-25): the buffer may have been replaced by load_state_dict
         return torch.argsort(self._permutation)
 
-    @staticmethod
-    def _permute(inputs, permutation, dim):
-        if dim >= inputs.ndimension():
+    def _gather(self, inputs, index):
+        dim = self._dim
+        if inputs.dim() <= dim:
             raise ValueError("No dimension {} in inputs.".format(dim))
-        if inputs.shape[dim] != len(permutation):
-            raise ValueError("Dimension {} in inputs must be of size {}.".format(dim, len(permutation)))
-        outputs = ops.permute(inputs, permutation, dim)
-        return outputs, inputs.new_zeros(inputs.shape[0])
+        if inputs.shape[dim] != index.numel():
+            raise ValueError("Dimension {} in inputs must be of size {}.".format(dim, index.numel()))
+        return ops.permute(inputs, index, dim), inputs.new_zeros(inputs.shape[0])
 
     def forward(self, inputs, context=None):
-        return self._permute(inputs, self._permutation, self._dim)
+        return self._gather(inputs, self._permutation)
 
     def inverse(self, inputs, context=None):
-        return self._permute(inputs, self._inverse_permutation, self._dim)
+        return self._gather(inputs, self._inverse_permutation)
 
 
 class RandomPermutation(Permutation):
-    """Permutes using a random, but fixed, permutation."""
+    """A permutation drawn once at construction (from torch's global generator, as the reference does)."""
 
     def __init__(self, features, dim=1):
-        if not check.is_positive_int(features):
-            raise ValueError("Number of features must be a positive integer.")
-        super().__init__(torch.randperm(features), dim)
+        super().__init__(torch.randperm(_need_feature_count(features)), dim)
 
 
 class ReversePermutation(Permutation):
-    """Reverses the elements of the input."""
+    """Feature order reversed."""
 
     def __init__(self, features, dim=1):
-        if not check.is_positive_int(features):
-            raise ValueError("Number of features must be a positive integer.")
-        super().__init__(torch.arange(features - 1, -1, -1), dim)
+        count = _need_feature_count(features)
+        super().__init__(torch.arange(count - 1, -1, -1), dim)
