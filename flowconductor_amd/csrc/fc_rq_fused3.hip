@@ -170,7 +170,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   for (int t = 0; t < kCt3; ++t) {
     const int bdim = 4 * (active ? wave : 0) + g;
     const float* bsrc = a.bias + bdim * a.wrows;
-    const float m = t < 4 ? wh_mul : 1.f;   // params 0..15 are widths and heights
+    const float m = t < 4 ? wh_mul : op.q.beta;   // params 0..15 are widths and heights; the derivative logits only ever
+                                                  // enter softplus(beta u): beta folded in like the factors above
     const bool bdim_ok = bdim < a.dt;
     auto bias_of = [&](int slot) {      // unconditional load from a valid slot, masked by a multiplication
       const int prm = slot_param(slot);
@@ -202,8 +203,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   float* dtab = tabs + wave * (kKnotFloats + kDerFloats) + kKnotFloats + lane;
   *reinterpret_cast<f2*>(ktab) = f2{op.q.left, op.q.bottom};
   *reinterpret_cast<f2*>(ktab + kK * 128) = f2{op.q.right, op.q.top};
-  dtab[0] = op.q.tail_const;
-  dtab[kK * 64] = op.q.tail_const;
+  dtab[0] = op.q.tail_const * op.q.beta;
+  dtab[kK * 64] = op.q.tail_const * op.q.beta;
 
   uint32_t err = 0;
   const int xvec = R * D / 4;     // float4 per x tile: thread tid owns slots tid + 512 k, k < XV
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     const float x = *xr;
     const float c_d = hscale[xb * R + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
     const float c_wh = c_d * wh_mul;        // (c_d is a power of two: the product is exact)
+    const float c_ud = c_d * op.q.beta;
     // h^T fragments are read one group of 6 MFMAs ahead of their use
     f16x8 bcur, bnext = hfrag(hb, pblk, term_h(0), 0);
     auto hook = [&](auto N) {
@@ -318,11 +320,16 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #define FC_HOOK(n) hook(std::integral_constant<int, n>{});
 #define FC_WH_SLOT(i) ((i) < 8 ? 2 * (i) : 2 * ((i) - 8) + 1)
 #define FC_WH(i) __builtin_fmaf(pa[FC_WH_SLOT(i) >> 2][FC_WH_SLOT(i) & 3], c_wh, bw[FC_WH_SLOT(i) >> 2][FC_WH_SLOT(i) & 3])
-#define FC_UD(j) __builtin_fmaf(pa[((j) + 16) >> 2][((j) + 16) & 3], c_d, bw[((j) + 16) >> 2][((j) + 16) & 3])
+#define FC_UD(j) __builtin_fmaf(pa[((j) + 16) >> 2][((j) + 16) & 3], c_ud, bw[((j) + 16) >> 2][((j) + 16) & 3])
 #define FC_KNOT_ST(slot, v) *reinterpret_cast<f2*>(ktab + (slot) * 128) = (v)
 #define FC_KNOT_LD(i, off) *reinterpret_cast<const f2*>(ktab + ((i) + (off)) * 128)
 #define FC_DER_ST(slot, v) dtab[(slot) * 64] = (v)
 #define FC_DER_LD(i, off) dtab[((i) + (off)) * 64]
+#define FC_COUNT_GE(count, a, b)                                                              \
+  do {                                                                                        \
+    const float fc_b_ = (b);                                                                  \
+    asm("v_cmp_ge_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(count) : "v"(a), "v"(fc_b_) : "vcc"); \
+  } while (0)
 #if FC_ABL & 1
     FC_ALL36(FC_HOOK)
     y = x + (FC_WH(0) + FC_WH(5) + FC_WH(10) + FC_WH(15) + FC_UD(0) + FC_UD(5)) * 0.f + q.left * 0.f;
@@ -330,6 +337,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #else
 #include "fc_rq_fused3_eval.inc"
 #endif
+#undef FC_COUNT_GE
 #undef FC_DER_LD
 #undef FC_DER_ST
 #undef FC_KNOT_LD

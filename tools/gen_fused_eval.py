@@ -1,7 +1,7 @@
 """Generates flowconductor_amd/csrc/fc_rq_fused3_eval.inc: the straight-line RQ-spline evaluation of one
 element in the fused final-Linear + spline kernel (K = 8 bins, linear tails), with the element's 23 raw
 parameters read from the lane's own MFMA accumulators (macros FC_WH(i): width / height logit i < 16, already
-divided by sqrt(hidden_features) and multiplied by log2(e); FC_UD(j): derivative logit j < 7) and 36 MFMA hook points spread evenly
+divided by sqrt(hidden_features) and multiplied by log2(e); FC_UD(j): derivative logit j < 7, multiplied by the softplus beta) and 36 MFMA hook points spread evenly
 over its instruction stream.  hipcc's sched_group_barrier pipeline clusters about half of the MFMAs,
 so the interleave is explicit in the source: FC_HOOK(n) issues MFMA number n of the NEXT block and pins its
 position with a sched_barrier.
@@ -66,7 +66,9 @@ for i in range(K - 1):
         add("const FC_F2 next%d = __builtin_elementwise_fma(l%d, gk, kc%d);\nFC_KNOT_ST(%d, next%d);" % (i, i, i, i + 1, i), 2)
     else:
         add("const FC_F2 next%d = __builtin_elementwise_fma(r%d, -gk, kc%d);\nFC_KNOT_ST(%d, next%d);" % (i, i, i, i + 1, i), 2)
-    add("idx += (xc >= (kInv ? next%d.y : next%d.x)) ? 1 : 0;" % (i, i), 2)
+    # idx += (xc >= knot) as a VOPC compare into vcc and an add-with-carry of 0: two 4-byte instructions (the compiler's
+    # choice, a 64-bit compare into an SGPR pair + v_cndmask + v_addc per pair of knots, costs a third more issue time)
+    add("FC_COUNT_GE(idx, xc, kInv ? next%d.y : next%d.x);" % (i, i), 2)
 add("const FC_F2 sel_lo = FC_KNOT_LD(idx, 0), sel_hi = FC_KNOT_LD(idx, 1);\n"
     "const float u0 = FC_DER_LD(idx, 0), u1 = FC_DER_LD(idx, 1);", 3)
 add("const float xk = sel_lo.x, yk = sel_lo.y;\nconst float wk = sel_hi.x - sel_lo.x, hk = sel_hi.y - sel_lo.y;", 2)
@@ -80,14 +82,15 @@ add("float theta;\nif constexpr (!kInv) {\n  const float tq = (xc - xk) * rwk;\n
 # (<= 2e-7 over the range where the softplus is not yet linear), measured effect on the kernel's logabsdet error
 # against float64 in tools/probe/fused_accuracy.py.
 for n in (0, 1):
-    add("const float xb%d = u%d * q.beta;\nconst float xm%d = fminf(xb%d, 20.f);\n"
-        "const float ex%d = __builtin_amdgcn_exp2f(xm%d * 1.4426950408889634f);" % (n, n, n, n, n, n), 7)
+    # (FC_UD hands out the derivative logits already multiplied by the softplus beta -- folded into the unscaling fma)
+    add("const float xb%d = u%d;\nconst float xm%d = fminf(xb%d, 20.f);\n"
+        "const float ex%d = __builtin_amdgcn_exp2f(xm%d * 1.4426950408889634f);" % (n, n, n, n, n, n), 6)
     # log1p(e) = log(u) + (e - (u - 1)) / u with u = fl(1 + e): the second term restores what the rounding of
     # 1 + e lost (|.| <= 2^-24, so a plain v_rcp is accurate enough for it); no special case for tiny e
     add("const float up%d = 1.f + ex%d;\nconst float rr%d = ex%d - (up%d - 1.f);" % (n, n, n, n, n), 3)
     add("const float l1p%d = __builtin_fmaf(__builtin_amdgcn_logf(up%d), 0.6931471805599453f, rr%d * __builtin_amdgcn_rcpf(up%d));"
         % (n, n, n, n), 10)
-    add("const float d%d = q.min_d + (xb%d > 20.f ? u%d : l1p%d * inv_beta);" % (n, n, n, n), 3)
+    add("const float d%d = q.min_d + (xb%d > 20.f ? xb%d : l1p%d) * inv_beta;" % (n, n, n, n), 3)
 add("const float dsum = d0 + d1 - 2.f * delta;", 3)
 add("""if constexpr (kInv) {
   const float rr = xc - yk;
@@ -119,7 +122,7 @@ out = ["// GENERATED by tools/gen_fused_eval.py -- do not edit by hand.",
        "// Expects in scope: FC_WH(i) / FC_UD(j) (logits of the element), FC_KNOT_ST / FC_KNOT_LD / FC_DER_ST / FC_DER_LD",
        "// (lane-private LDS tables of K + 1 knots and K + 1 derivative logits), FC_F2, x, q, inv_beta, err, the knot",
        "// constants sc1, kc0 .. kc%d (FC_F2: x = widths axis, y = heights axis), kInv (constexpr bool), outputs y / lad," % (K - 2),
-       "// and FC_HOOK(n).  FC_WH(i) is expected in log2 units (logit * log2(e))."]
+       "// FC_COUNT_GE(count, a, b): count += (a >= b), and FC_HOOK(n).  FC_WH(i) is expected in log2 units (logit * log2(e))."]
 # hook placement: hook k sits where the accumulated weight passes (k + 1 - SHIFT) / HOOKS of the total
 # (FC_GEN_SHIFT: probe knob for tools/probe/search_hooks.sh; the committed file uses 0)
 SHIFT = float(os.environ.get("FC_GEN_SHIFT", "0"))
