@@ -68,21 +68,28 @@ struct HiddenArgs {
   const f16x8* image;     // [layer][ks][t][piece][lane] fragments = the layout of `wfrag` below
   const float* image_un;  // [layers] 2^-S of every layer
   const float* image_bias; // [layers][64] biases in accumulator order
+  // fc_affine_coupling_resnet (kTail): the final Linear and the affine bijector run here too -- y [N, D] is the layer's
+  // output and h is not written.  The image then carries one more 64 x 64 layer: rows 0..31 = the final Linear's shift
+  // rows of dims 0..31, rows 32..63 = its scale rows (zero rows beyond d_t).
+  float* y;                 // [N, D]
+  const int32_t* tr_cols;   // [d_t] transformed columns
+  float* lad;               // [N]
+  int d_t, affine_act, inverse, accumulate;
 };
 
 // feature held by accumulator tile t, register r of a lane in group g
 __host__ __device__ constexpr int hid_feat(int t, int g, int r) { return 32 * (t >> 1) + 8 * g + 4 * (t & 1) + r; }
 
 // LDS: [layer][k-step][tile][piece][lane] f16x8 fragments, then bias [layer][g][16], unscale [layer], ids
-template <int NB, int K0S, int kCtx>
+template <int NB, int K0S, int kCtx, int kTail = 0>
 struct HiddenLds {
-  static constexpr int kMain = 1 + 2 * NB;                // initial layer + two per block
+  static constexpr int kMain = 1 + 2 * NB + kTail;        // initial layer + two per block (+ the final Linear)
   static constexpr int kCtxLayers = kCtx == 1 ? NB : kCtx == 2 ? NB + 1 : 0;   // context products: per block (+ initial)
   static constexpr int kLayers = kMain + kCtxLayers;
   static constexpr int kFrag0 = K0S * 4 * 2;              // fragments of the initial layer
   static constexpr int kFragL = 2 * 4 * 2;                // fragments of a 64 x 64 layer
   static constexpr int kFragG = 1 * 4 * 2;                // fragments of a 64 x C gate layer (C <= 32)
-  static constexpr int kFragsMain = kFrag0 + 2 * NB * kFragL;
+  static constexpr int kFragsMain = kFrag0 + (2 * NB + kTail) * kFragL;
   static constexpr int kFrags = kFragsMain + kCtxLayers * kFragG;
   static constexpr size_t kBytes = (size_t)kFrags * 64 * 16 + kLayers * 64 * 4 + 16 * 4 + 32 * K0S * 4 + 16 * 8 * 4;
   static_assert(kLayers <= 16, "wun holds 16 entries");
@@ -93,9 +100,12 @@ struct HiddenLds {
 // BPW: 16-sample blocks a wave pushes through the layers together.  Every layer's weight fragments (16 KB per wave) come
 // from LDS once per group of BPW blocks; at one block per wave the 16 waves of a CU ask the LDS pipe for as many cycles
 // as their matrix and vector instructions take to issue, and the reads sit right before the MFMAs that need them.
-template <int NB, int K0S, int kCtx, int kAct, int BPW>
-__global__ __launch_bounds__(512, (kCtx || BPW > 1) ? 2 : 4) void resnet_hidden_kernel(HiddenArgs a) {
-  using L = HiddenLds<NB, K0S, kCtx>;
+// kTail: the affine coupling layer's final Linear + bijector as a tail of the stack (one kernel per coupling layer; the
+// image is 16 KB larger and every wave stages its 16 rows in LDS: one workgroup per CU).
+template <int NB, int K0S, int kCtx, int kAct, int BPW, int kTail = 0>
+__global__ __launch_bounds__(512, (kCtx || BPW > 1 || kTail) ? 2 : 4) void resnet_hidden_kernel(HiddenArgs a) {
+  static_assert(!kTail || (kCtx == 0 && BPW == 1), "the coupling tail: no context, one block per wave");
+  using L = HiddenLds<NB, K0S, kCtx, kTail>;
   constexpr bool kPrefetchX = FC_HIDDEN_PREFETCH_X && (K0S == 1 || kCtx != 0 || BPW > 1);   // (16 more live registers spill in the 64-input kernels without a context at one block per wave: 128-register budget)
   extern __shared__ __attribute__((aligned(16))) unsigned char hsmem[];
   f16x8* wfrag = reinterpret_cast<f16x8*>(hsmem);
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(512, (kCtx || BPW > 1) ? 2 : 4) void resnet_hidden_
     if (tid < L::kLayers) wun[tid] = a.image_un[tid];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-  } else {
+  } else if constexpr (!kTail) {      // (the coupling-tail kernels only exist with a ready-made image)
   // Two rounds of global loads for ALL layers together (maxima, then fragments) with one barrier pair between them:
   // layer by layer the dependent load latencies and barriers of 5-13 layers cost ~15 us per launch.
   auto layer_src = [&](int l, const float*& w, const float*& b, int& kin, int& nks, int& base) {
@@ -344,6 +354,137 @@ __global__ __launch_bounds__(512, (kCtx || BPW > 1) ? 2 : 4) void resnet_hidden_
         xv[t][r] = v;
       }
   };
+  if constexpr (kTail) {
+    // ---- one affine coupling layer per launch -------------------------------------------------------------------------
+    // The wave's 16 rows (one contiguous 64 D-byte chunk of x) pass through a wave-private LDS tile: coalesced 16-byte
+    // loads in, the conditioner's inputs and the transformed columns picked from the tile, the results written back into
+    // it, coalesced 16-byte stores out -- the identity columns ride along.  (Per-lane 4-byte gathers / scatters at a
+    // column stride cost more address-path time than the whole stack.)  Row stride D | 1: conflict-free column reads.
+    const int TS = D | 1, wrap = TS - D;
+    float* tile = reinterpret_cast<float*>(hsmem + ((L::kBytes + 15) & ~size_t(15))) + (size_t)wave * 16 * TS;
+    const int chunk4 = 4 * D;                        // float4 per 16-row chunk; this lane owns pieces lane + 64 k
+    constexpr int XV = 8;                            // D <= 128
+    int toff[XV], tcol[XV];
+#pragma unroll
+    for (int k = 0; k < XV; ++k) {
+      const int e = 4 * (lane + 64 * k), r = e / D;
+      tcol[k] = e - r * D;
+      toff[k] = r * TS + tcol[k];
+    }
+    auto fetch_rows = [&](int64_t blk, float4 (&raw)[XV]) __attribute__((always_inline)) {
+      const float4* src = reinterpret_cast<const float4*>(a.x + blk * 16 * D);
+#pragma unroll
+      for (int k = 0; k < XV; ++k)
+        if (lane + 64 * k < chunk4) raw[k] = src[lane + 64 * k];
+    };
+    const int64_t nw = (int64_t)gridDim.x * (kHidThreads / 64);
+    const int64_t first = (int64_t)blockIdx.x * (kHidThreads / 64) + wave;
+    float4 raw[XV];
+    if (first < a.blocks16) fetch_rows(first, raw);
+    for (int64_t blk = first; blk < a.blocks16; blk += nw) {
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < XV; ++k)
+        if (lane + 64 * k < chunk4) {
+          const float v[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tile[toff[k] + j + (tcol[k] + j >= D ? wrap : 0)] = v[j];
+        }
+      __builtin_amdgcn_wave_barrier();
+      if (blk + nw < a.blocks16) fetch_rows(blk + nw, raw);        // the next block's rows, one iteration ahead
+      const float* trow = tile + s16 * TS;
+      f32x4 xin[1][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ks = t >> 1, j = 4 * (t & 1) + r;
+          float v = 0.f;
+          if (ks < K0S) {
+            const int c = mycol[ks < K0S ? ks : 0][j];
+            v = c >= 0 ? trow[c] : 0.f;
+          }
+          xin[0][t][r] = v;
+        }
+      float xt[8];
+      int tc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int dim = 8 * g + e;
+        tc[e] = a.tr_cols[dim < a.d_t ? dim : 0];
+        xt[e] = trow[tc[e]];
+      }
+      f16x8 bh[1][2], bl[1][2];
+      f32x4 acc[1][4], h[1][4], tmid[1][4];
+      float un = make_operand(xin[0], bh[0], bl[0]);
+      layer(0, K0S, bh, bl, acc);
+      finish(0, un, acc[0], h[0]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        f32x4 act[4];
+        activate16(h[0], act);
+        un = make_operand(act, bh[0], bl[0]);
+        layer(L::kFrag0 + (2 * nb) * L::kFragL, 2, bh, bl, acc);
+        finish(1 + 2 * nb, un, acc[0], tmid[0]);
+        activate16(tmid[0], act);
+        un = make_operand(act, bh[0], bl[0]);
+        layer(L::kFrag0 + (2 * nb + 1) * L::kFragL, 2, bh, bl, acc);
+        finish(2 + 2 * nb, un, acc[0], tmid[0]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[0][t][r] += tmid[0][t][r];
+      }
+      // final Linear: one more 64 x 64 product on the residual stream (no activation in front: resnet.py:99)
+      un = make_operand(h[0], bh[0], bl[0]);
+      layer(L::kFrag0 + 2 * NB * L::kFragL, 2, bh, bl, acc);
+      f32x4 prm[4];
+      finish(1 + 2 * NB, un, acc[0], prm);
+      // lane (s, g): dims 8g + e, e = 4t + r (t < 2): shift = prm[t][r], raw scale = prm[2 + t][r]
+      float ladsum = 0.f;
+      float* wrow = tile + s16 * TS;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = 4 * t + r;
+          if (8 * g + e < a.d_t) {
+            const float xv = xt[e], shift = prm[t][r], u = prm[2 + t][r];
+            float sc = 1.f, ls = 0.f;
+            // (the lean primitives of fc_math.h: hardware exp2 / log2 / rcp + one correction step, <= 1-2 ulp)
+            if (a.affine_act == FC_AFFINE_SIGMOID_PLUS2) {
+              const float v = u + 2.f;
+              const float ex = exp_lean(-fabsf(v));
+              const float rcp = div_lean(1.f, 1.f + ex);
+              sc = (v >= 0.f ? rcp : ex * rcp) + 1e-3f;
+              ls = log_lean(sc);
+            } else if (a.affine_act == FC_AFFINE_SOFTPLUS_CLAMP3) {
+              const float v = softplus_lean(u, 1.f) + 1e-3f;
+              sc = v < 0.f ? 0.f : (v > 3.f ? 3.f : v);      // torch.clamp: a NaN stays a NaN
+              ls = log_lean(sc);
+            }
+            wrow[tc[e]] = a.inverse ? div_lean(xv - shift, sc) : xv * sc + shift;
+            ladsum += a.inverse ? -ls : ls;
+          }
+        }
+      const float l = rows4_allsum(ladsum, lane);
+      const int64_t row = blk * 16 + s16;
+      if (g == 0) a.lad[row] = a.accumulate ? a.lad[row] + l : l;
+      __builtin_amdgcn_wave_barrier();
+      float4* dst = reinterpret_cast<float4*>(a.y + blk * 16 * D);
+#pragma unroll
+      for (int k = 0; k < XV; ++k)
+        if (lane + 64 * k < chunk4) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = tile[toff[k] + j + (tcol[k] + j >= D ? wrap : 0)];
+          dst[lane + 64 * k] = float4{v[0], v[1], v[2], v[3]};
+        }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
+
   // A wave walks groups of BPW consecutive 16-sample blocks; a group that reaches past the end repeats the last
   // block (computed twice, stored once).
   const int64_t groups = (a.blocks16 + BPW - 1) / BPW;
@@ -503,16 +644,39 @@ __global__ __launch_bounds__(512, (kCtx || BPW > 1) ? 2 : 4) void resnet_hidden_
 #undef FC_EACH_BLOCK
 }
 
-template <int NB, int K0S, int kCtx, int kAct, int BPW>
+template <int NB, int K0S, int kCtx, int kAct, int BPW, int kTail = 0>
 hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
-  using L = HiddenLds<NB, K0S, kCtx>;
+  using L = HiddenLds<NB, K0S, kCtx, kTail>;
   static PerDeviceOnce attr;
   const hipError_t ea = ensure_max_dynamic_lds(
-      attr, reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx, kAct, BPW>), 160 * 1024);
+      attr, reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx, kAct, BPW, kTail>), 160 * 1024);
   if (ea != hipSuccess) return ea;
-  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S, kCtx, kAct, BPW>), dim3((unsigned)grid), dim3(kHidThreads), L::kBytes,
+  // (tail kernels: + a [16][D | 1] float tile per wave)
+  const size_t lds = kTail ? ((L::kBytes + 15) & ~size_t(15)) + (size_t)(kHidThreads / 64) * 16 * (a.D | 1) * 4 : L::kBytes;
+  if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
+  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S, kCtx, kAct, BPW, kTail>), dim3((unsigned)grid), dim3(kHidThreads), lds,
                      s, a);
   return hipGetLastError();
+}
+
+// the affine coupling layer in one kernel: ReLU conditioner, <= 3 blocks (the image of 4 blocks + the final layer
+// would not fit in LDS), one workgroup per CU
+inline hipError_t dispatch_coupling_tail(const HiddenArgs& a, int num_blocks, hipStream_t s) {
+  int64_t grid = device_cu_count();
+  const int64_t need = (a.blocks16 + 7) / 8;
+  if (grid > need) grid = need;
+  const bool wide = a.k0 > 32;
+  switch (num_blocks * 2 + (wide ? 1 : 0)) {
+    case 0: return launch_hidden<0, 1, 0, 0, 1, 1>(a, grid, s);
+    case 1: return launch_hidden<0, 2, 0, 0, 1, 1>(a, grid, s);
+    case 2: return launch_hidden<1, 1, 0, 0, 1, 1>(a, grid, s);
+    case 3: return launch_hidden<1, 2, 0, 0, 1, 1>(a, grid, s);
+    case 4: return launch_hidden<2, 1, 0, 0, 1, 1>(a, grid, s);
+    case 5: return launch_hidden<2, 2, 0, 0, 1, 1>(a, grid, s);
+    case 6: return launch_hidden<3, 1, 0, 0, 1, 1>(a, grid, s);
+    case 7: return launch_hidden<3, 2, 0, 0, 1, 1>(a, grid, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 template <int kCtx, int kAct>
@@ -577,7 +741,7 @@ extern "C" int fc_resnet_hidden(const float* x, float* h, const int32_t* id_cols
   if (!x || !h || !id_cols || !w0 || !b0 || (num_blocks > 0 && (!wb || !bb))) return hipErrorInvalidValue;
   if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)wb & 15u) != 0) return hipErrorInvalidValue;
   fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, nullptr, nullptr, nullptr, 0,
-                   activation, activation_param, nullptr, nullptr, nullptr};
+                   activation, activation_param, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   if (activation == FC_ACT_RELU) return fc::dispatch_hidden<0, 0>(a, num_blocks, static_cast<hipStream_t>(stream));
   return fc::dispatch_hidden<0, 1>(a, num_blocks, static_cast<hipStream_t>(stream));
 }
@@ -594,9 +758,30 @@ extern "C" int fc_resnet_hidden_packed(const float* x, float* h, const int32_t* 
   if (!x || !h || !id_cols || !w_frag || !w_unscale || !bias_acc) return hipErrorInvalidValue;
   if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)w_frag & 15u) != 0) return hipErrorInvalidValue;
   fc::HiddenArgs a{x, h, id_cols, nullptr, nullptr, nullptr, nullptr, n / 16, d, in_features, nullptr, nullptr, nullptr, 0,
-                   activation, activation_param, static_cast<const fc::f16x8*>(w_frag), w_unscale, bias_acc};
+                   activation, activation_param, static_cast<const fc::f16x8*>(w_frag), w_unscale, bias_acc,
+                   nullptr, nullptr, nullptr, 0, 0, 0, 0};
   if (activation == FC_ACT_RELU) return fc::dispatch_hidden<0, 0>(a, num_blocks, static_cast<hipStream_t>(stream));
   return fc::dispatch_hidden<0, 1>(a, num_blocks, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int fc_affine_coupling_resnet(const float* x, float* y, const int32_t* id_cols, const int32_t* tr_cols,
+                                         const void* w_frag, const float* w_unscale, const float* bias_acc,
+                                         float* logabsdet, int64_t n, int32_t d, int32_t in_features, int32_t d_t,
+                                         int32_t hidden, int32_t num_blocks, int32_t scale_activation, int32_t inverse,
+                                         int32_t accumulate, void* stream) {
+  if (n < 0 || d <= 0 || hidden != fc::kHid || num_blocks < 0 || num_blocks > 3) return hipErrorInvalidValue;
+  if (in_features <= 0 || in_features > 64 || d_t <= 0 || d_t > 32 || in_features + d_t > d || d > 128) return hipErrorInvalidValue;
+  if (scale_activation != FC_AFFINE_SIGMOID_PLUS2 && scale_activation != FC_AFFINE_SOFTPLUS_CLAMP3 &&
+      scale_activation != FC_AFFINE_ADDITIVE)
+    return hipErrorInvalidValue;
+  if (n % 16 != 0) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  if (!x || !y || x == y || !id_cols || !tr_cols || !w_frag || !w_unscale || !bias_acc || !logabsdet) return hipErrorInvalidValue;
+  if (((uintptr_t)w_frag & 15u) != 0) return hipErrorInvalidValue;
+  fc::HiddenArgs a{x, nullptr, id_cols, nullptr, nullptr, nullptr, nullptr, n / 16, d, in_features, nullptr, nullptr, nullptr, 0,
+                   FC_ACT_RELU, 0.f, static_cast<const fc::f16x8*>(w_frag), w_unscale, bias_acc,
+                   y, tr_cols, logabsdet, d_t, scale_activation, inverse ? 1 : 0, accumulate ? 1 : 0};
+  return fc::dispatch_coupling_tail(a, num_blocks, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int fc_resnet_hidden_context(const float* x, const float* context, float* h, const int32_t* id_cols,
@@ -619,7 +804,7 @@ extern "C" int fc_resnet_hidden_context(const float* x, const float* context, fl
   if (context_mode == FC_CONTEXT_ADDITIVE && (!wc || !bc)) return hipErrorInvalidValue;
   if (((uintptr_t)h & 15u) != 0 || ((uintptr_t)wb & 15u) != 0) return hipErrorInvalidValue;
   fc::HiddenArgs a{x, h, id_cols, w0, b0, wb, bb, n / 16, d, in_features, context, wc, bc, context_features,
-                   activation, activation_param, nullptr, nullptr, nullptr};
+                   activation, activation_param, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (context_mode == FC_CONTEXT_GLU)
     return activation == FC_ACT_RELU ? fc::dispatch_hidden<1, 0>(a, num_blocks, s) : fc::dispatch_hidden<1, 1>(a, num_blocks, s);

@@ -193,7 +193,16 @@ class ResidualNet(nn.Module):
 
     def _storage_key(self):
         """Where the parameters live (a device pack plan holds raw pointers to these storages)."""
-        return tuple((p.data_ptr(), p.device) for p in self.parameters())
+        plist = self.__dict__.get("_fc_param_list")
+        if plist is None:
+            plist = self.__dict__["_fc_param_list"] = tuple(self.parameters())
+        return tuple(p.data_ptr() for p in plist)
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float(): new storages (and possibly new Parameter objects)
+        out = super()._apply(fn, *args, **kwargs)
+        self.__dict__.pop("_fc_param_list", None)
+        return out
 
     def hidden_backward_packed(self):
         from flowconductor_amd import ops

@@ -174,8 +174,15 @@ def cache_key(*tensors, extra=()):
 
 def has_hooks(module):
     """True when ``module`` or a sub-module carries forward (pre-)hooks (old-style weight_norm refreshes ``weight``
-    in one): the fast paths read the weights directly and never go through ``__call__``, so they step aside."""
-    return any(m._forward_hooks or m._forward_pre_hooks for m in module.modules())
+    in one): the fast paths read the weights directly and never go through ``__call__``, so they step aside.
+    (The sub-module list is kept on the module and rebuilt when the cache epoch moves or a child is added / removed:
+    walking ``modules()`` on every call was the largest single item of the per-layer host time.)"""
+    memo = module.__dict__.get("_fc_module_list")
+    count = len(module._modules)
+    if memo is None or memo[0] != _cache_epoch or memo[1] != count:
+        memo = (_cache_epoch, count, tuple(module.modules()))
+        module.__dict__["_fc_module_list"] = memo
+    return any(m._forward_hooks or m._forward_pre_hooks for m in memo[2])
 
 
 LAD_STORE, LAD_ACCUMULATE, LAD_STORE_NEG, LAD_ACCUMULATE_NEG = 0, 1, 2, 3
@@ -516,8 +523,11 @@ class DevicePack:
         self._jobs_dev = None
         self._root = None         # the pack this one was merged into
         self._key = None
+        self.prepare = []         # callables run before every launch (staging copies the jobs read from)
 
-    def add(self, mode, weight, bias, frag, unscale, bias_out=None, p=0, pp=0, nks=0, nt=0, group=0):
+    def add(self, mode, weight, bias, frag, unscale, bias_out=None, p=0, pp=0, nks=0, nt=0, group=0, track=True):
+        """``track=False``: ``weight`` / ``bias`` are staging copies refreshed by a ``prepare`` callable -- the caller lists
+        the tensors they are made from in ``sources`` instead."""
         if not weight.is_contiguous() or weight.dtype != torch.float32:
             raise ValueError("DevicePack sources must be contiguous float32 tensors")
         job = _hip.PackJob()
@@ -528,7 +538,8 @@ class DevicePack:
         job.mode, job.p, job.pp, job.nks, job.nt, job.group = mode, p, pp, nks, nt, group
         self.jobs.append(job)
         self.keep += [weight, bias, frag, unscale, bias_out]
-        self.sources += [t for t in (weight, bias) if t is not None]
+        if track:
+            self.sources += [t for t in (weight, bias) if t is not None]
 
     def root(self):
         node = self
@@ -547,8 +558,9 @@ class DevicePack:
         mine.jobs += theirs.jobs
         mine.keep += theirs.keep
         mine.sources += theirs.sources
+        mine.prepare += theirs.prepare
         mine._jobs_dev = mine._key = None
-        theirs.jobs, theirs.keep, theirs.sources, theirs._jobs_dev = [], [], [], None
+        theirs.jobs, theirs.keep, theirs.sources, theirs._jobs_dev, theirs.prepare = [], [], [], None, []
         theirs._root = mine
 
     def run(self):
@@ -559,6 +571,8 @@ class DevicePack:
                 raise RuntimeError("fc_pack_job layout mismatch between the header and the ctypes mirror")
             raw = b"".join(bytes(j) for j in pack.jobs)
             pack._jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(pack.device)
+        for fn in pack.prepare:
+            fn()
         _call("fc_pack_fragments", lib.fc_pack_fragments, pack.device, _hip.ptr(pack._jobs_dev), len(pack.jobs),
               _hip.stream_ptr(pack.device))
 
@@ -648,6 +662,86 @@ def device_pack_resnet_hidden_forward(net):
                  nks=k0s if i == 0 else 2, nt=4)
         off += size
     return pack, (w_frag, w_un, bias_acc)
+
+
+def device_pack_affine_coupling(net, d_t, additive):
+    """The LDS image of ``fc_affine_coupling_resnet``: the hidden layers of ``net`` (``device_pack_resnet_hidden_forward``)
+    plus its final Linear as one more 64 x 64 layer with rows 0..31 = shift rows, rows 32..63 = scale rows.  The re-ordered
+    copy of the final layer lives in a staging buffer refreshed before every pack launch.  Returns ``(pack, packed)``."""
+    dev = net.initial_layer.weight.device
+    k0s = 1 if net.initial_layer.in_features <= 32 else 2
+    hidden_layers = [net.initial_layer] + [lin for block in net.blocks for lin in block.linear_layers]
+    n_layers = len(hidden_layers) + 1
+    frag0, frag_l = k0s * 4 * 2 * 64 * 8, 2 * 4 * 2 * 64 * 8
+    w_frag = torch.empty(frag0 + (n_layers - 1) * frag_l, dtype=torch.float16, device=dev)
+    w_un = torch.empty(n_layers, dtype=torch.float32, device=dev)
+    bias_acc = torch.empty(n_layers, 64, dtype=torch.float32, device=dev)
+    lin = net.final_layer
+    stage_w = torch.zeros(64, 64, dtype=torch.float32, device=dev)
+    stage_b = torch.zeros(64, dtype=torch.float32, device=dev)
+    hf = lin.in_features
+
+    def stage():
+        with torch.no_grad():
+            stage_w[:d_t, :hf].copy_(lin.weight[:d_t])
+            stage_b[:d_t].copy_(lin.bias[:d_t])
+            if not additive:
+                stage_w[32:32 + d_t, :hf].copy_(lin.weight[d_t:2 * d_t])
+                stage_b[32:32 + d_t].copy_(lin.bias[d_t:2 * d_t])
+
+    pack = DevicePack(dev)
+    off = 0
+    for i, layer in enumerate(hidden_layers):
+        size = frag0 if i == 0 else frag_l
+        pack.add(PACK_HIDDEN, layer.weight, layer.bias, w_frag[off:off + size], w_un[i:i + 1], bias_acc[i],
+                 nks=k0s if i == 0 else 2, nt=4)
+        off += size
+    pack.add(PACK_HIDDEN, stage_w, stage_b, w_frag[off:off + frag_l], w_un[n_layers - 1:n_layers], bias_acc[n_layers - 1],
+             nks=2, nt=4, track=False)
+    pack.sources += [lin.weight, lin.bias]        # (the staging buffers' versions move only when these do)
+    pack.prepare.append(stage)
+    return pack, (w_frag, w_un, bias_acc)
+
+
+def affine_tail_fits(in_features, num_blocks, d):
+    """LDS budget of ``fc_affine_coupling_resnet``: the weight image (initial layer, 2 per block, the final Linear) + one
+    [16, D | 1] float tile per wave next to it, 160 KB per CU; D <= 128, <= 3 blocks."""
+    k0s = 1 if in_features <= 32 else 2
+    layers = 2 + 2 * num_blocks
+    image = (k0s * 8 + (2 * num_blocks + 1) * 16) * 1024 + layers * 64 * 4 + 64 + 32 * k0s * 4 + 512
+    return d <= 128 and num_blocks <= 3 and image + 16 + 8 * 16 * (d | 1) * 4 <= 160 * 1024
+
+
+def affine_tail_activation(code):
+    """Scale activations ``fc_affine_coupling_resnet`` evaluates itself."""
+    return code in (AFFINE_SIGMOID_PLUS2, AFFINE_SOFTPLUS_CLAMP3, AFFINE_ADDITIVE)
+
+
+def affine_coupling_resnet(inputs, id_cols, tr_cols, packed, in_features, num_blocks, activation, inverse=False,
+                           logabsdet_accum=None):
+    """One affine / additive coupling layer with a ResidualNet(hidden <= 64, <= 3 ReLU blocks) conditioner in ONE kernel
+    (``fc_affine_coupling_resnet``); rows a multiple of 16.  Returns ``(outputs, logabsdet)``; with ``logabsdet_accum`` the
+    layer's logabsdet is added onto that tensor, which is returned."""
+    lib = _hip.load()
+    x = _prep_2d(inputs)
+    _hip.require_no_grad(inputs)
+    n, d = x.shape
+    if n % HIDDEN_ROWS != 0 or not affine_tail_activation(activation):
+        raise ValueError("fc_affine_coupling_resnet: unsupported rows / activation")
+    w_frag, w_un, bias_acc = packed
+    ids, cols = _as_cols(id_cols, x.device), _as_cols(tr_cols, x.device)
+    y = torch.empty_like(x)
+    if logabsdet_accum is not None:
+        lad = logabsdet_accum
+        if lad.dtype != torch.float32 or lad.shape != (n,) or not lad.is_contiguous() or lad.device != x.device:
+            raise ValueError("logabsdet_accum must be a contiguous float32 [N] tensor on the inputs' device")
+    else:
+        lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    _call("fc_affine_coupling_resnet", lib.fc_affine_coupling_resnet, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(ids),
+          _hip.ptr(cols), _hip.ptr(w_frag), _hip.ptr(w_un), _hip.ptr(bias_acc), _hip.ptr(lad), n, d, in_features,
+          cols.numel(), 64, num_blocks, int(activation), 1 if inverse else 0, 0 if logabsdet_accum is None else 1,
+          _hip.stream_ptr(x.device))
+    return y, lad
 
 
 def resnet_hidden_packed(inputs, id_cols, packed, in_features, num_blocks, activation=(ACT_RELU, 0.0)):

@@ -204,6 +204,57 @@ class AffineCouplingTransform(CouplingTransform):
         return ops.affine_coupling(inputs, transform_params, self._cols(inputs.device),
                                    activation=code, inverse=inverse, logabsdet_accum=total)
 
+    def _one_kernel_ok(self, inputs, context):
+        """The whole layer in ``fc_affine_coupling_resnet``: plain ResidualNet(hidden <= 64, <= 3 ReLU blocks, no context,
+        no batch norm / active dropout, no hooks), <= 32 transformed dims, a scale activation the kernel knows, 2-D float32
+        inputs on the device, inference only."""
+        net = self.transform_net
+        n = inputs.shape[0] if inputs.dim() == 2 else 0
+        return (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and n >= ops.HIDDEN_ROWS and self.unconditional_transform is None and self.num_transform_features <= 32
+                and options.get("fused_hidden") and options.get("fused_final_layer")
+                and ops.affine_tail_activation(self._activation_code())
+                and _is_plain_resnet(net) and not ops.has_hooks(net)
+                and ops.affine_tail_fits(net.initial_layer.in_features, len(net.blocks), inputs.shape[1])
+                and net.hip_hidden_supported(inputs.shape[1], None)
+                and all(ops.activation_code(b.activation)[0] == ops.ACT_RELU for b in net.blocks)
+                and not (torch.is_grad_enabled()
+                         and (inputs.requires_grad or any(p.requires_grad for p in net.parameters()))))
+
+    def _one_kernel(self, inputs, inverse, total):
+        net = self.transform_net
+        where = net._storage_key()
+        plan = getattr(self, "_tail_image", None)
+        if plan is None or plan[0] != where:
+            pack, packed = ops.device_pack_affine_coupling(net, self.num_transform_features,
+                                                           self._activation_code() == ops.AFFINE_ADDITIVE)
+            plan = self._tail_image = [where, pack, packed]
+        plan[1].refresh()
+        n = inputs.shape[0]
+        body = n - n % ops.HIDDEN_ROWS
+        dev = inputs.device
+        args = (self._id_cols(dev), self._cols(dev), plan[2], net.initial_layer.in_features, len(net.blocks),
+                self._activation_code())
+        if body == n:
+            return ops.affine_coupling_resnet(inputs, *args, inverse=inverse, logabsdet_accum=total)
+        # the < 16 leftover rows: conditioner on PyTorch + the stand-alone kernel
+        out_a, lad_a = ops.affine_coupling_resnet(inputs[:body], *args, inverse=inverse,
+                                                  logabsdet_accum=None if total is None else total[:body])
+        rest = inputs[body:].contiguous()
+        params = net(rest[:, self.identity_features], None)
+        out_b, lad_b = self._coupling_kernel(rest, params, inverse)
+        outputs = torch.cat((out_a, out_b))
+        if total is None:
+            return outputs, torch.cat((lad_a, lad_b))
+        total[body:] += lad_b
+        return outputs, total
+
+    def _run(self, inputs, context, inverse):
+        if self._one_kernel_ok(inputs, context):
+            self._check(inputs)
+            return self._one_kernel(inputs, inverse, None)
+        return super()._run(inputs, context, inverse)
+
     def _apply_accumulate(self, inputs, context, inverse, total):
         """CompositeTransform fast path: the kernel adds this layer's logabsdet onto ``total`` itself."""
         if inputs.dim() != 2 or self.unconditional_transform is not None or not inputs.is_cuda:
@@ -211,6 +262,9 @@ class AffineCouplingTransform(CouplingTransform):
             total += logabsdet
             return outputs
         self._check(inputs)
+        if self._one_kernel_ok(inputs, context):
+            outputs, _ = self._one_kernel(inputs, inverse, total)
+            return outputs
         transform_params = self._conditioner(inputs, None, context)
         outputs, _ = self._coupling_kernel(inputs, transform_params, inverse, total=total)
         return outputs
@@ -224,6 +278,9 @@ class AdditiveCouplingTransform(AffineCouplingTransform):
 
     def _transform_dim_multiplier(self):
         return 1
+
+    def _activation_code(self):
+        return ops.AFFINE_ADDITIVE
 
     def _coupling_kernel(self, inputs, transform_params, inverse, total=None):
         # logabsdet == 0: nothing to add onto a running total

@@ -166,6 +166,21 @@ int fc_resnet_hidden_packed(const float* x, float* h, const int32_t* id_cols, co
                             int32_t in_features, int32_t hidden, int32_t num_blocks, int32_t activation,
                             float activation_param, void* stream);
 
+/* One kernel per AFFINE coupling layer (flowcon/transforms/coupling.py:73-100 + :212-269 with a ResidualNet conditioner,
+ * nn/nets/resnet.py:55-100): hidden stack, final Linear and the affine / additive bijector; neither h nor the [n, 2 d_t]
+ * parameter tensor reaches memory.  y [n, d] (must not alias x) receives the identity columns unchanged and the transformed
+ * ones; logabsdet [n] is written, or added to when accumulate != 0 (CompositeTransform's running total).
+ *   w_frag / w_unscale / bias_acc: the image of fc_resnet_hidden_packed with ONE MORE 64 x 64 layer, the final Linear
+ *   re-ordered as rows 0..31 = its shift rows of dims 0..31, rows 32..63 = its scale rows (zero rows beyond d_t; additive:
+ *   no scale rows), i.e. L = 2 + 2 num_blocks layers.
+ * scale_activation: FC_AFFINE_SIGMOID_PLUS2, FC_AFFINE_SOFTPLUS_CLAMP3 or FC_AFFINE_ADDITIVE.  ReLU conditioner, hidden == 64
+ * (narrower: zero-padded), num_blocks <= 3, in_features <= 64, d_t <= 32, d <= 128, n % 16 == 0; the weight image and the
+ * waves' row tiles (8 x 16 x (d | 1) floats) must fit the CU's 160 KB of LDS (else hipErrorInvalidConfiguration). */
+int fc_affine_coupling_resnet(const float* x, float* y, const int32_t* id_cols, const int32_t* tr_cols,
+                              const void* w_frag, const float* w_unscale, const float* bias_acc, float* logabsdet,
+                              int64_t n, int32_t d, int32_t in_features, int32_t d_t, int32_t hidden, int32_t num_blocks,
+                              int32_t scale_activation, int32_t inverse, int32_t accumulate, void* stream);
+
 /* Backward of fc_resnet_hidden (what torch.autograd yields for resnet.py:39-53, 93-99): the activations are recomputed
  * from x; grad_h [n, 64] in -> grad_x_id [n, 32 K0S] (gradient wrt x[:, id_cols], K0S = 1 for in_features <= 32 else 2),
  * and, ACCUMULATED with atomics (zero them first): grad_w0 [64][32 K0S], grad_wb [2 num_blocks][64][64], grad_b [L][64],

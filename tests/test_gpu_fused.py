@@ -153,9 +153,10 @@ def test_fused_flow_narrow_conditioners(hidden_features, n, device, monkeypatch)
         ref = O.flow_log_prob(flow, x)
     flow = flow.to(device)
     with torch.no_grad(), ops.KernelTimer("fc_rq_spline_fused_linear") as fused, \
-            ops.KernelTimer("fc_resnet_hidden") as hid:
+            ops.KernelTimer("fc_resnet_hidden") as hid, ops.KernelTimer("fc_affine_coupling_resnet") as one:
         lp = flow.log_prob(x.to(device))
-    assert len(fused.pairs) == 4 and len(hid.pairs) == 8
+    # RQ layers: hidden-stack kernel + fused final layer / spline kernel; affine layers: one kernel each
+    assert len(fused.pairs) == 4 and len(hid.pairs) == 4 and len(one.pairs) == 4
     assert maxdiff(lp, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
@@ -351,6 +352,61 @@ def test_fused_linear_input_widths(d, n, d_t, inverse, device):
     tol_y, tol_l = (2e-5, 2e-4) if not inverse else (3e-4, 3e-3)
     assert maxdiff(y, ref_y) <= tol_y * max(1.0, float(ref_y.abs().max()))
     assert maxdiff(lad, ref_lad) <= tol_l * max(1.0, float(ref_lad.abs().max()) / 10)
+
+
+@pytest.mark.parametrize("kind,d,hidden,blocks,n", [("affine", 32, 64, 2, 4096), ("affine", 10, 20, 1, 100), ("general", 64, 64, 3, 1040),
+                                                    ("additive", 24, 48, 0, 333), ("affine", 80, 64, 2, 512)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_affine_coupling_layer_in_one_kernel(kind, d, hidden, blocks, n, inverse, device):
+    """fc_affine_coupling_resnet (hidden stack + final Linear + affine / additive bijector, one launch per layer) against
+    the oracle and against the three-kernel path; leftover rows, narrow nets, 48 identity features (two k-steps), the
+    clamped-softplus scale, the running logabsdet total of a CompositeTransform."""
+    from flowconductor_amd import options, transforms, utils
+    from flowconductor_amd.nn import nets
+
+    torch.manual_seed(d + blocks)
+    mask = utils.create_alternating_binary_mask(d, even=True)
+    if d == 80:       # 48 identity features (two k-steps of the initial layer), 32 transformed
+        mask = torch.cat((torch.zeros(48), torch.ones(32)))
+
+    def net(i, o):
+        return nets.ResidualNet(i, o, hidden_features=hidden, num_blocks=blocks)
+
+    if kind == "additive":
+        t = transforms.AdditiveCouplingTransform(mask, net)
+    else:
+        act = (transforms.AffineCouplingTransform.GENERAL_SCALE_ACTIVATION if kind == "general"
+               else transforms.AffineCouplingTransform.DEFAULT_SCALE_ACTIVATION)
+        t = transforms.AffineCouplingTransform(mask, net, scale_activation=act)
+    t = t.eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.7)
+        t.transform_net.final_layer.bias.add_(torch.randn_like(t.transform_net.final_layer.bias) * 0.3)
+    x = torch.randn(n, d) * 1.3
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(t, x, inverse=inverse)
+    tg = t.to(device)
+    xd = x.to(device)
+    with torch.no_grad(), ops.KernelTimer("fc_affine_coupling_resnet") as one, ops.KernelTimer("fc_affine") as three:
+        y, lad = (tg.inverse if inverse else tg)(xd)
+    assert len(one.pairs) == 1 and len(three.pairs) == (1 if n % 16 else 0)
+    tol = 1e-4 if inverse else 2e-5
+    assert maxdiff(y, ref_y) <= tol * max(1.0, float(ref_y.abs().max()))
+    assert maxdiff(lad, ref_lad) <= 1e-4 * max(1.0, float(ref_lad.abs().max()))
+    with torch.no_grad(), options.override(fused_final_layer=False):
+        y3, lad3 = (tg.inverse if inverse else tg)(xd)
+    assert maxdiff(y, y3) <= tol * max(1.0, float(ref_y.abs().max()))
+    ident = tg.identity_features.to(device)
+    assert torch.equal(y[:, ident], xd[:, ident])
+    # inside a CompositeTransform: the kernel adds onto the running total
+    comp = transforms.CompositeTransform([tg, transforms.ReversePermutation(d), tg])
+    with torch.no_grad():
+        yc, ladc = (comp.inverse if inverse else comp)(xd)
+        a1, l1 = (tg.inverse if inverse else tg)(xd)
+        a2, _ = transforms.ReversePermutation(d).to(device)(a1)
+        a3, l3 = (tg.inverse if inverse else tg)(a2)
+    assert torch.equal(yc, a3) and maxdiff(ladc, l1 + l3) <= 1e-6 * max(1.0, float((l1 + l3).abs().max()))
 
 
 @pytest.mark.parametrize("d,d_t,n", [(64, 32, 4096), (44, 21, 2080), (12, 3, 96)])

@@ -156,9 +156,8 @@ def cfg2(device, steps=20, warmup=5):
     n = 1 << 18
     x = torch.randn(n, 32, device=device, generator=torch.Generator(device=device).manual_seed(1234))
     step_s, _ = _time_gpu(lambda: flow.log_prob(x), steps, warmup)
-    km = _kernel_ms(lambda: flow.log_prob(x), ["fc_affine", "fc_resnet_hidden"])
-    a_ms, a_n = km["fc_affine"]
-    h_ms, h_n = km["fc_resnet_hidden"]
+    km = _kernel_ms(lambda: flow.log_prob(x), ["fc_affine_coupling_resnet"])
+    a_ms, a_n = km["fc_affine_coupling_resnet"]
     xs = x[:2048].cpu()
     with torch.no_grad():
         z_ref, lad_ref = O.transform_apply(flow_cpu._transform, xs.clone())
@@ -168,11 +167,10 @@ def cfg2(device, steps=20, warmup=5):
     out = {"workload": "BASELINE.json configs[1]: 8-layer affine-coupling flow, D=32, ResidualNet(64, 2 blocks), N=2^18",
            "metric": "log_prob samples/sec", "unit": "samples/s", "value": n / step_s, "ms_per_step": step_s * 1e3,
            "dtype": "f32",
-           "roofline": _hbm_roofline("affine tile kernel", "fc_affine", a_ms, a_n, 264 * n,
-                                     "the bijector kernel: B = 4*16*(2+2)+8 = 264 B per sample and layer (SURVEY 8d)"),
-           "roofline_hidden": _hbm_roofline("resnet_hidden_kernel", "fc_resnet_hidden", h_ms, h_n, (4 * 32 + 4 * 64) * n,
-                                            "the layer's dominant kernel (conditioner hidden stack on the matrix cores): "
-                                            "x rows in, h rows out"),
+           "roofline": _hbm_roofline("resnet_hidden_kernel (coupling tail)", "fc_affine_coupling_resnet", a_ms, a_n, 264 * n,
+                                     "one kernel per coupling layer (hidden stack + final Linear + affine bijector); "
+                                     "B = 4*16*(2+2)+8 = 264 B per sample and layer (SURVEY 8d; the kernel itself moves "
+                                     "x in + y out + logabsdet = 264 B: the parameters never exist in memory)"),
            "parity": {"max_rel_dsamples": float(((z.cpu().double() - z_ref.double()).abs()
                                                  / z_ref.double().abs().clamp_min(1.0)).max()),
                       "max_abs_dlogabsdet": _maxdiff(lad, lad_ref), "rows": 2048},
