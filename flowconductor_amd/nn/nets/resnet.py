@@ -252,7 +252,8 @@ class ResidualNet(nn.Module):
             # weight image made on the device (one launch per refresh), copied into LDS by every launch.  In training
             # mode the image is the forward part of the backward kernel's images (same layout): one refresh per
             # optimizer step serves both directions.
-            if self.training and torch.is_grad_enabled() and self.hip_hidden_backward_supported():
+            # (`self.training` alone decides: the fused layer's autograd node runs its forward under no_grad)
+            if self.training and self.hip_hidden_backward_supported():
                 w_frag, _, w_un, bias_acc, _ = self.hidden_backward_packed()
                 return ops.resnet_hidden_packed(rows, id_cols, (w_frag, w_un, bias_acc), in_features, len(self.blocks), act)
             where = self._storage_key()
