@@ -169,7 +169,7 @@ class ResidualNet(nn.Module):
         from flowconductor_amd import ops
 
         width = ops.general_hidden_width(self.hidden_features)
-        key = ops.cache_key(*self.parameters(), extra=("wide", width))
+        key = ops.cache_key(*self._param_list(), extra=("wide", width))
         if getattr(self, "_hip_packed_wide", None) is None or self._hip_packed_wide[0] != key:
             self._hip_packed_wide = (key, ops.pack_resnet_hidden_wide(self, width))
         act = ops.activation_code(self.blocks[0].activation) if len(self.blocks) else (ops.ACT_RELU, 0.0)
@@ -193,10 +193,18 @@ class ResidualNet(nn.Module):
 
     def _storage_key(self):
         """Where the parameters live (a device pack plan holds raw pointers to these storages)."""
-        plist = self.__dict__.get("_fc_param_list")
-        if plist is None:
-            plist = self.__dict__["_fc_param_list"] = tuple(self.parameters())
-        return tuple(p.data_ptr() for p in plist)
+        return tuple(p.data_ptr() for p in self._param_list())
+
+    def _param_list(self):
+        """``tuple(self.parameters())`` kept on the module (walking the module tree on every call was a third of the
+        per-layer host time); dropped by ``_apply`` (.to / .cuda / .float) and rebuilt when the cache epoch moves."""
+        from flowconductor_amd import ops
+
+        memo = self.__dict__.get("_fc_param_list")
+        epoch = ops.cache_key()[0]
+        if memo is None or memo[0] != epoch:
+            memo = self.__dict__["_fc_param_list"] = (epoch, tuple(self.parameters()))
+        return memo[1]
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float(): new storages (and possibly new Parameter objects)
@@ -245,7 +253,6 @@ class ResidualNet(nn.Module):
         narrower net columns ``hidden_features``.. are zero."""
         from flowconductor_amd import ops
 
-        key = ops.cache_key(*self.parameters())
         in_features = self.initial_layer.in_features - (self.context_features or 0)
         act = ops.activation_code(self.blocks[0].activation) if len(self.blocks) else (ops.ACT_RELU, 0.0)
         if context is None:
@@ -263,6 +270,7 @@ class ResidualNet(nn.Module):
                 plan = self._hip_image = [where, pack, packed]
             plan[1].refresh()
             return ops.resnet_hidden_packed(rows, id_cols, plan[2], in_features, len(self.blocks), act)
+        key = ops.cache_key(*self._param_list())
         if getattr(self, "_hip_packed", None) is None or self._hip_packed[0] != key:
             self._hip_packed = (key, ops.pack_resnet_hidden(self))
         return ops.resnet_hidden(rows, id_cols, self._hip_packed[1], in_features, len(self.blocks), context, act)
