@@ -270,9 +270,25 @@ def main():
         reducer_note = "torch.distributed.all_reduce (%s)" % args.dist_backend
         if args.loglik_allreduce == "abi" and args.dist_backend == "nccl":
             ok = torch.ones(1, device=device)
-            try:
-                reducer = parallel.LoglikAllReduce(device, dist.group.WORLD)
-            except Exception as e:        # all ranks must take the same path: agree below
+            # Built on a helper thread with a deadline: a communicator that cannot be set up must cost this run its ABI
+            # collective, not its result (the native call cannot be interrupted; a stuck helper is left behind as a daemon).
+            import threading
+            box = {}
+
+            def build():
+                try:
+                    box["reducer"] = parallel.LoglikAllReduce(device, dist.group.WORLD)
+                except Exception as e:    # noqa: BLE001 -- any failure means "use the torch.distributed path"
+                    box["error"] = e
+
+            helper = threading.Thread(target=build, daemon=True)
+            helper.start()
+            helper.join(timeout=120.0)
+            if helper.is_alive():
+                box["error"] = TimeoutError("fc_comm_init_rank did not return within 120 s")
+            reducer = box.get("reducer") if "error" not in box else None
+            if reducer is None:           # all ranks must take the same path: agree below
+                e = box.get("error")
                 log("rank %d: fc_allreduce_loglik unavailable (%s: %s)" % (rank, type(e).__name__, e))
                 ok.zero_()
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
