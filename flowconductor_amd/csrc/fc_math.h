@@ -90,6 +90,18 @@ __device__ __forceinline__ float softplus_plain(float x, float beta, float inv_b
   return xb > 20.f ? x : l1p * inv_beta;
 }
 
+// sigmoid and tanh on the lean primitives (one exponential each, ~1-2 ulp; no overflow for any finite x)
+__device__ __forceinline__ float sigmoid_lean(float v) {
+  const float e = exp_lean(-fabsf(v));
+  const float r = div_lean(1.f, 1.f + e);
+  return v >= 0.f ? r : e * r;
+}
+__device__ __forceinline__ float tanh_lean(float v) {
+  const float e = exp_lean(-2.f * fabsf(v));
+  const float t = div_lean(1.f - e, 1.f + e);
+  return v >= 0.f ? t : -t;
+}
+
 // F.softplus(x, beta, threshold=20): x*beta > 20 ? x : log1p(exp(x*beta)) / beta
 __device__ __forceinline__ float softplus_b(float x, float beta) {
   const float xb = x * beta;
