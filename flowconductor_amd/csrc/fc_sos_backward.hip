@@ -35,11 +35,6 @@ struct SoSBwdArgs {
   float post;            // exp(log_scale_postact)
 };
 
-__device__ __forceinline__ float sig_lean(float v) {
-  const float e = exp_lean(-fabsf(v));
-  const float r = div_lean(1.f, 1.f + e);
-  return v >= 0.f ? r : e * r;
-}
 
 // One element: r -> the P raw values, g -> where the P gradients go (may alias r: every slot is read before it is
 // written, except the softmax logits, whose probabilities are kept in `sm` [S] until the last loop).  Returns grad_x.
@@ -62,10 +57,10 @@ __device__ __forceinline__ float sos_backward_element(const SoSBwdArgs& a, const
   // pass 2: y_sos, D_sos, W
   float ynum = 0.f, dsos = 0.f, wsum = 0.f;
   for (int k = 0; k < S; ++k) {
-    const float sk = 10.f * tanhf(r[k]);
-    const float al = 0.1f + 9.9f * sig_lean(r[S + k]);
+    const float sk = 10.f * tanh_lean(r[k]);
+    const float al = 0.1f + 9.9f * sigmoid_lean(r[S + k]);
     const float w = a.post * ((sm[k] * rz + 1e-6f) * rtot);
-    const float sg = sig_lean(al * (x - sk));
+    const float sg = sigmoid_lean(al * (x - sk));
     ynum += w * sg;
     dsos += w * al * (sg * (1.f - sg));
     wsum += w;
@@ -73,21 +68,21 @@ __device__ __forceinline__ float sos_backward_element(const SoSBwdArgs& a, const
   const float rw = div_lean(1.f, wsum);
   const float ysos = ynum * rw;
   const float sh = softplus_lean(r[3 * S], 1.f) + 0.1f;
-  const float su = sig_lean(x - sh), sv = sig_lean(-(x + sh));
+  const float su = sigmoid_lean(x - sh), sv = sigmoid_lean(-(x + sh));
   const float desp = su + sv;
   const float gD = gl * div_lean(1.f, dsos + desp);       // d lad / d D_sos = d lad / d D_esp
   const float dsu = su * (1.f - su), dsv = sv * (1.f - sv);
   // pass 3: per-sigmoid adjoints; the gradient of the normalised weight n_k is parked in the logit slot
   float gxs = 0.f, gn_n = 0.f, gn_sm = 0.f;
   for (int k = 0; k < S; ++k) {
-    const float th = tanhf(r[k]);
+    const float th = tanh_lean(r[k]);
     const float sk = 10.f * th;
-    const float sb = sig_lean(r[S + k]);
+    const float sb = sigmoid_lean(r[S + k]);
     const float al = 0.1f + 9.9f * sb;
     const float smk = sm[k] * rz;
     const float nk = (smk + 1e-6f) * rtot;
     const float w = a.post * nk;
-    const float sg = sig_lean(al * (x - sk));
+    const float sg = sigmoid_lean(al * (x - sk));
     const float d1 = sg * (1.f - sg);
     const float g_pre = gy * (w * d1 * rw) + gD * (w * al * d1 * (1.f - 2.f * sg));
     const float g_al = g_pre * (x - sk) + gD * (w * d1);
