@@ -360,3 +360,61 @@ def test_product_path_reads_no_environment_switches():
                 if re.search(r"os\.environ|getenv\s*\(", text):
                     offenders.append(os.path.relpath(os.path.join(base, f), ROOT))
     assert not offenders, offenders
+
+
+def test_device_pack_merge_and_refresh_launch_once_per_weight_version(monkeypatch):
+    """ops.DevicePack: merged packs refresh together, once per parameter version / cache epoch; staging sources that a
+    prepare callable rewrites do not re-trigger the launch (host logic only: the launch itself is stubbed)."""
+    from flowconductor_amd import ops
+
+    launches = []
+    monkeypatch.setattr(ops.DevicePack, "run", lambda self: launches.append(len(self.root().jobs)))
+    w1, b1 = torch.nn.Parameter(torch.randn(8, 4)), torch.nn.Parameter(torch.randn(8))
+    w2 = torch.nn.Parameter(torch.randn(4, 4))
+    out = torch.empty(64, dtype=torch.float16)
+    un = torch.empty(2)
+    a, b = ops.DevicePack(torch.device("cpu")), ops.DevicePack(torch.device("cpu"))
+    a.add(ops.PACK_HIDDEN, w1, b1, out, un[:1], nks=1, nt=1)
+    b.add(ops.PACK_HIDDEN, w2, None, out, un[1:], nks=1, nt=1)
+    stage = torch.zeros(4, 4)
+    b.add(ops.PACK_HIDDEN, stage, None, out, un[1:], nks=1, nt=1, track=False)
+    b.prepare.append(lambda: stage.copy_(w2.detach()))
+    a.merge(b)
+    assert b.root() is a and len(a.jobs) == 3 and len(a.prepare) == 1
+    a.refresh()
+    b.refresh()                      # same versions: the merged pack has run already
+    assert launches == [3]
+    stage.add_(1.0)                  # a staging buffer is not a source
+    a.refresh()
+    assert launches == [3]
+    with torch.no_grad():
+        w2.mul_(2.0)                 # an in-place optimizer-style update bumps the version
+    b.refresh()
+    assert launches == [3, 3]
+    ops.invalidate_hip_caches()      # .data surgery: the caller bumps the epoch
+    a.refresh()
+    assert launches == [3, 3, 3]
+
+
+def test_has_hooks_sees_hooks_added_after_the_module_list_was_memoised():
+    from flowconductor_amd import ops
+    from flowconductor_amd.nn import nets
+
+    net = nets.ResidualNet(4, 6, hidden_features=8, num_blocks=1)
+    assert not ops.has_hooks(net)
+    handle = net.blocks[0].linear_layers[0].register_forward_pre_hook(lambda m, i: None)
+    assert ops.has_hooks(net)
+    handle.remove()
+    assert not ops.has_hooks(net)
+    net.add_module("extra", torch.nn.Linear(2, 2))
+    net.extra.register_forward_hook(lambda m, i, o: None)
+    assert ops.has_hooks(net)
+
+
+def test_affine_tail_lds_budget():
+    from flowconductor_amd import ops
+
+    assert ops.affine_tail_fits(16, 2, 32) and ops.affine_tail_fits(48, 2, 80) and ops.affine_tail_fits(32, 3, 64)
+    assert not ops.affine_tail_fits(16, 4, 32)        # four blocks + the final layer: the image alone is too large
+    assert not ops.affine_tail_fits(16, 2, 200)       # row tiles of D > 128
+    assert not ops.affine_tail_fits(64, 3, 128)
