@@ -723,7 +723,7 @@ def affine_coupling_resnet(inputs, id_cols, tr_cols, packed, in_features, num_bl
     (``fc_affine_coupling_resnet``); rows a multiple of 16.  Returns ``(outputs, logabsdet)``; with ``logabsdet_accum`` the
     layer's logabsdet is added onto that tensor, which is returned."""
     lib = _hip.load()
-    x = _prep_2d(inputs)
+    x = _prep_2d(inputs, align16=True)        # the kernel moves whole 16-row chunks with 16-byte loads
     _hip.require_no_grad(inputs)
     n, d = x.shape
     if n % HIDDEN_ROWS != 0 or not affine_tail_activation(activation):

@@ -399,6 +399,10 @@ def test_affine_coupling_layer_in_one_kernel(kind, d, hidden, blocks, n, inverse
     assert maxdiff(y, y3) <= tol * max(1.0, float(ref_y.abs().max()))
     ident = tg.identity_features.to(device)
     assert torch.equal(y[:, ident], xd[:, ident])
+    # a row-sliced (possibly 16-byte-misaligned) view gives the rows of the full batch
+    with torch.no_grad():
+        yv, ladv = (tg.inverse if inverse else tg)(xd[1:])
+    assert maxdiff(yv, y[1:]) <= tol * max(1.0, float(ref_y.abs().max())) and maxdiff(ladv, lad[1:]) <= 1e-5 * max(1.0, float(ref_lad.abs().max()))
     # inside a CompositeTransform: the kernel adds onto the running total
     comp = transforms.CompositeTransform([tg, transforms.ReversePermutation(d), tg])
     with torch.no_grad():
