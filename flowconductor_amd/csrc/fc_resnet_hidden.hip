@@ -28,8 +28,11 @@
 //                      B fragment of k-step ks, element j  =  accumulator tile 2 ks + (j >> 2), register j & 3.
 // Between layers a lane therefore only does bias + ReLU + split on its own 16 registers; the row maximum
 // for the scaling takes two cross-lane steps.  The residual stream h lives in 16 registers per lane.
-// Weights: both f16 pieces of all layers as ready-made A fragments in LDS (72 KB at <= 32 inputs),
-// built once per workgroup from the row-major f32 weights.
+// Weights: both f16 pieces of all layers as ready-made A fragments in LDS (72 KB at <= 32 inputs): copied from an
+// image prepared once per weight version by fc_pack_fragments (fc_resnet_hidden_packed, fc_affine_coupling_resnet), or
+// built by every workgroup from the row-major f32 weights (fc_resnet_hidden, fc_resnet_hidden_context).
+// kTail (fc_affine_coupling_resnet): the final Linear of an affine coupling layer and the bijector itself run as a tail of
+// the stack -- one kernel per coupling layer.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fc_split.h"

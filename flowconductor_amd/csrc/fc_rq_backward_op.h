@@ -40,7 +40,7 @@ template <int KS, bool kSearch>
 __device__ __forceinline__ void knots_axis(const float* __restrict__ p, int K, float minb, float c1, float lo, float hi,
                                            float v, int& idx, float& k_lo, float& k_hi, float& pre_lo, float& pre_hi) {
   const float span = hi - lo;
-  double cum = 0.0;   // ATen's CPU cumsum accumulates f32 in double (as the forward kernels do)
+  double cum = 0.0;   // ATen's CPU cumsum accumulates f32 in double (as the run-time-K forward walk does)
   float psum = 0.f, prev = lo, prevp = 0.f;
   int found = kSearch ? 0 : idx;
   k_lo = lo; k_hi = lo; pre_lo = 0.f; pre_hi = 0.f;

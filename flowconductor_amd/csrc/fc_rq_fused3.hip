@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
       // Fairness between the two waves of a SIMD.  VALU issue goes to the higher s_setprio, then to the OLDER
       // wave: left alone, waves 0-3 run each step unimpeded, wait ~3700 cycles per tile at the barriers, and
       // waves 4-7 finish alone at single-wave issue rate.  A priority that falls as a wave advances (a
-      // sawtooth over 12 hooks) always favours the wave that is behind, so both reach the barrier together.
+      // sawtooth over FC_PRIO_PERIOD hooks) always favours the wave that is behind, so both reach the barrier together.
       if constexpr (n % (FC_PRIO_PERIOD / 4) == FC_PRIO_PERIOD / 4 - 1)
         __builtin_amdgcn_s_setprio(3 - ((n + 1) % FC_PRIO_PERIOD) / (FC_PRIO_PERIOD / 4));
       __builtin_amdgcn_sched_barrier(FC_HOOK_MASK);
