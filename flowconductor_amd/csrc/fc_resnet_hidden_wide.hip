@@ -27,6 +27,12 @@ namespace fc {
 
 constexpr int kWR = 64;          // rows per tile: four 16-sample blocks
 constexpr int kWThreads = 512;
+// Waves per SIMD the register budget is set for: 4 = 128 registers, TWO workgroups per CU (their LDS, 2 x 68 KB, always
+// fitted; the H = 256 kernel's 152 registers did not).  The kernel waits on its weight stream from L2 for ~60 % of its
+// wave cycles, so the second workgroup pays: 0.62 -> 0.50 ms per 2^18 rows at H = 256 despite 76 B of spills.
+#ifndef FC_WIDE_WAVES
+#define FC_WIDE_WAVES 4
+#endif
 
 struct WideArgs {
   const float* x;          // [N, D]
@@ -53,7 +59,7 @@ __device__ __forceinline__ float wide_act(float v, int act, float p) {
 
 // HQ = H / 64 (2 or 4); kRelu: the blocks' activation is ReLU (a v_max) / the one named by a.act
 template <int HQ, bool kRelu>
-__global__ __launch_bounds__(kWThreads) void resnet_hidden_wide_kernel(WideArgs a) {
+__global__ __launch_bounds__(kWThreads, FC_WIDE_WAVES) void resnet_hidden_wide_kernel(WideArgs a) {
   constexpr int H = 64 * HQ, KS = H / 32, HB = H + 8, R = kWR;
   constexpr int TPW = H / 16 / 8;            // output tiles (16 features) per wave: 1 or 2
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
