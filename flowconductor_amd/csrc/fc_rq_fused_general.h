@@ -77,8 +77,12 @@ __device__ __forceinline__ float group_allmax(float m, int lane) {
 }
 
 // HQ = H / 64 (1, 2, 4): float4 pieces of the h tile per thread
+// (K <= 8 at hidden <= 128: 128 registers, so that TWO workgroups share a CU -- the kernel spends half of its wave cycles
+//  waiting for weight fragments from L2: 0.79 -> 0.73 ms per 2^20 rows at K = 8 / hidden 64; K = 10 needs 171 registers)
+constexpr int gen_waves_per_simd(int k, int hq) { return (k <= 8 && hq <= 2) ? 4 : 2; }
+
 template <int K, bool kTails, int HQ>
-__global__ __launch_bounds__(kGenThreads) void rq_fused_general_kernel(RQOp<K> op, GenArgs a) {
+__global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fused_general_kernel(RQOp<K> op, GenArgs a) {
   using S = GenShape<K, kTails>;
   constexpr int PP = S::PP, T = S::T, TC = S::TC;
   constexpr int R = kGenRows;
@@ -253,7 +257,8 @@ hipError_t launch_general_hq(const RQOp<K>& op, const GenArgs& a, hipStream_t st
       attr, reinterpret_cast<const void*>(&rq_fused_general_kernel<K, kTails, HQ>), 160 * 1024);
   if (ea != hipSuccess) return ea;
   const int64_t cus = device_cu_count();
-  const unsigned grid = (unsigned)(cus < a.tiles ? cus : a.tiles);
+  const int64_t wgs = cus * ((gen_waves_per_simd(K, HQ) == 4 && 2 * lds <= 160 * 1024) ? 2 : 1);
+  const unsigned grid = (unsigned)(wgs < a.tiles ? wgs : a.tiles);
   hipLaunchKernelGGL((rq_fused_general_kernel<K, kTails, HQ>), dim3(grid), dim3(kGenThreads), lds, stream, op, a);
   return hipGetLastError();
 }
