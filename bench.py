@@ -223,6 +223,9 @@ def main():
                     help="abi: fc_allreduce_loglik (RCCL through the C ABI); torch: torch.distributed.all_reduce")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-device0 rehearses the N>1 code path on a one-GPU box")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="rehearsal only: set up the process group, the C-ABI reducer and every collective of the N>1 "
+                         "path although WORLD_SIZE is 1 (one-GPU box: RCCL with a single rank)")
     ap.add_argument("--share-device0", action="store_true",
                     help="rehearsal only: every rank on the single GPU of the box (with --dist-backend gloo)")
     args = ap.parse_args()
@@ -249,7 +252,8 @@ def main():
     device = torch.device("cuda", plan["device_index"])
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    collective = world > 1 or args.rehearse_dist      # the N>1 code path (process group, reducer, barriers)
+    if collective:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -266,7 +270,7 @@ def main():
 
     # the path's one collective: {sum log_prob, count}, 16 bytes, through the C ABI (RCCL) when the job runs on RCCL
     reducer, reducer_note = None, "none (1 rank)"
-    if world > 1:
+    if collective:
         reducer_note = "torch.distributed.all_reduce (%s)" % args.dist_backend
         if args.loglik_allreduce == "abi" and args.dist_backend == "nccl":
             ok = torch.ones(1, device=device)
@@ -303,7 +307,7 @@ def main():
     def step():
         with torch.no_grad():
             return parallel.sharded_log_prob_mean(flow.log_prob, x, chunk=chunk, reducer=reducer,
-                                                  group=None if world == 1 else dist.group.WORLD)
+                                                  group=dist.group.WORLD if collective else None)
 
     torch.set_num_threads(host_cores())
     log("rank %d/%d on cuda:%d (%s): %d samples (rows %d..%d, seed %d), %s scaling, host cores %d"
@@ -391,7 +395,7 @@ def main():
                        "samples_per_gpu": n_local, "global_batch": total // args.steps,
                        "chunk_rows": rows_per_launch, "parallelism": "batch-sharded dp%d" % world,
                        "mean_log_prob": mean_lp},
-            "rccl_ranks": world if (world > 1 and args.dist_backend == "nccl") else 0,
+            "rccl_ranks": world if (collective and args.dist_backend == "nccl") else 0,
             "loglik_allreduce": reducer_note,
             "per_rank": per_rank,
             "library": _hip.library_info(),
