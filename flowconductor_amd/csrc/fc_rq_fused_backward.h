@@ -59,7 +59,7 @@ struct BwdArgs {
 
 constexpr int kBwdH = 64, kBwdHB = kBwdH + 8, kBwdR = kGenRows, kBwdTS = 32 + 8;   // TS: f16 per row of a transposed image
 
-inline size_t bwd_lds_bytes(int d, int role) {
+__host__ __device__ inline size_t bwd_lds_bytes(int d, int role) {
   size_t b = (size_t)2 * 2 * kBwdR * kBwdHB * 2;            // hbuf [buf][piece][row][72]
   b += (size_t)2 * 2 * kBwdR * (d + 4) * 4;                 // xbuf + gbuf, [buf][row][D + 4]
   b += 2 * kBwdR * 4 * 2;                                   // hscale, gl  [buf][row]
@@ -92,10 +92,19 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   _Float16* htbuf = reinterpret_cast<_Float16*>(bias_lds + 32 * 52 + (kMerged ? 2 * R * H : 0));   // roles 1, 2: [2][2][H][TS]
   _Float16* strips = htbuf + (size_t)2 * 2 * H * TS;                              // roles 1, 2: [8 waves][2][16][TS]
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // (the wave index as a scalar: fragment, bias and strip addresses then are SGPR bases + one lane offset instead of two dozen
+  //  64-bit VGPR pointers -- those were spilled, and every fragment load of the recompute waited for its address reload)
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int s16 = lane & 15, g = lane >> 4;
   const int64_t stride = gridDim.x, tile0 = blockIdx.x;
   if (tile0 >= a.tiles) return;
+#ifdef FC_BWD_POISON   // tools/probe only: every LDS word starts as a NaN, so a read of a word nobody wrote shows in the result
+  {
+    const int words = (int)(bwd_lds_bytes(D, kRole) / 4);
+    for (int i = threadIdx.x; i < words; i += kGenThreads) reinterpret_cast<uint32_t*>(bsm)[i] = FC_BWD_POISON;
+    __syncthreads();
+  }
+#endif
   if (tid < 32) cs[tid] = tid < a.dt ? a.cols[tid] : 0;
   const int WD = (a.dt + 3) >> 2;
   const bool active = wave < WD;
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   for (int i = tid; i < WD * 4 * PP; i += kGenThreads) bias_lds[i] = a.bias[i];
   const f32x4* bw = reinterpret_cast<const f32x4*>(bias_lds + (grp * 4 + g) * PP);
   const float w_un = a.wun[grp];
-  const f16x8* wsrc = a.wfrag + (size_t)grp * KS * T * 2 * 64 + lane;
+  const f16x8* const wgrp = a.wfrag + (size_t)grp * KS * T * 2 * 64;      // wave-uniform
 
   const int xvec = R * D / 4;
   float4 hv, xv0, xv1, gv0, gv1;
@@ -206,10 +215,13 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
       for (int ks = 0; ks < KS; ++ks) {
         const f16x8 bh0 = hfrag(buf, 0, 0, ks), bl0 = hfrag(buf, 0, 1, ks);
         const f16x8 bh1 = hfrag(buf, 1, 0, ks), bl1 = hfrag(buf, 1, 1, ks);
-        const f16x8* wk = wsrc + (size_t)ks * T * 2 * 64;
+        // scalar base, re-made per k-step behind an opaque asm: otherwise the two dozen fragment addresses are hoisted out of
+        // the tile loop as 64-bit VGPR pairs (and spilled)
+        const f16x8* wk = wgrp + (size_t)ks * T * 2 * 64;
+        asm volatile("" : "+s"(wk));
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const f16x8 ah = wk[(t * 2 + 0) * 64], al = wk[(t * 2 + 1) * 64];
+          const f16x8 ah = wk[(t * 2 + 0) * 64 + lane], al = wk[(t * 2 + 1) * 64 + lane];
           acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, acc[0][t], 0, 0, 0);
           acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh1, acc[1][t], 0, 0, 0);
           acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, acc[0][t], 0, 0, 0);
@@ -218,6 +230,17 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
           acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, acc[1][t], 0, 0, 0);
         }
       }
+#ifdef FC_BWD_DRAIN
+      {   // every accumulator chain ends in a VALU read here, before any later load may be given one of their registers
+        float drain = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int t = 0; t < T; ++t) drain += acc[b][t][3];
+        asm volatile("" ::"v"(drain));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
       // ---- spline backward of this lane's two elements -> G in registers ------------------------------------------
       float gp[2][PP8];
 #pragma unroll
@@ -271,13 +294,14 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
               bl[b][kk][j] = pl;
             }
         }
-        const f16x8* wt = a.wtfrag + (size_t)grp * 4 * KK * 2 * 64 + lane;
+        const f16x8* wt = a.wtfrag + (size_t)grp * 4 * KK * 2 * 64;
+        asm volatile("" : "+s"(wt));
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
           f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
           for (int kk = 0; kk < KK; ++kk) {
-            const f16x8 ah = wt[((size_t)(ht * KK + kk) * 2 + 0) * 64], al = wt[((size_t)(ht * KK + kk) * 2 + 1) * 64];
+            const f16x8 ah = wt[((size_t)(ht * KK + kk) * 2 + 0) * 64 + lane], al = wt[((size_t)(ht * KK + kk) * 2 + 1) * 64 + lane];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
               o[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[b][kk], o[b], 0, 0, 0);
@@ -326,6 +350,12 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
             fshift[i] = shift;
           }
           const float sc = fshift[i] == 1000 ? 1.f : __uint_as_float((uint32_t)(127 + fshift[i]) << 23);
+#ifdef FC_BWD_DEBUG   // tools/probe only (role 1 does not write gx): the scale decisions of every (tile, wave, dim, feature)
+          if (kRole == 1 && s16 == 0) {
+            a.gx[tile * R * D + (wave * 4 + g) * PP + i] = (float)fshift[i];
+            a.gx[tile * R * D + 768 + (wave * 4 + g) * PP + i] = m;
+          }
+#endif
           gp[0][i] *= sc;
           gp[1][i] *= sc;
         }
@@ -402,8 +432,12 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
           if (4 * t + r < P && fshift[4 * t + r] != 1000) {
             const float un = __uint_as_float((uint32_t)(127 - fshift[4 * t + r]) << 23);
 #pragma unroll
-            for (int ht = 0; ht < 4; ++ht)
+            for (int ht = 0; ht < 4; ++ht) {
               atomicAdd(a.gw + ((size_t)(grp * 4 + g) * PP + 4 * t + r) * H + 16 * ht + s16, dw[t][ht][r] * un);
+#ifdef FC_BWD_PARTIALS   // tools/probe only (role 1 does not write gx; one tile per workgroup): this workgroup's share
+              if (kRole == 1 && g == 3 && t == 0) a.gx[tile0 * R * D + (wave * 4 + r) * H + 16 * ht + s16] = dw[t][ht][r] * un;
+#endif
+            }
           }
     }
   }

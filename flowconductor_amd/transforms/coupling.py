@@ -571,8 +571,10 @@ class _FusedRQCouplingFunction(torch.autograd.Function):
             hidden = layer._hidden_for_fused(x, None, None, 64)
             kw = layer._fused_kw(net)
             rows, lad = x, None
-            k8 = ops.fused_linear_supported(x.shape[0], x.shape[1], min(layer.num_transform_features, ops.FUSED_DT),
-                                            net.hidden_features, layer.num_bins, layer.tails)
+            # (raw weights: only a conditioner that IS 64 wide -- a narrower one is zero-padded by the packed fragments)
+            k8 = net.hidden_features == ops.FUSED_HIDDEN and ops.fused_linear_supported(
+                x.shape[0], x.shape[1], min(layer.num_transform_features, ops.FUSED_DT), net.hidden_features,
+                layer.num_bins, layer.tails)
             lin = net.final_layer
             for w_frag, w_un, bias_pad, _, cols, rows_slice in layer._train_chunks(x.device):
                 if k8:    # the hand-scheduled north-star kernel takes the f32 weights as they are

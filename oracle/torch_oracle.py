@@ -13,11 +13,31 @@ known-answer tests restated in ``tests/test_oracle_known_answers.py``.
 
 Works in float32 (parity / CPU baseline) and float64 (error-vs-truth measurements).
 """
+import contextlib
 import math
 
 import numpy as np
 import torch
 import torch.nn.functional as F
+
+
+_DIFFERENTIABLE_PARAMETERS = False
+
+
+def _p(parameter):
+    """A module parameter as the oracle uses it: detached (the oracle is an inference restatement) unless
+    ``differentiable_parameters()`` is active (gradient checks against torch.autograd walking the oracle)."""
+    return parameter if _DIFFERENTIABLE_PARAMETERS else parameter.detach()
+
+
+@contextlib.contextmanager
+def differentiable_parameters():
+    global _DIFFERENTIABLE_PARAMETERS
+    previous, _DIFFERENTIABLE_PARAMETERS = _DIFFERENTIABLE_PARAMETERS, True
+    try:
+        yield
+    finally:
+        _DIFFERENTIABLE_PARAMETERS = previous
 
 
 class OracleInputOutsideDomain(Exception):
@@ -317,7 +337,7 @@ def _rq_cdf(t, inputs, context, inverse):
     n = inputs.shape[0]
 
     def share(p):
-        return p.detach()[None, ...].expand(n, *p.shape)
+        return _p(p)[None, ...].expand(n, *p.shape)
 
     rows = torch.cat((share(t.unnormalized_widths), share(t.unnormalized_heights),
                       share(t.unnormalized_derivatives)), dim=-1).clone()
@@ -392,7 +412,7 @@ def householder_apply(inputs, q_vectors):
 
 def _householder(t, inputs, context, inverse):
     """orthogonal.py:63-72 / :111-117."""
-    q = t.q_vectors.detach() if isinstance(t.q_vectors, torch.nn.Parameter) else t.q_vectors
+    q = _p(t.q_vectors) if isinstance(t.q_vectors, torch.nn.Parameter) else t.q_vectors
     if inverse:
         q = q.flip(-2)
     return householder_apply(inputs, q), inputs.new_zeros(inputs.shape[0])
@@ -404,7 +424,7 @@ def _planar(t, inputs, context, inverse):
     """planar.py:30-69 (no inverse)."""
     if inverse:
         raise NotImplementedError("PlanarTransform has no inverse")
-    w, u, b = t.w.detach(), t.u.detach(), t.b.detach()
+    w, u, b = _p(t.w), _p(t.u), _p(t.b)
     wtu = torch.mm(u, w.T)
     m_wtu = -1 + F.softplus(wtu)
     u_hat = u + (m_wtu - wtu) * (w / (torch.norm(w, p=2, dim=1) ** 2))
@@ -441,9 +461,9 @@ def _sylvester(t, inputs, context, inverse):
     if inverse:
         raise NotImplementedError("SylvesterTransform has no inverse")
     f = t.features
-    r1 = _upper_from(t.upper_entries1.detach(), torch.tanh(t.log_upper_diag1.detach()), f)
-    r2 = _upper_from(t.upper_entries2.detach(), torch.tanh(t.log_upper_diag2.detach()), f)
-    return sylvester_forward(inputs, t.Q_orth.q_vectors.detach(), r1, r2, t.bias.detach())
+    r1 = _upper_from(_p(t.upper_entries1), torch.tanh(_p(t.log_upper_diag1)), f)
+    r2 = _upper_from(_p(t.upper_entries2), torch.tanh(_p(t.log_upper_diag2)), f)
+    return sylvester_forward(inputs, _p(t.Q_orth.q_vectors), r1, r2, _p(t.bias))
 
 
 # ---- lu.py / linear.py ---------------------------------------------------------------------------------
@@ -452,11 +472,11 @@ def lu_matrices(t):
     """lu.py:44-54."""
     f = t.features
     il = np.tril_indices(f, k=-1)
-    lower = t.lower_entries.detach().new_zeros(f, f)
-    lower[il[0], il[1]] = t.lower_entries.detach()
+    lower = _p(t.lower_entries).new_zeros(f, f)
+    lower[il[0], il[1]] = _p(t.lower_entries)
     lower[range(f), range(f)] = 1.0
-    upper_diag = F.softplus(t.unconstrained_upper_diag.detach()) + t.eps
-    upper = _upper_from(t.upper_entries.detach(), upper_diag, f)
+    upper_diag = F.softplus(_p(t.unconstrained_upper_diag)) + t.eps
+    upper = _upper_from(_p(t.upper_entries), upper_diag, f)
     return lower, upper, upper_diag
 
 
@@ -464,7 +484,7 @@ def _lu_linear(t, inputs, context, inverse):
     """lu.py:56-91 (no-cache path) and linear.py:45-76 (eval-mode cache path)."""
     lower, upper, upper_diag = lu_matrices(t)
     logabsdet = torch.sum(torch.log(upper_diag))
-    bias = t.bias.detach()
+    bias = _p(t.bias)
     ones = inputs.new_ones(inputs.shape[0])
     if not t.training and t.using_cache:
         if not inverse:
@@ -488,7 +508,7 @@ def _actnorm(t, inputs, context, inverse):
     """normalization.py:171-204 (initialised / eval mode)."""
     if inputs.dim() not in (2, 4):
         raise ValueError("Expecting inputs to be a 2D or a 4D tensor.")
-    log_scale, shift = t.log_scale.detach(), t.shift.detach()
+    log_scale, shift = _p(t.log_scale), _p(t.shift)
     scale = torch.exp(log_scale)
     if inputs.dim() == 4:
         scale, shift = scale.view(1, -1, 1, 1), shift.view(1, -1, 1, 1)
@@ -506,8 +526,8 @@ def _batchnorm(t, inputs, context, inverse):
     """normalization.py:98-141 in eval mode."""
     if inputs.dim() != 2:
         raise ValueError("Expected 2-dim inputs, got inputs of shape: {}".format(inputs.shape))
-    weight = F.softplus(t.unconstrained_weight.detach()) + t.eps
-    bias, mean, var = t.bias.detach(), t.running_mean, t.running_var
+    weight = F.softplus(_p(t.unconstrained_weight)) + t.eps
+    bias, mean, var = _p(t.bias), t.running_mean, t.running_var
     ones = inputs.new_ones(inputs.shape[0])
     if inverse:
         outputs = torch.sqrt(var + t.eps) * ((inputs - bias) / weight) + mean
@@ -567,7 +587,7 @@ def _logtanh(t, x, c, inverse):
 def _leaky_relu(t, x, c, inverse):
     """nonlinearities.py:115-136."""
     mask = (x < 0).to(x.dtype)
-    ls = t.log_negative_slope.detach()
+    ls = _p(t.log_negative_slope)
     if inverse:
         return F.leaky_relu(x, negative_slope=(1 / t.negative_slope)), sum_except_batch(-ls * mask)
     return F.leaky_relu(x, negative_slope=t.negative_slope), sum_except_batch(ls * mask)
@@ -575,7 +595,7 @@ def _leaky_relu(t, x, c, inverse):
 
 def _sigmoid(t, x, c, inverse):
     """nonlinearities.py:139-169."""
-    temp = t.temperature.detach()
+    temp = _p(t.temperature)
     if inverse:
         if torch.min(x) < 0 or torch.max(x) > 1:
             raise OracleInputOutsideDomain()
@@ -690,7 +710,7 @@ def monotonic_inverse(forward_fn, z, lim, num_iterations, ratio_multiplier=1.5, 
 
 def _sos_params(t):
     def val(p):
-        return p.detach() if isinstance(p, torch.nn.Parameter) else p
+        return _p(p) if isinstance(p, torch.nn.Parameter) else p
     esp = t.extended_softplus.shift
     return (val(t.shift_preact), val(t.log_scale_preact), val(t.raw_softmax), val(esp),
             float(val(t.log_scale_postact).reshape(-1)[0]))
@@ -976,7 +996,7 @@ def _make_sibling_cdf(kind):
         n = x.shape[0]
 
         def share(p):
-            return p.detach()[None, ...].expand(n, *p.shape).clone()
+            return _p(p)[None, ...].expand(n, *p.shape).clone()
 
         if kind == "linear":
             plist = [share(t.unnormalized_pdf)]
@@ -1025,7 +1045,7 @@ def _cond_lu(t, x, p, inverse):
     """conditional.py:300-346."""
     f = _int(t.features)
     m = p.view(-1, f, f)
-    sp = F.softplus(t.scale_non_diag.detach())
+    sp = F.softplus(_p(t.scale_non_diag))
     eye = torch.eye(f, dtype=x.dtype)
     lower = sp * torch.tril(m, diagonal=-1) + eye
     upper = sp * torch.triu(m, diagonal=1) + torch.diag_embed(F.softplus(m.diagonal(0, -1, -2)) + t.eps)

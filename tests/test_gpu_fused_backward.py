@@ -77,7 +77,8 @@ def _layer(d, hidden, k, tails, seed, blocks=2, mask="alternating"):
 
 @pytest.mark.parametrize("d,hidden,k,tails,n,mask", [(64, 64, 8, "linear", 256, "alternating"), (64, 64, 10, "linear", 200, "alternating"),
                                                      (16, 32, 10, None, 77, "alternating"), (128, 64, 8, "linear", 96, "alternating"),
-                                                     (10, 20, 5, "linear", 33, "alternating"), (64, 64, 8, "linear", 160, "mid_split")])
+                                                     (10, 20, 5, "linear", 33, "alternating"), (64, 64, 8, "linear", 160, "mid_split"),
+                                                     (54, 32, 8, "linear", 512, "alternating")])   # K = 8 with a narrow net
 def test_coupling_layer_trains_through_fused_kernels(d, hidden, k, tails, n, mask, device):
     """Parameter and input gradients of one RQ coupling layer on the fused training path (forward: fc_resnet_hidden +
     fc_rq_spline_fused_general; backward: fc_rq_fused_linear_backward twice per 32 transformed dims) against float64
@@ -101,9 +102,10 @@ def test_coupling_layer_trains_through_fused_kernels(d, hidden, k, tails, n, mas
             ops.KernelTimer("fc_rq_spline_fused_linear") as tf8, ops.KernelTimer("fc_rq_spline_backward") as told:
         y, lad = t_gpu(xd)
         ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
-    # forward: the hand-scheduled K = 8 kernel for the north-star shape, the general one otherwise
+    # forward: the hand-scheduled K = 8 kernel for the north-star shape (it takes the 64-wide nn.Linear weights as they
+    # are), the general one otherwise
     assert len(tb.pairs) == 2 * groups and len(tf.pairs) + len(tf8.pairs) == groups and not told.pairs
-    assert bool(tf8.pairs) == (k == 8 and tails == "linear")
+    assert bool(tf8.pairs) == (k == 8 and tails == "linear" and hidden == 64)
     assert maxdiff(y.detach(), y_ref.detach()) <= 2e-5 * max(1.0, float(y_ref.detach().abs().max()))
     assert maxdiff(lad.detach(), lad_ref.detach()) <= 3e-4
     assert _relerr(xd.grad, x64.grad) <= 2e-4
