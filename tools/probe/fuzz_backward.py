@@ -91,7 +91,8 @@ for c in range(cases):
     elif kind == "sylvester":
         t = T.SylvesterTransform(features=d, num_householder=ri(1, min(d, 8)), device="cpu")
     elif kind == "householder":
-        t = T.HouseholderSequence(features=d, num_transforms=ri(1, 8))
+        # (more than 2 d - 1 reflections make the reference's initialisation index past the features or produce zero vectors)
+        t = T.HouseholderSequence(features=d, num_transforms=ri(1, min(8, 2 * d - 1)))
     elif kind == "lu":
         t = T.LULinear(d, identity_init=False)
     elif kind == "maf":
