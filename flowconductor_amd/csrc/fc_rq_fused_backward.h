@@ -57,6 +57,10 @@ struct BwdArgs {
   int D, dt;
 };
 
+// a fragment pointer that went through an opaque asm (to keep it a scalar base) must say it is global memory again: the
+// compiler otherwise emits flat loads, which also count on lgkmcnt and are waited for before every LDS read
+typedef const __attribute__((address_space(1))) f16x8* GlobalFrags;
+
 constexpr int kBwdH = 64, kBwdHB = kBwdH + 8, kBwdR = kGenRows, kBwdTS = 32 + 8;   // TS: f16 per row of a transposed image
 
 __host__ __device__ inline size_t bwd_lds_bytes(int d, int role) {
@@ -178,9 +182,11 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   // role 0: sums of G over this lane's samples (the bias gradient); role 1: the wave's slice of gW
   float gbacc[kDx ? PP : 1];
   f32x4 dw[kDw ? T : 1][4];
-  int fshift[kDw ? PP : 1];     // per feature, the gW accumulators hold sum G' 2^fshift (1000 = nothing yet)
+  // per feature, the gW accumulators hold sum G' 2^fshift: fshift + 128 in one byte (255 = nothing yet), four features per
+  // register (24 separate registers were a quarter of the role's spills)
+  uint32_t fsh[kDw ? (PP + 3) / 4 : 1];
 #pragma unroll
-  for (int i = 0; i < (kDw ? PP : 1); ++i) fshift[i] = 1000;
+  for (int i = 0; i < (kDw ? (PP + 3) / 4 : 1); ++i) fsh[i] = 0xffffffffu;
   if constexpr (kDx) {
 #pragma unroll
     for (int i = 0; i < PP; ++i) gbacc[i] = 0.f;
@@ -201,24 +207,64 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   int buf = 0;
   for (int64_t tile = tile0; tile < a.tiles; tile += stride) {
     const bool has_next = tile + stride < a.tiles;
-    if (has_next) fetch(tile + stride);
+    // vmcnt retires in order: rows requested ahead of the fragment loads make the first product wait out an HBM round trip
+    // instead of an L2 one, so role 0 (which has the registers) asks for them after its recompute; roles 1 and 2 ask first
+    constexpr bool kFetchLate = kRole == 0 && T <= 6;      // (wider layers: the late request costs spills)
+    if (!kFetchLate && has_next) fetch(tile + stride);
+    f32x4 acc[2][T];
     if (active) {
       // ---- recompute the parameters of both blocks against each weight fragment (the forward kernel's product: one
       // pass over the wave's 24 KB of fragments per tile -- they stream from L2, whose bandwidth bounds this kernel when
       // every block fetches them again) -----------------------------------------------------------------------------
-      f32x4 acc[2][T];
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (kRole == 0) {
+        // Role 0 has registers to spare (183 of 256): the fragment pairs run through a ring of kRing loads in flight, so the
+        // L2 round trip of a fragment overlaps the 6 x kRing MFMAs before it instead of being waited out pair by pair.
+        constexpr int NF = KS * T, kRing = NF < 6 ? NF : 6;
+        const f16x8* wk_ = wgrp;
+        asm volatile("" : "+s"(wk_));
+        const GlobalFrags wk = (GlobalFrags)wk_;
+        f16x8 rh[kRing], rl[kRing];
+#pragma unroll
+        for (int i = 0; i < kRing; ++i) {
+          rh[i] = wk[(i * 2 + 0) * 64 + lane];
+          rl[i] = wk[(i * 2 + 1) * 64 + lane];
+        }
+        f16x8 bh0, bl0, bh1, bl1;
+#pragma unroll
+        for (int i = 0; i < NF; ++i) {
+          const int ks = i / T, t = i - ks * T;
+          if (t == 0) {
+            bh0 = hfrag(buf, 0, 0, ks); bl0 = hfrag(buf, 0, 1, ks);
+            bh1 = hfrag(buf, 1, 0, ks); bl1 = hfrag(buf, 1, 1, ks);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const f16x8 ah = rh[i % kRing], al = rl[i % kRing];
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh1, acc[1][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl1, acc[1][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, acc[1][t], 0, 0, 0);
+          if (i + kRing < NF) {
+            rh[i % kRing] = wk[((i + kRing) * 2 + 0) * 64 + lane];
+            rl[i % kRing] = wk[((i + kRing) * 2 + 1) * 64 + lane];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const f16x8 bh0 = hfrag(buf, 0, 0, ks), bl0 = hfrag(buf, 0, 1, ks);
         const f16x8 bh1 = hfrag(buf, 1, 0, ks), bl1 = hfrag(buf, 1, 1, ks);
         // scalar base, re-made per k-step behind an opaque asm: otherwise the two dozen fragment addresses are hoisted out of
         // the tile loop as 64-bit VGPR pairs (and spilled)
-        const f16x8* wk = wgrp + (size_t)ks * T * 2 * 64;
-        asm volatile("" : "+s"(wk));
+        const f16x8* wk_ = wgrp + (size_t)ks * T * 2 * 64;
+        asm volatile("" : "+s"(wk_));
+        const GlobalFrags wk = (GlobalFrags)wk_;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
           const f16x8 ah = wk[(t * 2 + 0) * 64 + lane], al = wk[(t * 2 + 1) * 64 + lane];
@@ -241,6 +287,13 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
         __builtin_amdgcn_sched_barrier(0);
       }
 #endif
+    }
+    if constexpr (kFetchLate) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (has_next) fetch(tile + stride);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (active) {
       // ---- spline backward of this lane's two elements -> G in registers ------------------------------------------
       float gp[2][PP8];
 #pragma unroll
@@ -294,19 +347,45 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
               bl[b][kk][j] = pl;
             }
         }
-        const f16x8* wt = a.wtfrag + (size_t)grp * 4 * KK * 2 * 64;
-        asm volatile("" : "+s"(wt));
+        const f16x8* wt_ = a.wtfrag + (size_t)grp * 4 * KK * 2 * 64;
+        asm volatile("" : "+s"(wt_));
+        const GlobalFrags wt = (GlobalFrags)wt_;
+        // (role 0: the W^T fragment pairs through the same kind of ring as the forward fragments above)
+        constexpr int NW = 4 * KK, kWRing = kRole == 0 ? (NW < 6 ? NW : 6) : 1;
+        f16x8 wrh[kWRing], wrl[kWRing];
+        if constexpr (kRole == 0) {
+#pragma unroll
+          for (int i = 0; i < kWRing; ++i) {
+            wrh[i] = wt[((size_t)i * 2 + 0) * 64 + lane];
+            wrl[i] = wt[((size_t)i * 2 + 1) * 64 + lane];
+          }
+        }
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
           f32x4 o[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
           for (int kk = 0; kk < KK; ++kk) {
-            const f16x8 ah = wt[((size_t)(ht * KK + kk) * 2 + 0) * 64 + lane], al = wt[((size_t)(ht * KK + kk) * 2 + 1) * 64 + lane];
+            f16x8 ah, al;
+            if constexpr (kRole == 0) {
+              __builtin_amdgcn_sched_barrier(0);
+              ah = wrh[(ht * KK + kk) % kWRing];
+              al = wrl[(ht * KK + kk) % kWRing];
+            } else {
+              ah = wt[((size_t)(ht * KK + kk) * 2 + 0) * 64 + lane];
+              al = wt[((size_t)(ht * KK + kk) * 2 + 1) * 64 + lane];
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
               o[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[b][kk], o[b], 0, 0, 0);
               o[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[b][kk], o[b], 0, 0, 0);
               o[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[b][kk], o[b], 0, 0, 0);
+            }
+            if constexpr (kRole == 0) {
+              if (ht * KK + kk + kWRing < NW) {
+                wrh[(ht * KK + kk) % kWRing] = wt[((size_t)(ht * KK + kk + kWRing) * 2 + 0) * 64 + lane];
+                wrl[(ht * KK + kk) % kWRing] = wt[((size_t)(ht * KK + kk + kWRing) * 2 + 1) * 64 + lane];
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
 #pragma unroll
@@ -339,23 +418,20 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
         for (int i = 0; i < PP; ++i) {
           const float m = row16_allmax(fmaxf(fabsf(gp[0][i]), fabsf(gp[1][i])));
           const uint32_t e = (__float_as_uint(m) >> 23) & 255u;
-          const int shift = (e >= 11u && e < 255u) ? 137 - (int)e : fshift[i];
-          if (shift < fshift[i]) {
-            if (fshift[i] != 1000) {
-              const int dlt = shift - fshift[i];
+          const int sh8 = 8 * (i & 3);
+          uint32_t cur = (fsh[i >> 2] >> sh8) & 255u;                       // fshift + 128, 255 = nothing yet
+          const uint32_t want = (e >= 11u && e < 255u) ? 265u - e : cur;     // (137 - e) + 128, in [11, 254]
+          if (want < cur) {
+            if (cur != 255u) {
+              const int dlt = (int)want - (int)cur;
               const float resc = dlt < -126 ? 0.f : __uint_as_float((uint32_t)(127 + dlt) << 23);
 #pragma unroll
               for (int ht = 0; ht < 4; ++ht) dw[i >> 2][ht][i & 3] *= resc;
             }
-            fshift[i] = shift;
+            fsh[i >> 2] = (fsh[i >> 2] & ~(255u << sh8)) | (want << sh8);
+            cur = want;
           }
-          const float sc = fshift[i] == 1000 ? 1.f : __uint_as_float((uint32_t)(127 + fshift[i]) << 23);
-#ifdef FC_BWD_DEBUG   // tools/probe only (role 1 does not write gx): the scale decisions of every (tile, wave, dim, feature)
-          if (kRole == 1 && s16 == 0) {
-            a.gx[tile * R * D + (wave * 4 + g) * PP + i] = (float)fshift[i];
-            a.gx[tile * R * D + 768 + (wave * 4 + g) * PP + i] = m;
-          }
-#endif
+          const float sc = cur == 255u ? 1.f : __uint_as_float((cur - 1u) << 23);          // 2^(cur - 128)
           gp[0][i] *= sc;
           gp[1][i] *= sc;
         }
@@ -429,8 +505,8 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
       for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (4 * t + r < P && fshift[4 * t + r] != 1000) {
-            const float un = __uint_as_float((uint32_t)(127 - fshift[4 * t + r]) << 23);
+          if (4 * t + r < P && ((fsh[t] >> (8 * r)) & 255u) != 255u) {
+            const float un = __uint_as_float((255u - ((fsh[t] >> (8 * r)) & 255u)) << 23);      // 2^-(cur - 128)
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
               atomicAdd(a.gw + ((size_t)(grp * 4 + g) * PP + 4 * t + r) * H + 16 * ht + s16, dw[t][ht][r] * un);

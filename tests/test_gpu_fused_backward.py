@@ -211,3 +211,37 @@ def test_device_pack_equals_the_tensor_op_packers(k, tails, d_t, hidden, device)
     ref = ops.pack_resnet_hidden_backward(net)
     for got, want in zip(packed[:4], ref[:4]):
         assert torch.equal(got.reshape(-1), want.reshape(-1))
+
+
+def test_fused_linear_backward_repeated_fresh_batches(device):
+    """gW / gb / gh / gx at N = 4096 (one 32-row tile per workgroup on every CU) for eight independently drawn batches, fresh
+    tensors each time.  Regression test: with spilled fragment addresses the dw role returned, now and then, a wrong
+    [dim, widths] slice of gW for one tile (tools/probe/cold_launch_gw.py, tools/probe/fuzz_backward.py found it)."""
+    k, tails, d, d_t, n, hidden = 8, "linear", 64, 32, 4096, 64
+    p = 3 * k - 1
+    kw = dict(wh_divisor=float(hidden) ** 0.5)
+    cols = torch.arange(0, 2 * d_t, 2, dtype=torch.int32)
+    for trial in range(9):
+        torch.manual_seed(100 + trial)
+        if trial == 8:     # several tiles per workgroup, magnitudes growing along the batch: the per-feature scale of the gW
+            n = 3 * 256 * 32 + 64     # accumulators is lowered (and the accumulators rescaled) from tile to tile
+        x = torch.randn(n, d) * 1.5
+        h = torch.relu(torch.randn(n, hidden)) * 1.5 + torch.randn(n, hidden) * 0.2
+        if trial == 8:
+            h *= torch.logspace(-3, 0.5, n).unsqueeze(1)
+            x[:, ::2] *= torch.linspace(0.05, 1.0, n).unsqueeze(1)
+        w = torch.randn(d_t * p, hidden) * (1.0 / hidden ** 0.5)
+        b = torch.randn(d_t * p) * 0.3
+        gy, gl = torch.randn(n, d), torch.randn(n)
+        x64, h64, w64, b64 = (t.double().requires_grad_(True) for t in (x, h, w, b))
+        rows = (h64 @ w64.T + b64).view(n, d_t, p)
+        out, lad_e = O.rq_from_rows(x64[:, cols.long()], rows.clone(), k, tails, 3.0, False, **kw)
+        y64 = x64.clone().index_copy(1, cols.long(), out)
+        loss = (y64 * gy.double()).sum() + (lad_e.sum(dim=1) * gl.double()).sum()
+        gx_ref, gh_ref, gw_ref, gb_ref = torch.autograd.grad(loss, (x64, h64, w64, b64))
+        packed = ops.pack_final_layer_general(w.to(device), b.to(device), k, tails, 64)
+        packed_t = ops.pack_final_layer_transposed(w.to(device), k, tails)
+        gx, gh, gw, gb = ops.rq_fused_linear_backward(x.to(device), h.to(device), gy.to(device), gl.to(device), packed,
+                                                      packed_t, cols.to(device), num_bins=k, tails=tails, tail_bound=3.0, **kw)
+        assert _relerr(gw, gw_ref) <= 2e-4, trial
+        assert _relerr(gb, gb_ref) <= 2e-4 and _relerr(gh, gh_ref) <= 2e-4 and _relerr(gx, gx_ref) <= 2e-4, trial

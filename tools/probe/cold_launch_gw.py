@@ -1,4 +1,8 @@
-"""Which 32-row tile produces the wrong gW row?  (seed-0 case of repro_gw2.py)"""
+"""First launch of a fresh process: gW of fc_rq_fused_linear_backward (roles 0 + 1) at N = 4096 against float64 autograd, with the
+per-tile shares of a probe build when given (FC_BWD_PARTIALS).  Round 2 history: with the fragment addresses held as two dozen
+spilled 64-bit VGPR pointers, about every second cold launch produced a wrong [dim 4 w + 3, widths] slice for one tile
+(second wave of a SIMD, lane group 3); with scalar bases (no address spills) 0 of 44.  Run it several times, each in a new
+process:  for i in 1 2 3 4 5 6 7 8; do python tools/probe/cold_launch_gw.py [--k 10] [--lib tools/probe/build/libfc_ablN.so]; done"""
 import os, sys, torch
 sys.path[:0] = [os.getcwd()]
 from flowconductor_amd import ops, _hip
