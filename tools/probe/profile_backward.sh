@@ -20,3 +20,13 @@ with open("gpurun_out/r02d_bwd_role1_sq_counters.txt", "w") as o:
 PY
 grep -h Kernel_Name -m1 -A0 gpurun_out/pmc_fused_bwd_r02d/p1/*/*counter_collection.csv | head -1; cut -d, -f1-12 gpurun_out/pmc_fused_bwd_r02d/p1/*/*counter_collection.csv | grep -o 'rq_fused_backward_kernel[^(]*' | sort | uniq -c
 rm -rf gpurun_out/pmc_fused_bwd_r02d/p*
+OUT=$R/gpurun_out/prof_r02d
+mkdir -p $OUT
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- python3 $R/tools/probe/bench_train.py 19 --json > $OUT/train.json 2> $OUT/train.err
+echo "train trace exit $?"
+cd $R
+f=$(ls $OUT/trace_train/*/*kernel_stats.csv 2>/dev/null | head -1)
+[ -n "$f" ] && cp $f gpurun_out/r02d_train_kernel_stats.csv
+cp $OUT/train.json gpurun_out/r02d_train_under_rocprof.json
+rm -rf $OUT/trace_train
