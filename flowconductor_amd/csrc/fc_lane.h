@@ -10,15 +10,6 @@ namespace fc {
 // move, a DPP move, a canonicalising max and the max itself per step.  The s_nop 1 is the VALU-write -> DPP-read
 // hazard the compiler cannot see inside an asm block.)
 __device__ __forceinline__ float row16_allmax(float m) {
-#ifdef FC_DPP_BUILTIN
-#define FC_RORM(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x120 + (n), 0xf, 0xf, false))
-  m = fmaxf(m, FC_RORM(8));
-  m = fmaxf(m, FC_RORM(4));
-  m = fmaxf(m, FC_RORM(2));
-  m = fmaxf(m, FC_RORM(1));
-#undef FC_RORM
-  return m;
-#endif
   asm("s_nop 1\n\t"
       "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\t"

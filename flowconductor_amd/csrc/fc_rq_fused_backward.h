@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   const int s16 = lane & 15, g = lane >> 4;
   const int64_t stride = gridDim.x, tile0 = blockIdx.x;
   if (tile0 >= a.tiles) return;
-#ifdef FC_BWD_POISON   // tools/probe only: every LDS word starts as a NaN, so a read of a word nobody wrote shows in the result
+#ifdef FC_BWD_POISON   // tools/probe only (-DFC_BWD_POISON=0x7fc07fc0u): every LDS word starts as that pattern, so a read of a word nobody wrote shows
   {
     const int words = (int)(bwd_lds_bytes(D, kRole) / 4);
     for (int i = threadIdx.x; i < words; i += kGenThreads) reinterpret_cast<uint32_t*>(bsm)[i] = FC_BWD_POISON;
@@ -276,17 +276,6 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
           acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, acc[1][t], 0, 0, 0);
         }
       }
-#ifdef FC_BWD_DRAIN
-      {   // every accumulator chain ends in a VALU read here, before any later load may be given one of their registers
-        float drain = 0.f;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-          for (int t = 0; t < T; ++t) drain += acc[b][t][3];
-        asm volatile("" ::"v"(drain));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
     }
     if constexpr (kFetchLate) {
       __builtin_amdgcn_sched_barrier(0);
