@@ -123,7 +123,10 @@ for c in range(cases):
         assert gp[name] is not None, tag + (name, "missing gradient")
         sp = max(1e-6, float(ref.abs().max()))
         ep, fp = md(gp[name], ref), md(gp32[name], ref)
-        assert ep <= 3e-4 * sp + 8 * fp, tag + (name, ep, fp, sp)
-        ratio = max(ratio, ep / (3e-4 * sp + 8 * fp))
+        # a parameter gradient is a sum of n per-sample terms of O(|gy|) = O(1), each good to ~1e-7 relative in float32: where
+        # they cancel (sum-of-sigmoids shifts: |sum| ~ 0.05 from 1 333 terms) the absolute error of the sum does not shrink with it
+        bound = 3e-4 * sp + 8 * fp + 1e-7 * n
+        assert ep <= bound, tag + (name, ep, fp, sp)
+        ratio = max(ratio, ep / bound)
     worst[kind] = max(worst.get(kind, 0.0), ratio)
 print("fuzz ok: seed %d, %d cases; worst gradient error / bound per kind %s" % (seed, cases, {a: "%.2f" % b for a, b in worst.items()}))
