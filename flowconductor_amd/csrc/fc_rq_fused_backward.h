@@ -120,16 +120,18 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   const f16x8* const wgrp = a.wfrag + (size_t)grp * KS * T * 2 * 64;      // wave-uniform
 
   const int xvec = R * D / 4;
-  float4 hv, xv0, xv1, gv0, gv1;
+  float4 hv, xv0, gv0;
   float glv = 0.f;
-  hv = xv0 = xv1 = gv0 = gv1 = float4{0.f, 0.f, 0.f, 0.f};
+  hv = xv0 = gv0 = float4{0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int64_t t) __attribute__((always_inline)) {
     hv = reinterpret_cast<const float4*>(a.h + t * R * H)[tid];
     const float4* xg = reinterpret_cast<const float4*>(a.x + t * R * D);
     const float4* gg = reinterpret_cast<const float4*>(a.gy + t * R * D);
-    const int i0 = tid < xvec ? tid : 0, i1 = tid + kGenThreads < xvec ? tid + kGenThreads : 0;
-    xv0 = xg[i0]; xv1 = xg[i1];
-    gv0 = gg[i0]; gv1 = gg[i1];
+    // (one 16-byte piece of x and gy per thread rides in registers across the tile; a layer wider than 64 features has a second
+    //  piece per thread, which park() reads when it needs it: eight registers fewer for every other layer)
+    const int i0 = tid < xvec ? tid : 0;
+    xv0 = xg[i0];
+    gv0 = gg[i0];
     if (tid < R) glv = a.gl ? a.gl[t * R + tid] : 0.f;
   };
   auto slot = [&](float* base, int buf, int i) __attribute__((always_inline)) {
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
     const int e = i * 4, r = e / D, c = e - r * D;
     return reinterpret_cast<float4*>(base + buf * R * (D + 4) + r * XS + c);
   };
-  auto park = [&](int buf) __attribute__((always_inline)) {
+  auto park = [&](int buf, int64_t t) __attribute__((always_inline)) {
     {   // thread tid holds h[row tid / 16][4 (tid % 16) ..]: the 16 threads of a row are one DPP row
       const int r = tid >> 4, c = (tid & 15) * 4;
       const float v[4] = {hv.x, hv.y, hv.z, hv.w};
@@ -170,8 +172,8 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
       *slot(gbuf, buf, tid) = gv0;
     }
     if (tid + kGenThreads < xvec) {
-      *slot(xbuf, buf, tid + kGenThreads) = xv1;
-      *slot(gbuf, buf, tid + kGenThreads) = gv1;
+      *slot(xbuf, buf, tid + kGenThreads) = reinterpret_cast<const float4*>(a.x + t * R * D)[tid + kGenThreads];
+      *slot(gbuf, buf, tid + kGenThreads) = reinterpret_cast<const float4*>(a.gy + t * R * D)[tid + kGenThreads];
     }
     if (tid < R) glb[buf * R + tid] = glv;
   };
@@ -202,17 +204,17 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   }
 
   fetch(tile0);
-  park(0);
+  park(0, tile0);
   __syncthreads();
   int buf = 0;
   for (int64_t tile = tile0; tile < a.tiles; tile += stride) {
     const bool has_next = tile + stride < a.tiles;
     // vmcnt retires in order: rows requested ahead of the fragment loads make the first product wait out an HBM round trip
     // instead of an L2 one, so role 0 (which has the registers) asks for them after its recompute; roles 1 and 2 ask first
-    constexpr bool kFetchLate = kRole == 0 && T <= 6;      // (wider layers: the late request costs spills)
+    constexpr bool kFetchLate = kRole == 0;
     if (!kFetchLate && has_next) fetch(tile + stride);
-    f32x4 acc[2][T];
     if (active) {
+      f32x4 acc[2][T];
       // ---- recompute the parameters of both blocks against each weight fragment (the forward kernel's product: one
       // pass over the wave's 24 KB of fragments per tile -- they stream from L2, whose bandwidth bounds this kernel when
       // every block fetches them again) -----------------------------------------------------------------------------
@@ -276,13 +278,11 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
           acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, acc[1][t], 0, 0, 0);
         }
       }
-    }
-    if constexpr (kFetchLate) {
-      __builtin_amdgcn_sched_barrier(0);
-      if (has_next) fetch(tile + stride);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (active) {
+      if constexpr (kFetchLate) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) fetch(tile + stride);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // ---- spline backward of this lane's two elements -> G in registers ------------------------------------------
       float gp[2][PP8];
 #pragma unroll
@@ -450,8 +450,10 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
           }
         }
       }
+    } else if constexpr (kFetchLate) {
+      if (has_next) fetch(tile + stride);       // (waves without spline work still carry their share of the next tile)
     }
-    if (has_next) park(buf ^ 1);
+    if (has_next) park(buf ^ 1, tile + stride);
     __syncthreads();
     if constexpr (kMerged) {
       float4* og = reinterpret_cast<float4*>(a.gx + tile * R * D);
