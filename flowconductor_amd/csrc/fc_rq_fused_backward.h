@@ -210,8 +210,8 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   for (int64_t tile = tile0; tile < a.tiles; tile += stride) {
     const bool has_next = tile + stride < a.tiles;
     // vmcnt retires in order: rows requested ahead of the fragment loads make the first product wait out an HBM round trip
-    // instead of an L2 one, so role 0 (which has the registers) asks for them after its recompute; roles 1 and 2 ask first
-    constexpr bool kFetchLate = kRole == 0;
+    // instead of an L2 one, so the roles that have the registers ask for them after their recompute (role 0; role 1 up to K = 8)
+    constexpr bool kFetchLate = kRole == 0 || (kRole == 1 && T <= 6);
     if (!kFetchLate && has_next) fetch(tile + stride);
     if (active) {
       f32x4 acc[2][T];
