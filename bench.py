@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="rehearsal only: set up the process group, the C-ABI reducer and every collective of the N>1 "
                          "path although WORLD_SIZE is 1 (one-GPU box: RCCL with a single rank)")
+    ap.add_argument("--comm-timeout", type=float, default=120.0,
+                    help="deadline in seconds for the RCCL bootstrap of the C-ABI reducer (then: torch.distributed path)")
     ap.add_argument("--share-device0", action="store_true",
                     help="rehearsal only: every rank on the single GPU of the box (with --dist-backend gloo)")
     args = ap.parse_args()
@@ -269,40 +271,19 @@ def main():
     chunk = (1 << args.chunk_log2) if args.chunk_log2 else None
 
     # the path's one collective: {sum log_prob, count}, 16 bytes, through the C ABI (RCCL) when the job runs on RCCL
-    reducer, reducer_note = None, "none (1 rank)"
+    reducer, reducer_note, stuck_helper = None, "none (1 rank)", False
     if collective:
         reducer_note = "torch.distributed.all_reduce (%s)" % args.dist_backend
-        if args.loglik_allreduce == "abi" and args.dist_backend == "nccl":
-            ok = torch.ones(1, device=device)
-            # Built on a helper thread with a deadline: a communicator that cannot be set up must cost this run its ABI
-            # collective, not its result (the native call cannot be interrupted; a stuck helper is left behind as a daemon).
-            import threading
-            box = {}
-
-            def build():
-                try:
-                    box["reducer"] = parallel.LoglikAllReduce(device, dist.group.WORLD)
-                except Exception as e:    # noqa: BLE001 -- any failure means "use the torch.distributed path"
-                    box["error"] = e
-
-            helper = threading.Thread(target=build, daemon=True)
-            helper.start()
-            helper.join(timeout=120.0)
-            if helper.is_alive():
-                box["error"] = TimeoutError("fc_comm_init_rank did not return within 120 s")
-            reducer = box.get("reducer") if "error" not in box else None
-            if reducer is None:           # all ranks must take the same path: agree below
-                e = box.get("error")
-                log("rank %d: fc_allreduce_loglik unavailable (%s: %s)" % (rank, type(e).__name__, e))
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if float(ok.item()) == 1.0:
+        if args.loglik_allreduce == "abi" and (args.dist_backend == "nccl" or args.share_device0):
+            # Collective set-up on THIS thread (it owns the device); only the blocking RCCL bootstrap inside runs under a
+            # deadline.  Either every rank gets a reducer or every rank gets CollectiveSetupFailed (they agree inside).
+            try:
+                reducer = parallel.LoglikAllReduce(device, dist.group.WORLD, init_timeout_s=args.comm_timeout)
                 reducer_note = "fc_allreduce_loglik (RCCL ncclAllReduce through the C ABI, %d ranks)" % world
-            else:
-                if reducer is not None:
-                    reducer.close()
-                reducer = None
-                reducer_note += " [fc_allreduce_loglik failed to initialise on some rank]"
+            except parallel.CollectiveSetupFailed as e:
+                log("rank %d: fc_allreduce_loglik unavailable (%s)" % (rank, e))
+                stuck_helper = stuck_helper or e.stuck_helper
+                reducer_note += " [fc_allreduce_loglik failed to initialise on some rank: %s]" % e
 
     def step():
         with torch.no_grad():
@@ -398,6 +379,9 @@ def main():
             "rccl_ranks": world if (collective and args.dist_backend == "nccl") else 0,
             "loglik_allreduce": reducer_note,
             "per_rank": per_rank,
+            "rank_skew": {"max_ms_per_step": max(r["ms_per_step"] for r in per_rank),
+                          "min_ms_per_step": min(r["ms_per_step"] for r in per_rank),
+                          "max_over_min": max(r["ms_per_step"] for r in per_rank) / min(r["ms_per_step"] for r in per_rank)},
             "library": _hip.library_info(),
             "options": options.snapshot(),
         }
@@ -496,6 +480,12 @@ def main():
     if reducer is not None:
         reducer.close()
     if dist is not None:
+        if stuck_helper:
+            # a thread of this process is still parked inside ncclCommInitRank: do not run RCCL / interpreter tear-down
+            # around it; the line above is out, leave at once
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -128,7 +128,9 @@ SIGNATURES = {
     "fc_pack_job_bytes": [],
     "fc_comm_unique_id": [_P],
     "fc_comm_init_rank": [ctypes.POINTER(ctypes.c_void_p), _I32, _P, _I32],
+    "fc_comm_init_rank_on_device": [ctypes.POINTER(ctypes.c_void_p), _I32, _P, _I32, _I32],
     "fc_comm_destroy": [_P],
+    "fc_comm_abort": [_P],
     "fc_allreduce_loglik": [_P, _P, _P],
 }
 

@@ -23,6 +23,7 @@ struct Rccl {
   decltype(&ncclCommInitRank) comm_init_rank = nullptr;
   decltype(&ncclAllReduce) all_reduce = nullptr;
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclCommAbort) comm_abort = nullptr;
   decltype(&ncclCommCount) comm_count = nullptr;
   bool ok = false;
 };
@@ -44,6 +45,7 @@ static const Rccl& rccl() {
     r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
     r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(h, "ncclAllReduce"));
     r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    r.comm_abort = reinterpret_cast<decltype(r.comm_abort)>(dlsym(h, "ncclCommAbort"));
     r.comm_count = reinterpret_cast<decltype(r.comm_count)>(dlsym(h, "ncclCommCount"));
     r.ok = r.get_unique_id && r.comm_init_rank && r.all_reduce && r.comm_destroy;
   });
@@ -76,6 +78,25 @@ extern "C" int fc_comm_init_rank(void** comm_out, int32_t nranks, const void* id
   const ncclResult_t e = r.comm_init_rank(&comm, nranks, id, rank);   // binds the CURRENT device
   *comm_out = e == ncclSuccess ? static_cast<void*>(comm) : nullptr;
   return fc::rc(e);
+}
+
+extern "C" int fc_comm_init_rank_on_device(void** comm_out, int32_t nranks, const void* id128, int32_t rank, int32_t device) {
+  // The current device is per host THREAD: a caller that sets up the communicator off its main thread (a deadline
+  // around this blocking collective) would otherwise bind device 0 on every rank.
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess) return e;
+  if (device < 0 || device >= count) return hipErrorInvalidDevice;
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return e;
+  return fc_comm_init_rank(comm_out, nranks, id128, rank);
+}
+
+extern "C" int fc_comm_abort(void* comm) {
+  const fc::Rccl& r = fc::rccl();
+  if (!r.ok || !r.comm_abort) return hipErrorNotSupported;
+  if (!comm) return 0;
+  return fc::rc(r.comm_abort(static_cast<ncclComm_t>(comm)));
 }
 
 extern "C" int fc_comm_destroy(void* comm) {

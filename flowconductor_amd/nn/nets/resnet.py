@@ -10,6 +10,8 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from flowconductor_amd import ops
+
 
 class ResidualBlock(nn.Module):
     """pre-activation block: x + W1 drop(act(bn(W0 act(bn(x))))) with an optional GLU gate on context."""
@@ -44,7 +46,7 @@ class ResidualBlock(nn.Module):
         return inputs + h
 
 
-class ResidualNet(nn.Module):
+class ResidualNet(ops.RuntimeCaches, nn.Module):
     """Linear -> num_blocks x ResidualBlock -> Linear, for 1-dim feature vectors."""
 
     def __init__(self, in_features, out_features, hidden_features, context_features=None,
@@ -197,13 +199,15 @@ class ResidualNet(nn.Module):
 
     def _param_list(self):
         """``tuple(self.parameters())`` kept on the module (walking the module tree on every call was a third of the
-        per-layer host time); dropped by ``_apply`` (.to / .cuda / .float) and rebuilt when the cache epoch moves."""
-        from flowconductor_amd import ops
-
+        per-layer host time) together with WHERE each one hangs: the memo is valid only while every slot still holds
+        the same Parameter object (``lin.weight = nn.Parameter(...)``, ``load_state_dict(assign=True)`` and late
+        parametrizations replace objects without touching versions or pointers of the orphans); also dropped by
+        ``_apply`` (.to / .cuda / .float) and when the cache epoch moves."""
         memo = self.__dict__.get("_fc_param_list")
         epoch = ops.cache_key()[0]
-        if memo is None or memo[0] != epoch:
-            memo = self.__dict__["_fc_param_list"] = (epoch, tuple(self.parameters()))
+        if memo is None or memo[0] != epoch or not all(m._parameters.get(n) is p for m, n, p in memo[2]):
+            slots = tuple((m, n, p) for m in self.modules() for n, p in m._parameters.items() if p is not None)
+            memo = self.__dict__["_fc_param_list"] = (epoch, tuple(self.parameters()), slots)
         return memo[1]
 
     def _apply(self, fn, *args, **kwargs):

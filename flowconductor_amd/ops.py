@@ -172,6 +172,29 @@ def cache_key(*tensors, extra=()):
     return tuple((t._version, t.data_ptr(), t.device) for t in tensors) + (_cache_epoch,) + tuple(extra)
 
 
+# Attributes in which this package's modules keep run-time state derived from their parameters (kernel-layout weight
+# images, DevicePack plans with raw device pointers, index tensors, memo lists).  None of it is model state: it is
+# rebuilt on demand and must not travel with ``copy.deepcopy`` / ``pickle`` / ``torch.save(module)``.
+RUNTIME_CACHE_ATTRS = frozenset((
+    "_hip_packed", "_hip_packed_wide", "_hip_packed_bwd", "_hip_image", "_final_padded", "_tail_image", "_train_pack",
+    "_packed", "_masked_final", "_mm_cache", "_dense_cache", "_sp_cache", "_all_cols", "_ctx_cols", "_cols_cache",
+    "_id_cols_cache", "_fc_param_list", "_fc_module_list"))
+
+
+class RuntimeCaches:
+    """Mixin (before ``nn.Module`` in the bases): ``copy.deepcopy``, ``pickle`` and ``torch.save`` of the module see the
+    run-time caches of ``RUNTIME_CACHE_ATTRS`` as ``None`` -- a copy starts cold and re-packs from ITS OWN parameters; a
+    checkpoint of the whole module holds parameters and buffers only (``fc_pack_job`` structs carry raw device
+    pointers and cannot be pickled at all)."""
+
+    def __getstate__(self):
+        state = dict(super().__getstate__())
+        for name in RUNTIME_CACHE_ATTRS:
+            if state.get(name) is not None:
+                state[name] = None
+        return state
+
+
 def has_hooks(module):
     """True when ``module`` or a sub-module carries forward (pre-)hooks (old-style weight_norm refreshes ``weight``
     in one): the fast paths read the weights directly and never go through ``__call__``, so they step aside.
@@ -522,6 +545,7 @@ class DevicePack:
         self.sources = []         # the parameters the jobs read (their versions say when a refresh is due)
         self._jobs_dev = None
         self._root = None         # the pack this one was merged into
+        self.children = []        # packs merged into this one (they keep their own jobs)
         self._key = None
         self.prepare = []         # callables run before every launch (staging copies the jobs read from)
 
@@ -547,21 +571,37 @@ class DevicePack:
             node = node._root
         return node
 
+    def _invalidate(self):
+        self._jobs_dev = self._key = None
+
+    def _walk(self):
+        yield self
+        for child in self.children:
+            yield from child._walk()
+
     def merge(self, other):
-        """Take over ``other``'s jobs: one launch then refreshes both (a coupling layer's final-layer and hidden-stack
-        images change together, once per optimizer step)."""
-        mine, theirs = self.root(), other.root()
-        if mine is theirs:
+        """Adopt ``other``: one launch then refreshes both (a coupling layer's final-layer and hidden-stack images change
+        together, once per optimizer step).  Non-destructive: ``other`` keeps its jobs and can be re-parented later (its
+        previous parent lets go of it), so a rebuilt parent never inherits jobs whose sources are gone."""
+        mine = self.root()
+        if other is mine or other._root is mine:
             return
-        if theirs.device != mine.device:
+        if other.device != mine.device:
             raise ValueError("DevicePack.merge: packs live on different devices")
-        mine.jobs += theirs.jobs
-        mine.keep += theirs.keep
-        mine.sources += theirs.sources
-        mine.prepare += theirs.prepare
-        mine._jobs_dev = mine._key = None
-        theirs.jobs, theirs.keep, theirs.sources, theirs._jobs_dev, theirs.prepare = [], [], [], None, []
-        theirs._root = mine
+        if any(node is other for node in mine._walk()) or any(node is mine for node in other._walk()):
+            return
+        if other._root is not None:
+            other._root.children = [c for c in other._root.children if c is not other]
+            other._root.root()._invalidate()
+        other._root = mine
+        mine.children.append(other)
+        mine._invalidate()
+
+    def all_jobs(self):
+        return [job for node in self._walk() for job in node.jobs]
+
+    def all_sources(self):
+        return [t for node in self._walk() for t in node.sources]
 
     def run(self):
         pack = self.root()
@@ -569,18 +609,20 @@ class DevicePack:
         if pack._jobs_dev is None:
             if lib.fc_pack_job_bytes() != ctypes.sizeof(_hip.PackJob):
                 raise RuntimeError("fc_pack_job layout mismatch between the header and the ctypes mirror")
-            raw = b"".join(bytes(j) for j in pack.jobs)
-            pack._jobs_dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(pack.device)
-        for fn in pack.prepare:
-            fn()
-        _call("fc_pack_fragments", lib.fc_pack_fragments, pack.device, _hip.ptr(pack._jobs_dev), len(pack.jobs),
+            jobs = pack.all_jobs()
+            raw = b"".join(bytes(j) for j in jobs)
+            pack._jobs_dev = (torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(pack.device), len(jobs))
+        for node in pack._walk():
+            for fn in node.prepare:
+                fn()
+        _call("fc_pack_fragments", lib.fc_pack_fragments, pack.device, _hip.ptr(pack._jobs_dev[0]), pack._jobs_dev[1],
               _hip.stream_ptr(pack.device))
 
     def refresh(self):
         """``run()`` if any source parameter changed since the last refresh (``cache_key``: versions + cache epoch)."""
         pack = self.root()
         seen, srcs = set(), []
-        for t in pack.sources:
+        for t in pack.all_sources():
             if id(t) not in seen:
                 seen.add(id(t))
                 srcs.append(t)

@@ -32,38 +32,112 @@ def rank_plan(rank, world, local_rank, scaling="weak", rows_per_gpu=1 << 20, tot
             "row_lo": lo, "row_hi": hi, "n_local": hi - lo, "scaling": scaling}
 
 
+class CollectiveSetupFailed(RuntimeError):
+    """``LoglikAllReduce`` could not be built on SOME rank; raised on EVERY rank of the group (they agree first), so the
+    callers all take the same fall-back.  ``stuck_helper`` is true on a rank whose ``fc_comm_init_rank`` never returned:
+    that process still has a thread parked inside RCCL and should leave through ``os._exit`` when it is done."""
+
+    def __init__(self, message, stuck_helper=False):
+        super().__init__(message)
+        self.stuck_helper = stuck_helper
+
+
 class LoglikAllReduce:
     """The path's one collective through the C ABI: ``fc_allreduce_loglik`` (RCCL ``ncclAllReduce`` of two float64 on
-    the compute stream).  Built collectively by all ranks; the 128-byte RCCL unique id travels over the existing
-    ``torch.distributed`` process group (any backend -- it is host data).
+    the compute stream).  Built collectively by all ranks of ``group``:
 
-        reducer = LoglikAllReduce(device, group)          # every rank
-        total, count = reducer(log_prob)                   # per evaluation; returns Python floats
+        reducer = LoglikAllReduce(device, group)          # every rank; raises CollectiveSetupFailed on every rank or none
+        total, count = reducer(log_prob)                   # per evaluation; returns Python floats (one host sync)
+        stats = reducer.reduce_async(log_prob)             # device tensor {sum, count}, no host sync (training loops)
+
+    Set-up protocol (every ``torch.distributed`` call is issued by the CALLING thread inside ``torch.cuda.device(device)``:
+    the current device is thread-local, and a NCCL group bound with ``device_id`` refuses tensors of another device):
+      1. each rank loads the library, rank 0 draws the 128-byte RCCL id; MIN all-reduce of "ok so far" -- a rank that
+         cannot even load RCCL stops everybody HERE, before anyone enters the blocking collective of step 3;
+      2. the id travels as a uint8 tensor broadcast (on ``device`` for nccl groups, on the CPU for gloo);
+      3. ``fc_comm_init_rank_on_device`` (``ncclCommInitRank``, blocking, cannot be interrupted) runs on a helper thread
+         under a deadline; the ABI entry sets the device itself, the helper touches nothing of ``torch.distributed``;
+      4. MIN all-reduce of the outcome; on failure the ranks that did get a communicator abort it.
     """
 
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, init_timeout_s=120.0):
+        import threading
+
         import torch.distributed as dist
 
         from flowconductor_amd import _hip
 
-        self._lib = _hip.load()
         self.device = torch.device(device)
-        self.world = dist.get_world_size(group) if group is not None or dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        if self.device.type != "cuda":
+            raise ValueError("LoglikAllReduce needs a HIP device, got %s" % (self.device,))
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self._comm = None
+        distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if distributed else 1
+        self.rank = dist.get_rank(group) if distributed else 0
+        on_device = distributed and dist.get_backend(group) == "nccl"
+        flag_device = self.device if on_device else torch.device("cpu")
+
+        def agree(ok):
+            """MIN over the ranks of a local success flag (main thread, device context)."""
+            if not distributed or self.world == 1:
+                return bool(ok)
+            flag = torch.tensor([1.0 if ok else 0.0], device=flag_device)
+            with torch.cuda.device(self.device):
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return float(flag.item()) == 1.0
+
+        # 1. local, no collective
+        error = None
         ident = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            _hip.check(self._lib.fc_comm_unique_id(ident), "fc_comm_unique_id")
-        payload = [ident.raw]
-        if self.world > 1:
-            dist.broadcast_object_list(payload, src=0, group=group)
-        comm = ctypes.c_void_p()
-        with torch.cuda.device(self.device):       # ncclCommInitRank binds the current device
-            _hip.check(self._lib.fc_comm_init_rank(ctypes.byref(comm), self.world, payload[0], self.rank),
-                       "fc_comm_init_rank")
-        self._comm = comm
+        try:
+            self._lib = _hip.load()
+            if self.rank == 0:
+                _hip.check(self._lib.fc_comm_unique_id(ident), "fc_comm_unique_id")
+        except Exception as e:      # noqa: BLE001 -- reported through the agreement below
+            error = e
+        if not agree(error is None):
+            raise CollectiveSetupFailed("fc_comm_unique_id / library load failed on some rank (this rank: %r)" % (error,))
+        # 2. the id, as a tensor broadcast on the calling thread
+        if distributed and self.world > 1:
+            wire = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).to(flag_device)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            with torch.cuda.device(self.device):
+                dist.broadcast(wire, src=src, group=group)
+            ident = ctypes.create_string_buffer(bytes(wire.cpu().tolist()), 128)
+        # 3. the blocking RCCL bootstrap, under a deadline
+        box = {}
+        lib, world, rank, index = self._lib, self.world, self.rank, self.device.index
+
+        def bootstrap():
+            comm = ctypes.c_void_p()
+            try:
+                _hip.check(lib.fc_comm_init_rank_on_device(ctypes.byref(comm), world, ident, rank, index),
+                           "fc_comm_init_rank_on_device")
+                box["comm"] = comm
+            except Exception as e:  # noqa: BLE001
+                box["error"] = e
+
+        helper = threading.Thread(target=bootstrap, daemon=True, name="fc_comm_init_rank")
+        helper.start()
+        helper.join(timeout=init_timeout_s)
+        stuck = helper.is_alive()
+        if stuck:
+            box["error"] = TimeoutError("fc_comm_init_rank_on_device did not return within %g s" % init_timeout_s)
+        # 4. agree on the outcome
+        if not agree("comm" in box and "error" not in box):
+            if "comm" in box and not stuck:
+                self._lib.fc_comm_abort(box["comm"])
+            raise CollectiveSetupFailed("fc_comm_init_rank failed on some rank (this rank: %r)" % (box.get("error"),),
+                                        stuck_helper=stuck)
+        self._comm = box["comm"]
         self._stats = torch.zeros(2, dtype=torch.float64, device=self.device)
 
-    def __call__(self, log_prob):
+    def reduce_async(self, log_prob):
+        """{sum log_prob, count} over all ranks as a float64 DEVICE tensor of two elements, enqueued on the current
+        stream of the device; no host synchronisation.  The tensor is this object's own buffer: read it (or copy it)
+        before the next call."""
         from flowconductor_amd import _hip
 
         stats = self._stats
@@ -72,7 +146,10 @@ class LoglikAllReduce:
         with torch.cuda.device(self.device):
             _hip.check(self._lib.fc_allreduce_loglik(ctypes.c_void_p(stats.data_ptr()), self._comm,
                                                      _hip.stream_ptr(self.device)), "fc_allreduce_loglik")
-        total, count = stats.tolist()
+        return stats
+
+    def __call__(self, log_prob):
+        total, count = self.reduce_async(log_prob).tolist()
         return total, count
 
     def close(self):
@@ -98,6 +175,8 @@ def local_log_prob(log_prob_fn, inputs, context=None, chunk=None):
     """Per-sample log_prob of this rank's rows, optionally in row chunks (bounds the
     ``[chunk, d_t*(3K-1)]`` conditioner-output buffer that each layer materialises)."""
     n = inputs.shape[0]
+    if n == 0:      # an empty shard (fewer rows than ranks): contributes {0, 0}; the reference cannot evaluate 0 rows either
+        return inputs.new_zeros(0)
     if chunk is None or chunk >= n:
         return log_prob_fn(inputs) if context is None else log_prob_fn(inputs, context)
     parts = []

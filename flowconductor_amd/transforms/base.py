@@ -31,7 +31,7 @@ def own_autograd_check(fn):
     return fn
 
 
-class Transform(nn.Module):
+class Transform(ops.RuntimeCaches, nn.Module):
     """Base class for all transform objects."""
 
     # True for transforms whose HIP kernels sit behind torch.autograd (or that only delegate to children); every

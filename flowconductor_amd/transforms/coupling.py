@@ -412,9 +412,14 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
     def _train_chunks(self, device):
         """Training: forward + W^T fragments of the final Linear for every group of <= 32 dims, re-packed on the device
         in one launch whenever the weights changed -- [(w_frag, w_unscale, bias_pad, wt_frag, cols, row slice)]."""
-        lin = self.transform_net.final_layer
+        net = self.transform_net
+        lin = net.final_layer
+        hidden_pack = None
+        if getattr(net, "hip_hidden_backward_supported", None) is not None and net.hip_hidden_backward_supported():
+            hidden_pack = net.hidden_backward_plan()[1]        # rebuilt by the net when ITS storages moved
+        where = (lin.weight.data_ptr(), lin.bias.data_ptr(), device)
         plan = getattr(self, "_train_pack", None)
-        if plan is None or plan[0] is not lin.weight or plan[0].device != device or plan[1] != lin.weight.data_ptr():
+        if plan is None or plan[0] is not lin.weight or plan[1] != where or plan[4] is not hidden_pack:
             per_dim = self._transform_dim_multiplier()
             cols = self._cols(device)
             spec = []
@@ -423,10 +428,9 @@ class PiecewiseRationalQuadraticCouplingTransform(PiecewiseCouplingTransform):
                 spec.append((slice(lo * per_dim, hi * per_dim), cols[lo:hi].contiguous()))
             pack, chunks = ops.device_pack_final_layer(lin.weight.detach(), lin.bias.detach(), self.num_bins, self.tails,
                                                        spec)
-            net = self.transform_net
-            if getattr(net, "hip_hidden_backward_supported", None) is not None and net.hip_hidden_backward_supported():
-                pack.merge(net.hidden_backward_plan()[1])      # the hidden stack's images ride in the same launch
-            plan = self._train_pack = [lin.weight, lin.weight.data_ptr(), pack, chunks]
+            if hidden_pack is not None:
+                pack.merge(hidden_pack)      # the hidden stack's images ride in the same launch
+            plan = self._train_pack = [lin.weight, where, pack, chunks, hidden_pack]
         plan[2].refresh()
         return plan[3]
 
@@ -584,15 +588,19 @@ class _FusedRQCouplingFunction(torch.autograd.Function):
                     rows, lad = ops.rq_spline_fused_general(rows, hidden, w_frag, w_un, bias_pad, cols,
                                                             tails=layer.tails, logabsdet_accum=lad, inverse=False, **kw)
         ctx.layer, ctx.n = layer, n
-        ctx.save_for_backward(x, hidden)
+        # The backward re-packs and reads the LIVE weights (they are not copied): saving the parameters makes autograd's
+        # version check refuse a backward after an optimizer step / in-place edit between forward and backward, exactly
+        # as it would for the plain torch graph ("modified by an inplace operation").
+        ctx.save_for_backward(x, hidden, *net_params)
         ctx.param_ids = [id(p) for p in net_params]
         return rows[:n], lad[:n]
 
     @staticmethod
+    @torch.autograd.function.once_differentiable      # no double backward: create_graph=True raises instead of going silent
     def backward(ctx, grad_outputs, grad_logabsdet):
         layer, n = ctx.layer, ctx.n
         net = layer.transform_net
-        x, hidden = ctx.saved_tensors
+        x, hidden = ctx.saved_tensors[:2]
         rows_total = x.shape[0]
         gy = torch.zeros_like(x) if grad_outputs is None else grad_outputs
         gl = grad_logabsdet

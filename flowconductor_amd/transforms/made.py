@@ -8,6 +8,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from flowconductor_amd import ops
 from flowconductor_amd.utils import torchutils
 
 
@@ -117,7 +118,7 @@ class MaskedResidualBlock(nn.Module):
         return inputs + h
 
 
-class MADE(nn.Module):
+class MADE(ops.RuntimeCaches, nn.Module):
     """Masked autoencoder: masked initial layer, ``num_blocks`` masked blocks, masked output layer
     producing ``output_multiplier`` values per input feature (feature-major)."""
 

@@ -471,11 +471,16 @@ int fc_pack_job_bytes(void);
  *   fc_comm_init_rank   collective over all ranks; binds the calling thread's CURRENT device to `rank`
  *   fc_allreduce_loglik sum_count: DEVICE pointer to two float64 {sum, count}, reduced in place (sum) across the
  *                       ranks of `comm`, asynchronous on `stream` (ncclAllReduce, RCCL over xGMI)
- *   fc_comm_destroy     releases the communicator */
+ *   fc_comm_init_rank_on_device  the same after hipSetDevice(device) in the calling thread (the current device is per
+ *                       host thread: use this one when the set-up runs off the thread that owns the device)
+ *   fc_comm_destroy     releases the communicator (collective: every rank's outstanding work must have finished)
+ *   fc_comm_abort       tears a communicator down without waiting for the other ranks (failed set-up on a peer) */
 #define FC_COMM_UNIQUE_ID_BYTES 128
 int fc_comm_unique_id(void* id_out128);
 int fc_comm_init_rank(void** comm_out, int32_t nranks, const void* id128, int32_t rank);
+int fc_comm_init_rank_on_device(void** comm_out, int32_t nranks, const void* id128, int32_t rank, int32_t device);
 int fc_comm_destroy(void* comm);
+int fc_comm_abort(void* comm);
 int fc_allreduce_loglik(double* sum_count, void* comm, void* stream);
 
 #ifdef __cplusplus

@@ -368,7 +368,7 @@ def test_device_pack_merge_and_refresh_launch_once_per_weight_version(monkeypatc
     from flowconductor_amd import ops
 
     launches = []
-    monkeypatch.setattr(ops.DevicePack, "run", lambda self: launches.append(len(self.root().jobs)))
+    monkeypatch.setattr(ops.DevicePack, "run", lambda self: launches.append(len(self.root().all_jobs())))
     w1, b1 = torch.nn.Parameter(torch.randn(8, 4)), torch.nn.Parameter(torch.randn(8))
     w2 = torch.nn.Parameter(torch.randn(4, 4))
     out = torch.empty(64, dtype=torch.float16)
@@ -380,7 +380,7 @@ def test_device_pack_merge_and_refresh_launch_once_per_weight_version(monkeypatc
     b.add(ops.PACK_HIDDEN, stage, None, out, un[1:], nks=1, nt=1, track=False)
     b.prepare.append(lambda: stage.copy_(w2.detach()))
     a.merge(b)
-    assert b.root() is a and len(a.jobs) == 3 and len(a.prepare) == 1
+    assert b.root() is a and len(a.all_jobs()) == 3 and len(b.jobs) == 2 and len(b.prepare) == 1
     a.refresh()
     b.refresh()                      # same versions: the merged pack has run already
     assert launches == [3]
@@ -394,6 +394,16 @@ def test_device_pack_merge_and_refresh_launch_once_per_weight_version(monkeypatc
     ops.invalidate_hip_caches()      # .data surgery: the caller bumps the epoch
     a.refresh()
     assert launches == [3, 3, 3]
+    # a REBUILT parent (the final layer's storage moved) adopts the live child; the old parent lets go of it and keeps
+    # only its own -- now stale -- jobs to itself: nothing that is launched again points into freed storage
+    a2 = ops.DevicePack(torch.device("cpu"))
+    a2.add(ops.PACK_HIDDEN, torch.nn.Parameter(torch.randn(8, 4)), None, out, un[:1], nks=1, nt=1)
+    a2.merge(b)
+    assert b.root() is a2 and len(a2.all_jobs()) == 3 and len(a.all_jobs()) == 1 and a.children == []
+    a2.merge(b)                      # idempotent
+    assert len(a2.all_jobs()) == 3
+    b.refresh()
+    assert launches == [3, 3, 3, 3]
 
 
 def test_has_hooks_sees_hooks_added_after_the_module_list_was_memoised():
@@ -418,3 +428,57 @@ def test_affine_tail_lds_budget():
     assert not ops.affine_tail_fits(16, 4, 32)        # four blocks + the final layer: the image alone is too large
     assert not ops.affine_tail_fits(16, 2, 200)       # row tiles of D > 128
     assert not ops.affine_tail_fits(64, 3, 128)
+
+
+def test_runtime_caches_do_not_travel_with_deepcopy_or_pickle():
+    """Packed-weight plans (fc_pack_job structs with raw device pointers, closures) live on the modules; a deep copy /
+    pickle / torch.save of a module that has run must succeed and start cold (EMA snapshots, whole-module
+    checkpoints -- the reference supports both)."""
+    import copy
+    import io
+    import pickle
+
+    from flowconductor_amd import _hip
+
+    t = T.PiecewiseRationalQuadraticCouplingTransform(utils.create_alternating_binary_mask(8), _net, num_bins=4)
+    pack = ops.DevicePack(torch.device("cpu"))
+    pack.prepare.append(lambda: None)                  # a local closure, as the real plans hold
+    t._train_pack = [t.transform_net.final_layer.weight, 0, pack, []]
+    t._tail_image = [0, pack, (torch.zeros(3),)]
+    t.transform_net._hip_image = [0, _hip.PackJob(), (torch.zeros(3),)]
+    t.transform_net._hip_packed = ((1, 2), torch.zeros(5))
+    for name in ("_train_pack", "_tail_image"):
+        assert name in ops.RUNTIME_CACHE_ATTRS
+    with pytest.raises(Exception):
+        pickle.dumps(t._train_pack)                    # what used to break deepcopy of the whole module
+    t2 = copy.deepcopy(t)
+    assert t2._train_pack is None and t2._tail_image is None
+    assert t2.transform_net._hip_image is None and t2.transform_net._hip_packed is None
+    assert t._train_pack is not None and t.transform_net._hip_image is not None    # the original keeps its plans
+    assert t2.transform_net.final_layer.weight.data_ptr() != t.transform_net.final_layer.weight.data_ptr()
+    buf = io.BytesIO()
+    torch.save(t, buf)
+    buf.seek(0)
+    t3 = torch.load(buf, weights_only=False)
+    assert t3._train_pack is None and t3.transform_net._hip_image is None
+    assert all(torch.equal(a, b) for a, b in zip(t3.state_dict().values(), t.state_dict().values()))
+    made = T.made.MADE(features=4, hidden_features=8)
+    made._hip_packed = (0, _hip.PackJob())
+    assert copy.deepcopy(made)._hip_packed is None
+
+
+def test_param_list_memo_sees_replaced_parameter_objects():
+    """ResidualNet._param_list() (the source list of every packed-weight key) follows Parameter objects that are
+    REPLACED rather than written in place: direct assignment and load_state_dict(assign=True)."""
+    net = nets.ResidualNet(4, 6, hidden_features=8)
+    before = net._param_list()
+    assert before is net._param_list()                                   # memoised
+    old = net.final_layer.weight
+    net.final_layer.weight = torch.nn.Parameter(torch.zeros_like(old))
+    after = net._param_list()
+    assert any(p is net.final_layer.weight for p in after) and not any(p is old for p in after)
+    key = net._storage_key()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(sd, assign=True)
+    assert net._storage_key() != key
+    assert all(a is b for a, b in zip(net._param_list(), net.parameters()))

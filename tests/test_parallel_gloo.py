@@ -120,3 +120,49 @@ def test_sharded_nll_backward_world2_matches_single_process(tmp_path):
     assert abs(res["nll"] - expect) <= 1e-5 * max(1.0, abs(expect))
     for got, p in zip(res["grads"], flow.parameters()):
         assert torch.allclose(got, p.grad, rtol=1e-4, atol=1e-6)
+
+
+def _plan_worker(rank, world, port, scaling, total, out_path):
+    """What bench.py does per rank, on CPU: rank_plan -> its rows of ONE global batch -> sharded mean."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from flowconductor_amd import parallel
+        from oracle import torch_oracle as O
+
+        plan = parallel.rank_plan(rank, world, rank, scaling, rows_per_gpu=5, total_rows=total)
+        flow = _flow()
+        rows = world * 5 if scaling == "weak" else total
+        x = torch.randn(rows, 6, generator=torch.Generator().manual_seed(3))
+        with torch.no_grad():
+            mean = parallel.sharded_log_prob_mean(lambda v: O.flow_log_prob(flow, v), x[plan["row_lo"]:plan["row_hi"]],
+                                                  group=dist.group.WORLD)
+        plans = [None] * world
+        dist.all_gather_object(plans, plan)
+        if rank == world - 1:
+            torch.save({"mean": mean, "plans": plans, "rows": rows}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scaling,total", [("weak", None), ("strong", 43), ("strong", 5)])
+def test_rank_plan_world8_sharded_mean(tmp_path, scaling, total):
+    """World size 8 (the driver's largest run): weak plan (equal shards), strong plans with uneven shards (43 rows over
+    8 ranks) and with EMPTY shards (5 rows over 8 ranks): the global mean equals the single-process one."""
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_plan_worker, args=(8, _free_port(), scaling, total, out), nprocs=8, join=True)
+    res = torch.load(out)
+    plans = res["plans"]
+    assert [p["rank"] for p in plans] == list(range(8))
+    assert [p["device_index"] for p in plans] == list(range(8))
+    assert len({p["seed"] for p in plans}) == 8
+    assert plans[0]["row_lo"] == 0 and plans[-1]["row_hi"] == res["rows"]
+    assert all(a["row_hi"] == b["row_lo"] for a, b in zip(plans, plans[1:]))
+    from oracle import torch_oracle as O
+
+    flow = _flow()
+    x = torch.randn(res["rows"], 6, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        expect = float(O.flow_log_prob(flow, x).double().mean())
+    assert abs(res["mean"] - expect) <= 1e-5 * max(1.0, abs(expect))
