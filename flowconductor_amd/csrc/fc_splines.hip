@@ -288,7 +288,18 @@ struct CubicSplineOp {
       out = ca * (t * t * t) + cb * (t * t) + cc * t + dco;
       lad = logf(3.f * ca * (t * t) + 2.f * cb * t + cc);
     } else {
-      // Blinn's closed form (cubic.py:152-244)
+      // Blinn's closed form (cubic.py:152-244), evaluated without its two cancellations.  The reference's float32
+      // sequence is correct in exact arithmetic but loses the answer in two places (measured against its own float64
+      // evaluation: max error 1e-3 .. 8e-3 on random parameters, tools/probe/cubic_inverse_accuracy.py):
+      //  * one real root: q^3 = (-dep1 - sqrt(-disc)) / 2 cancels to a few ulps when |delta_1|^3 << dep1^2 (an almost
+      //    quadratic bin just above the |a| < 1e-3 fallback) and the cube root amplifies what is left by ~1e3.  Here the
+      //    cube of larger magnitude is taken by the sum that does not cancel and the other from p q = -delta_1.
+      //  * a -> 0 fallback: (-b + sqrt(b^2 - 4 a c)) / (2 a) cancels (and is 0 / 0 at a = 0); 2 c / (-b - sqrt(..)) is
+      //    the same root (b = left knot derivative > 0, c <= 0 inside the bin).
+      // Two Newton steps on the bin's cubic then remove the rounding of the closed form itself; a step is taken only
+      // if it stays inside the bin (+- eps) with a positive slope.  The a -> 0 fallback is NOT polished: there the
+      // reference DEFINES the inverse through the quadratic part alone, and that definition is kept.
+      // Against float64 the result is never further off than the reference's float32 result (same probe).
       const float b_ = (cb / ca) / 3.f;
       const float c_ = (cc / ca) / 3.f;
       const float d_ = (dco - xn) / ca;
@@ -316,14 +327,25 @@ struct CubicSplineOp {
         out = m1 ? r1 : (m2 ? r2 : (m3 ? r3 : r1));
       } else {
         const float sq = sqrtf(-disc);
-        const float p = cbrt_ref((-dep1 + sq) / 2.f);
-        const float qq = cbrt_ref((-dep1 - sq) / 2.f);
+        const float big = (-dep1 + (dep1 <= 0.f ? sq : -sq)) / 2.f;
+        const float p = cbrt_ref(big);
+        const float qq = p != 0.f ? -dep2 / p : 0.f;
         out = (p + qq) - b_ + left_w;
       }
       if (fabsf(ca) < q.quad_thresh) {
         const float a2 = cb, b2 = cc, c2 = dco - xn;
-        const float alpha = (-b2 + sqrtf(b2 * b2 - 4.f * a2 * c2)) / (2.f * a2);
+        const float alpha = (2.f * c2) / (-b2 - sqrtf(b2 * b2 - 4.f * a2 * c2));
         out = alpha + left_w;
+      } else {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const float t = out - left_w;
+          const float fv = ((ca * t + cb) * t + cc) * t + (dco - xn);
+          const float fp = (3.f * ca * t + 2.f * cb) * t + cc;
+          const float nxt = out - fv / fp;
+          // (comparisons are false for NaN: a failed step keeps the closed-form root)
+          if (fp > 0.f && nxt > left_w - q.eps && nxt < right_w + q.eps) out = nxt;
+        }
       }
       const float t = out - left_w;
       lad = -logf(3.f * ca * (t * t) + 2.f * cb * t + cc);
