@@ -405,7 +405,9 @@ def main():
             f_bytes = (4 * HIDDEN + 8 * FEATURES + 4) * rows_per_launch
             f_gbs = f_bytes / (f_avg * 1e-3) / 1e9
             flops = 2.0 * HIDDEN * (FEATURES // 2) * (3 * BINS - 1) * rows_per_launch
-            out["roofline"] = {"bound": "hbm", "achieved": f_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound` names the resource that actually binds the kernel; achieved / peak / frac stay
+            # what the contract defines: algorithmic HBM bytes per launch over the launch time, against the HBM peak
+            out["roofline"] = {"bound": "valu_issue", "roof": "hbm", "achieved": f_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": f_gbs / HBM_PEAK_GBS,
                                "traffic": measured_traffic_per_launch("fc_rq_spline_fused_linear", rows_per_launch),
                                "traffic_source": src,
@@ -438,7 +440,7 @@ def main():
                 h_bytes = (4 * FEATURES + 4 * HIDDEN) * rows_per_launch
                 hflops = 2.0 * (HIDDEN * (FEATURES // 2) + 2 * BLOCKS * HIDDEN * HIDDEN) * rows_per_launch
                 h_gbs = h_bytes / (h_avg * 1e-3) / 1e9
-                out["roofline_hidden"] = {"bound": "hbm", "achieved": h_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                out["roofline_hidden"] = {"bound": "mfma_issue", "roof": "hbm", "achieved": h_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": h_gbs / HBM_PEAK_GBS,
                                           "traffic": measured_traffic_per_launch("fc_resnet_hidden", rows_per_launch),
                                           "kernel": "fc_resnet_hidden -> fc::resnet_hidden_kernel<2, 1, 0, 0, 1>",

@@ -61,10 +61,15 @@ struct BwdArgs {
 // compiler otherwise emits flat loads, which also count on lgkmcnt and are waited for before every LDS read
 typedef const __attribute__((address_space(1))) f16x8* GlobalFrags;
 
-constexpr int kBwdH = 64, kBwdHB = kBwdH + 8, kBwdR = kGenRows, kBwdTS = 32 + 8;   // TS: f16 per row of a transposed image
+// row strides of the images read as b128 fragments are 32 mod 64 bytes (conflict-free under ds_read_b128's four non-contiguous
+// 16-lane groups, tools/lds_conflicts.py): h rows 160 B, transposed images (TS f16 per row) 96 B
+constexpr int kBwdH = 64, kBwdR = kGenRows, kBwdTS = 32 + 16;
+// f16 per h row: 80 (160 B, conflict-free); role 0 at D > 124 keeps the 144 B of rounds 1-2 (2-way on the fragment reads):
+// its 68 KB of partial gh tiles leave no room for the wider rows next to a 128-column x / gy tile pair
+__host__ __device__ inline int bwd_hb(int d, int role) { return (role == 0 && d > 124) ? kBwdH + 8 : kBwdH + 16; }
 
 __host__ __device__ inline size_t bwd_lds_bytes(int d, int role) {
-  size_t b = (size_t)2 * 2 * kBwdR * kBwdHB * 2;            // hbuf [buf][piece][row][72]
+  size_t b = (size_t)2 * 2 * kBwdR * bwd_hb(d, role) * 2;   // hbuf [buf][piece][row][80 or 72]
   b += (size_t)2 * 2 * kBwdR * (d + 4) * 4;                 // xbuf + gbuf, [buf][row][D + 4]
   b += 2 * kBwdR * 4 * 2;                                   // hscale, gl  [buf][row]
   b += 32 * 4 + (size_t)32 * 52 * 4;                        // cols, bias image
@@ -79,10 +84,11 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   using S = GenShape<K, kTails>;
   constexpr int P = S::P, PP = S::PP, T = S::T;
   constexpr int PP8 = (PP + 7) / 8 * 8, KK = PP8 / 8;       // role 0: k-steps of the W^T product (8 parameters per lane)
-  constexpr int R = kBwdR, H = kBwdH, HB = kBwdHB, KS = 2, TS = kBwdTS;
+  constexpr int R = kBwdR, H = kBwdH, KS = 2, TS = kBwdTS;
   constexpr bool kDx = kRole != 1, kDw = kRole != 0, kMerged = kRole == 2;    // role 2: both products from one G
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   const int D = a.D;
+  const int HB = bwd_hb(D, kRole);
   const bool pad_x = (D & 3) == 0;
   const int XS = pad_x ? D + 4 : D;
   _Float16* hbuf = reinterpret_cast<_Float16*>(bsm);                             // [2][2][R][HB]

@@ -61,7 +61,7 @@ struct GenShape {
 };
 
 inline size_t gen_lds_bytes(int d, int h) {
-  const size_t hb = (size_t)2 * 2 * kGenRows * (h + 8) * 2;       // [buf][piece][row][H + 8] f16
+  const size_t hb = (size_t)2 * 2 * kGenRows * (h + 16) * 2;      // [buf][piece][row][H + 16] f16
   const size_t xb = (size_t)2 * kGenRows * (d + 4) * 4;           // [buf][row][D + 4]
   return hb + xb + 2 * kGenRows * 4 /* row scales */ + 2 * 8 * kGenRows * 4 /* logabsdet partials */ + 32 * 4 +
          (size_t)32 * 52 * 4 /* bias image, PP <= 52 */;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
   using S = GenShape<K, kTails>;
   constexpr int PP = S::PP, T = S::T, TC = S::TC;
   constexpr int R = kGenRows;
-  constexpr int H = 64 * HQ, KS = H / 32, HB = H + 8;
+  constexpr int H = 64 * HQ, KS = H / 32, HB = H + 16;   // row stride 32 mod 64 bytes: conflict-free b128 fragment reads (tools/lds_conflicts.py)
   constexpr int kRowLanes = H / 4;                       // threads that share a row of the h tile
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   const int D = a.D;

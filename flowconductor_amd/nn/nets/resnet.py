@@ -204,7 +204,7 @@ class ResidualNet(ops.RuntimeCaches, nn.Module):
         parametrizations replace objects without touching versions or pointers of the orphans); also dropped by
         ``_apply`` (.to / .cuda / .float) and when the cache epoch moves."""
         memo = self.__dict__.get("_fc_param_list")
-        epoch = ops.cache_key()[0]
+        epoch = ops.cache_epoch()
         if memo is None or memo[0] != epoch or not all(m._parameters.get(n) is p for m, n, p in memo[2]):
             slots = tuple((m, n, p) for m in self.modules() for n, p in m._parameters.items() if p is not None)
             memo = self.__dict__["_fc_param_list"] = (epoch, tuple(self.parameters()), slots)

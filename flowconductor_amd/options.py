@@ -30,6 +30,11 @@ _DEFAULTS = {
     # fc_rq_fused_linear_backward: one launch computing gx, gh, gb and gW from one evaluation of the spline backward
     # (role 2) instead of two launches (roles 0 and 1) that each recompute it
     "fused_backward_merged": False,
+    # Packed-weight caches (kernel-layout copies of parameters) are keyed on the parameters' version counters and storage
+    # pointers; a write THROUGH ``.data`` (``p.data.copy_(ema)``) moves neither.  True: every call re-packs (one
+    # fc_pack_fragments launch per layer, ~1 % of a cfg-3 log_prob) -- for code that edits ``.data`` of an eval-mode model
+    # and cannot call ``ops.invalidate_hip_caches()`` after it.
+    "paranoid_caches": False,
 }
 
 _values = dict(_DEFAULTS)

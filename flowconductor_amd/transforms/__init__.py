@@ -16,6 +16,7 @@ from flowconductor_amd.transforms.base import (  # noqa: F401
     Transform,
 )
 from flowconductor_amd.transforms.conditional import (  # noqa: F401
+    AffineConditionalTransform,
     ConditionalLUTransform,
     ConditionalOrthogonalTransform,
     ConditionalPiecewiseRationalQuadraticTransform,
@@ -39,7 +40,7 @@ from flowconductor_amd.transforms.coupling import (  # noqa: F401
     PiecewiseRationalQuadraticCouplingTransform,
 )
 from flowconductor_amd.transforms.adaptive_sigmoids import SumOfSigmoids  # noqa: F401
-from flowconductor_amd.transforms.linear import Linear  # noqa: F401
+from flowconductor_amd.transforms.linear import Linear, ScalarScale, ScalarShift  # noqa: F401
 from flowconductor_amd.transforms.lu import LULinear  # noqa: F401
 from flowconductor_amd.transforms.no_analytic_inv import (  # noqa: F401
     MonotonicTransform,

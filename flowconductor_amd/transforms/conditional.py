@@ -98,6 +98,37 @@ class ConditionalTransform(Transform):
         raise NotImplementedError()
 
 
+class AffineConditionalTransform(ConditionalTransform):
+    """y = (softplus(u(context)) + eps) x + shift(context), parameters interleaved [N, F, (u, shift)] (conditional.py:98-152).
+
+    The reference's class reads ``self._epsilon`` in both directions but never sets it (its constructor, :99-119, only
+    forwards to the base class): as shipped, its first forward raises AttributeError.  Here ``_epsilon`` is 1e-3, the
+    value of the identical bijector under the autoregressive conditioner (autoregressive.py:89); the golden fixture
+    ``cond_affine_d5`` comes from the reference's own code with that one attribute supplied (tests/golden/cases.py)."""
+
+    _epsilon = 1e-3
+
+    def __init__(self, features, hidden_features, context_features, **kwargs):
+        self.features = features
+        super().__init__(features=features, hidden_features=hidden_features, context_features=context_features,
+                         **kwargs)
+
+    def _output_dim_multiplier(self):
+        return 2
+
+    def _check_epsilon(self):
+        if self._epsilon != 1e-3:       # the kernel's constant (fc_affine.hip, FC_AFFINE_MAF_SOFTPLUS)
+            raise ValueError("AffineConditionalTransform: the HIP bijector is built for _epsilon = 1e-3")
+
+    def _forward_given_params(self, inputs, conditional_params):
+        self._check_epsilon()
+        return ops.affine_coupling(inputs, conditional_params, None, activation=ops.AFFINE_MAF_SOFTPLUS)
+
+    def _inverse_given_params(self, inputs, conditional_params):
+        self._check_epsilon()
+        return ops.affine_coupling(inputs, conditional_params, None, activation=ops.AFFINE_MAF_SOFTPLUS, inverse=True)
+
+
 class ConditionalShiftTransform(ConditionalTransform):
     """y = x + shift(context); logabsdet = 0 (conditional.py:155-209)."""
 

@@ -8,6 +8,7 @@ and reused -- any ``train(True)`` drops them -- and the map itself is one ``fc_l
     forward:  y = W x + b,            logabsdet =  log|det W|   (the same value for every row)
     inverse:  y = W^-1 (x - b),       logabsdet = -log|det W|
 """
+import numpy as np
 import torch
 from torch import nn
 
@@ -97,3 +98,56 @@ class Linear(Transform):
     weight = check.abstract("weight", "() -> dense [D, D] weight")
     weight_inverse = check.abstract("weight_inverse", "() -> dense [D, D] inverse weight")
     logabsdet = check.abstract("logabsdet", "() -> scalar log|det W|")
+
+
+class ScalarScale(Transform):
+    """y = (exp(_scale) + eps) x with ONE scalar for the whole tensor (flowcon/transforms/linear.py:232-252; the
+    reference's matrix/ helpers compose it).  The reference's log-determinant multiplies log(scale) by the SUM of the
+    non-batch sizes (``np.sum(inputs.shape[1:])``), which equals the number of elements only for [N, D] inputs: kept."""
+
+    _HIP_AUTOGRAD = True
+
+    def __init__(self, scale=1.0, trainable=True, eps=1e-4):
+        super().__init__()
+        if not np.all(np.asarray(scale) > 1e-6):
+            raise AssertionError("Scale too small..")
+        self._scale = nn.Parameter(torch.log(torch.tensor(scale, dtype=torch.get_default_dtype())), requires_grad=trainable)
+        self.eps = eps
+
+    @property
+    def scale(self):
+        return torch.exp(self._scale) + self.eps
+
+    def _map(self, inputs, inverse):
+        scale = self.scale
+        outputs = ops.pointwise_affine_autograd(inputs, scale.reshape(1), torch.zeros(1, device=inputs.device), inverse=inverse)
+        logabsdet = inputs.new_ones(inputs.shape[0]) * torch.log(scale).sum() * float(np.sum(inputs.shape[1:]))
+        return outputs, (-logabsdet if inverse else logabsdet)
+
+    def forward(self, inputs, context=None):
+        return self._map(inputs, False)
+
+    def inverse(self, inputs, context=None):
+        return self._map(inputs, True)
+
+
+class ScalarShift(Transform):
+    """y = x + shift with one scalar (flowcon/transforms/linear.py:255-266); logabsdet = 0."""
+
+    _HIP_AUTOGRAD = True
+
+    def __init__(self, shift=0.0, trainable=True):
+        super().__init__()
+        self.shift = nn.Parameter(torch.tensor(shift, dtype=torch.get_default_dtype()), requires_grad=trainable)
+
+    def _map(self, inputs, inverse):
+        # (x - b) / 1 is the kernel's inverse form: subtracting the shift
+        outputs = ops.pointwise_affine_autograd(inputs, torch.ones(1, device=inputs.device), self.shift.reshape(1),
+                                                inverse=inverse)
+        return outputs, inputs.new_zeros(inputs.shape[0])
+
+    def forward(self, inputs, context=None):
+        return self._map(inputs, False)
+
+    def inverse(self, inputs, context=None):
+        return self._map(inputs, True)

@@ -41,50 +41,44 @@ class BatchNorm(Transform):
     def _grad_needed(self, inputs):
         return torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
 
+    def _statistics(self, inputs, differentiable):
+        """(mean, var) the map uses: the batch's own in training mode (unbiased variance, normalization.py:104-107; the
+        running averages move by ``momentum`` towards them), the running averages otherwise."""
+        if not self.training:
+            return self.running_mean, self.running_var
+        with torch.set_grad_enabled(differentiable):
+            var, mean = torch.var_mean(inputs, dim=0)
+        with torch.no_grad():
+            self.running_mean.lerp_(mean.detach(), self.momentum)
+            self.running_var.lerp_(var.detach(), self.momentum)
+        return mean, var
+
+    def _map(self, inputs, inverse):
+        """Both directions, both execution modes.  With gradients required the map is plain torch arithmetic on the device
+        (training is a cross-batch reduction, SURVEY 8e: not a row-wise kernel; gradients flow through the batch statistics);
+        otherwise the point-wise kernel.  forward: y = w (x - mean) / std + b;  inverse: x = std (y - b) / w + mean."""
+        self._check(inputs)
+        differentiable = self._grad_needed(inputs)
+        mean, var = self._statistics(inputs, differentiable) if not inverse else (self.running_mean, self.running_var)
+        std = torch.sqrt(var + self.eps)
+        weight, bias = (self.weight, self.bias) if differentiable else (self.weight.detach(), self.bias.detach())
+        if differentiable:
+            outputs = std * ((inputs - bias) / weight) + mean if inverse else weight * ((inputs - mean) / std) + bias
+        else:
+            outputs = ops.batchnorm_eval(inputs, mean, std, weight, bias, inverse=inverse)
+        log_det = torch.sum(torch.log(weight) - 0.5 * torch.log(var + self.eps))
+        return outputs, (-log_det if inverse else log_det) * inputs.new_ones(inputs.shape[0])
+
     @own_autograd_check
     def forward(self, inputs, context=None):
-        self._check(inputs)
-        if self._grad_needed(inputs):
-            # Under autograd (training is a cross-batch reduction, SURVEY 8e: not a row-wise kernel) the map is the
-            # reference's torch expression on the device, differentiable through the batch statistics
-            # (normalization.py:98-119)
-            if self.training:
-                mean, var = inputs.mean(0), inputs.var(0)
-                with torch.no_grad():
-                    self.running_mean.mul_(1 - self.momentum).add_(mean.detach() * self.momentum)
-                    self.running_var.mul_(1 - self.momentum).add_(var.detach() * self.momentum)
-            else:
-                mean, var = self.running_mean, self.running_var
-            outputs = self.weight * ((inputs - mean) / torch.sqrt(var + self.eps)) + self.bias
-            logabsdet_ = torch.log(self.weight) - 0.5 * torch.log(var + self.eps)
-            return outputs, torch.sum(logabsdet_) * inputs.new_ones(inputs.shape[0])
-        if self.training:
-            with torch.no_grad():
-                mean, var = inputs.mean(0), inputs.var(0)
-                self.running_mean.mul_(1 - self.momentum).add_(mean * self.momentum)
-                self.running_var.mul_(1 - self.momentum).add_(var * self.momentum)
-        else:
-            mean, var = self.running_mean, self.running_var
-        weight = self.weight.detach()
-        outputs = ops.batchnorm_eval(inputs, mean, torch.sqrt(var + self.eps), weight, self.bias.detach())
-        logabsdet_ = torch.log(weight) - 0.5 * torch.log(var + self.eps)
-        return outputs, torch.sum(logabsdet_) * inputs.new_ones(inputs.shape[0])
+        return self._map(inputs, inverse=False)
 
     @own_autograd_check       # the reference's InverseNotAvailable comes first
     def inverse(self, inputs, context=None):
         if self.training:
             raise InverseNotAvailable(
                 "Batch norm inverse is only available in eval mode, not in training mode.")
-        self._check(inputs)
-        if self._grad_needed(inputs):   # normalization.py:121-141 in torch ops (see forward)
-            outputs = torch.sqrt(self.running_var + self.eps) * ((inputs - self.bias) / self.weight) + self.running_mean
-            logabsdet_ = -torch.log(self.weight) + 0.5 * torch.log(self.running_var + self.eps)
-            return outputs, torch.sum(logabsdet_) * inputs.new_ones(inputs.shape[0])
-        weight = self.weight.detach()
-        outputs = ops.batchnorm_eval(inputs, self.running_mean, torch.sqrt(self.running_var + self.eps),
-                                     weight, self.bias.detach(), inverse=True)
-        logabsdet_ = -torch.log(weight) + 0.5 * torch.log(self.running_var + self.eps)
-        return outputs, torch.sum(logabsdet_) * inputs.new_ones(inputs.shape[0])
+        return self._map(inputs, inverse=True)
 
 
 class ActNorm(Transform):
@@ -132,11 +126,11 @@ class ActNorm(Transform):
         return self._run(inputs, inverse=True)
 
     def _initialize(self, inputs):
-        if inputs.dim() == 4:
-            inputs = inputs.permute(0, 2, 3, 1).reshape(-1, inputs.shape[1])
+        """One-off data-dependent initialisation (normalization.py:206-218): per feature / channel, over every other
+        position of the batch, log_scale = -log(std) with the unbiased std and shift = -mean(x / std)."""
+        per_feature = inputs if inputs.dim() == 2 else inputs.movedim(1, -1).reshape(-1, inputs.shape[1])
         with torch.no_grad():
-            std = inputs.std(dim=0)
-            mu = (inputs / std).mean(dim=0)
-            self.log_scale.data = -torch.log(std)
-            self.shift.data = -mu
-            self.initialized.data = torch.tensor(True, dtype=torch.bool)
+            std = per_feature.std(dim=0)
+            self.log_scale.copy_(-std.log())
+            self.shift.copy_(-(per_feature / std).mean(dim=0))
+            self.initialized.fill_(True)

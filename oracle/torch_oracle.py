@@ -1028,6 +1028,18 @@ def _cond_shift(t, x, p, inverse):
     return (x - shift if inverse else x + shift), x.new_zeros(x.shape[0])
 
 
+def _cond_affine(t, x, p, inverse):
+    """conditional.py:121-152 (``_epsilon`` is read but never set by the reference: supplied by the caller, see
+    tests/golden/cases.py ``cond_affine_d5``)."""
+    p = p.view(-1, _int(t.features), 2)
+    scale = F.softplus(p[..., 0]) + t._epsilon
+    shift = p[..., 1]
+    lad = torch.log(scale).sum(-1)
+    if inverse:
+        return (x - shift) / scale, -lad
+    return scale * x + shift, lad
+
+
 def _cond_scale(t, x, p, inverse):
     """conditional.py:229-260."""
     scale = F.softplus(p.view(-1, _int(t.features))) + t.eps
@@ -1203,6 +1215,7 @@ _DISPATCH = {
     "PiecewiseLinearCDF": _make_sibling_cdf("linear"),
     "PiecewiseQuadraticCDF": _make_sibling_cdf("quadratic"),
     "PiecewiseCubicCDF": _make_sibling_cdf("cubic"),
+    "AffineConditionalTransform": _conditional(_cond_affine),
     "ConditionalShiftTransform": _conditional(_cond_shift),
     "ConditionalScaleTransform": _conditional(_cond_scale),
     "ConditionalLUTransform": _conditional(_cond_lu),

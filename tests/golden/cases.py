@@ -346,6 +346,18 @@ def _(L):
     return L.transforms.ConditionalShiftTransform(features=5, hidden_features=16, context_features=3)
 
 
+@case("cond_affine_d5", 5, context=3)
+def _(L):
+    # conditional.py:98-152 reads self._epsilon but never sets it (AttributeError as shipped): supplied here, with the
+    # value of the identical autoregressive bijector (autoregressive.py:89)
+    import importlib
+
+    mod = importlib.import_module(L.transforms.__name__ + ".conditional")
+    t = mod.AffineConditionalTransform(features=5, hidden_features=16, context_features=3)
+    t._epsilon = 1e-3
+    return t
+
+
 @case("cond_scale_d5", 5, context=3)
 def _(L):
     return L.transforms.ConditionalScaleTransform(features=5, hidden_features=16, context_features=3)

@@ -117,7 +117,10 @@ def main():
     make_knot_fixture(os.path.join(HERE, "fn_rq_interior_knots.npz"))
     if "--knots-only" in sys.argv:
         return
+    only = sys.argv[sys.argv.index("--only") + 1:] if "--only" in sys.argv else None      # --only name [name ...]
     for name, spec in cases.CASES.items():
+        if only is not None and name not in only:
+            continue
         torch.manual_seed(1234)
         t = spec["build"](L)
         cases.boost_parameters(t, spec["boost"], seed=0)

@@ -18,7 +18,7 @@ def _floor(g, key, n):
     return float(np.max(np.abs(g[k32].astype(np.float64) - g[k64])))
 
 
-def _check(name, n, what, got, g, key, exact, mult=8.0):
+def _check(name, n, what, got, g, key, exact, mult=4.0):
     """GPU vs the reference's float32 golden.
 
     Bit-exact for index ops.  Otherwise the bound is the north-star's 1e-5 relative (scaled by
@@ -26,7 +26,8 @@ def _check(name, n, what, got, g, key, exact, mult=8.0):
     very quantity, measured as max |reference-f32 - reference-f64| when the fixture was generated
     (ill-conditioned spline inverses carry 1e-3-level noise in the reference itself).  The floor
     is one realisation of a heavy-tailed error (tools/noise_floor.py: p99.99 -> max spans 6x, and
-    the HIP kernel's error distribution vs float64 equals the reference-f32's), hence the margin."""
+    the HIP kernel's error distribution vs float64 equals the reference-f32's), hence the margin: `mult` = 4 since round 3
+    (8 in round 2; the largest multiple any of the 60 fixtures needs is 3.4, tools/probe/golden_margins.py)."""
     ref = g["%s_%d" % (key, n)]
     if exact:
         assert torch.equal(got.cpu(), torch.from_numpy(ref)), (name, n, what)
@@ -65,7 +66,7 @@ def test_gpu_matches_reference_golden(name, device):
                 xi, ladi = t.inverse(yin, ctx)
             # the same margin as the forward direction: the largest multiple of the floor any of the 60 cases needs
             # is 3.4 (tools/probe/golden_margins.py; the autoregressive spline inverses, once bounded by 64 x, need 2.7)
-            mult = 8.0
+            mult = 4.0
             _check(name, n, "inverse outputs", xi, g, "xinv", exact, mult)
             _check(name, n, "inverse logabsdet", ladi, g, "ladinv", exact, mult)
             # well-conditioned direction: pushing the kernel's inverse forward again lands on y

@@ -103,3 +103,93 @@ def test_inverse_transform_of_a_transform_without_inverse_raises(device):
     t = T.InverseTransform(T.PlanarTransform(features=4)).to(device)
     with pytest.raises(T.InverseNotAvailable):
         t(torch.zeros(3, 4, device=device))
+
+
+def test_per_sample_sylvester_full_size_2_18(device):
+    """BASELINE.json configs[4] in its conditional (per-sample) form at FULL size: x [2^18, 128], q [2^18, 32, 128],
+    R1 / R2 [2^18, 128, 128] (38 GB of per-sample parameters).  512 rows spread over the batch against the float64
+    formula of conditional.py:936-953; on ALL rows: finite, deterministic, and a row's result independent of where in
+    the launch it sits (the same rows as a 512-row launch, bitwise)."""
+    from flowconductor_amd import ops
+
+    n, d, m = 1 << 18, 128, 32
+    gen = torch.Generator(device=device).manual_seed(2718)
+    x = torch.randn(n, d, device=device, generator=gen)
+    q = torch.randn(n, m, d, device=device, generator=gen)
+    r1 = torch.randn(n, d, d, device=device, generator=gen).mul_(1.0 / d ** 0.5)
+    r2 = torch.randn(n, d, d, device=device, generator=gen).mul_(1.0 / d ** 0.5)
+    r1.diagonal(dim1=1, dim2=2).tanh_()
+    r2.diagonal(dim1=1, dim2=2).tanh_()        # (below the diagonal: random junk, never read)
+    bias = torch.randn(n, d, device=device, generator=gen).mul_(0.1)
+    with torch.no_grad():
+        y, lad = ops.sylvester(x, q, r1, r2, bias)
+        y2, lad2 = ops.sylvester(x, q, r1, r2, bias)
+    assert y.shape == (n, d) and lad.shape == (n,)
+    assert torch.isfinite(y).all() and torch.isfinite(lad).all()
+    assert torch.equal(y, y2) and torch.equal(lad, lad2)
+    idx = torch.cat((torch.arange(0, 128), torch.arange(n // 3 + 5, n // 3 + 5 + 128), torch.arange(n // 2 - 64, n // 2 + 64),
+                     torch.arange(n - 128, n))).to(device)
+    with torch.no_grad():
+        ys, lads = ops.sylvester(x[idx], q[idx].contiguous(), r1[idx].contiguous(), r2[idx].contiguous(), bias[idx])
+    assert torch.equal(y[idx], ys) and torch.equal(lad[idx], lads)
+    xd, qd = x[idx].double().cpu(), q[idx].double().cpu()
+    r1d, r2d, bd = torch.triu(r1[idx].double().cpu()), torch.triu(r2[idx].double().cpu()), bias[idx].double().cpu()
+
+    def reflect(v, reverse):
+        for i in (range(m - 1, -1, -1) if reverse else range(m)):
+            qi = qd[:, i]
+            v = v - (v * qi).sum(-1, keepdim=True) * (2.0 / (qi * qi).sum(-1, keepdim=True)) * qi
+        return v
+
+    act = torch.tanh(torch.einsum("nij,nj->ni", r1d, reflect(xd, True)) + bd)
+    ref_y = xd + reflect(torch.einsum("nij,nj->ni", r2d, act), False)
+    ref_lad = torch.log(1 + (1 - act ** 2) * (r1d.diagonal(dim1=1, dim2=2) * r2d.diagonal(dim1=1, dim2=2))).sum(-1)
+    assert float((ys.double().cpu() - ref_y).abs().max()) <= 2e-5 * max(1.0, float(ref_y.abs().max()))
+    assert float((lads.double().cpu() - ref_lad).abs().max()) <= 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10)
+
+
+def test_scalar_scale_and_shift(device):
+    """flowcon/transforms/linear.py:232-266, including the reference's log-determinant factor (the SUM of the non-batch
+    sizes) and gradients of the scalar parameters."""
+    s, b = T.ScalarScale(scale=3.0, trainable=True).to(device), T.ScalarShift(0.25, trainable=True).to(device)
+    x = torch.randn(9, 5, device=device)
+    with torch.no_grad():
+        y, lad = s(x)
+        xb, ladb = s.inverse(y)
+        z, lz = b(x)
+        zb, _ = b.inverse(z)
+    scale = float(torch.exp(s._scale) + s.eps)
+    assert torch.allclose(y, x * scale, rtol=1e-6) and torch.allclose(lad, torch.full((9,), 5 * np.log(scale), device=device), rtol=1e-6)
+    assert torch.allclose(xb, x, atol=1e-6) and torch.allclose(ladb, -lad)
+    assert torch.allclose(z, x + 0.25) and float(lz.abs().max()) == 0.0 and torch.allclose(zb, x, atol=1e-6)
+    x4 = torch.randn(3, 2, 4, 5, device=device)
+    with torch.no_grad():
+        _, lad4 = s(x4)
+    assert torch.allclose(lad4, torch.full((3,), (2 + 4 + 5) * np.log(scale), device=device), rtol=1e-6)    # sum, not product
+    (s(x)[0].sum() + s(x)[1].sum() + b(x)[0].sum()).backward()
+    assert s._scale.grad is not None and b.shift.grad is not None
+    assert abs(float(b.shift.grad) - x.numel()) < 1e-3
+
+
+@pytest.mark.parametrize("hidden,bins", [(64, 8), (32, 10), (128, 10)])
+def test_paranoid_caches_see_data_writes_without_invalidation(device, hidden, bins):
+    """with options.paranoid_caches an eval-mode model whose weights are edited through `.data` gives
+    fresh results WITHOUT ops.invalidate_hip_caches() -- on the hand-scheduled K = 8 path, the packed-fragment general
+    path and the wide hidden stack; the default (off) keeps the documented caveat."""
+    from flowconductor_amd import options
+
+    torch.manual_seed(9)
+    d = 16
+    t = T.PiecewiseRationalQuadraticCouplingTransform(
+        utils.create_alternating_binary_mask(d), lambda i, o: nets.ResidualNet(i, o, hidden_features=hidden, num_blocks=2),
+        num_bins=bins, tails="linear", tail_bound=3.0).eval().to(device)
+    x = torch.randn(256, d, device=device)
+    with torch.no_grad(), options.override(paranoid_caches=True):
+        y0, _ = t(x)
+        for p in t.transform_net.parameters():
+            p.data.mul_(1.5)                       # EMA-style swap; no invalidate_hip_caches()
+        y1, lad1 = t(x)
+        with options.override(fused_final_layer=False, fused_hidden=False):
+            y_ref, lad_ref = t(x)                  # conditioner on PyTorch kernels: always the live weights
+    assert float((y0 - y_ref).abs().max()) > 1e-3, "the weight change must be visible"
+    assert float((y1 - y_ref).abs().max()) <= 2e-5 and float((lad1 - lad_ref).abs().max()) <= 3e-4

@@ -1,5 +1,5 @@
 """The BASELINE.json configurations other than the headline one, as bench.py's ``configs`` block (and on their own:
-``python tools/bench_configs.py [cfg1 cfg2 cfg5_shared cfg5_per_sample nsf_k10_h256]``, one JSON object per line).
+``python tools/bench_configs.py [cfg3_sample cfg1 cfg2 cfg5_shared cfg5_per_sample nsf_k10_h256]``, one JSON object per line).
 
 Every entry carries what the headline line carries: throughput, the dominant kernel's ``roofline`` (algorithmic bytes or
 flops of SURVEY.md 8d per launch / the average launch duration from HIP events on the launch stream), ``cpu_baseline``
@@ -84,9 +84,11 @@ def _cpu_baseline(fn, units, what):
             "sample": "%s, %d repeats, %.1f s" % (what, reps, dt)}
 
 
-def _hbm_roofline(kernel, entry, ms, launches, bytes_per_launch, note=None):
+def _hbm_roofline(kernel, entry, ms, launches, bytes_per_launch, note=None, bound="hbm"):
+    """``bound``: the resource that binds the kernel; achieved / peak / frac are always the algorithmic HBM bytes over
+    the launch time against the HBM peak (``roof``)."""
     gbs = bytes_per_launch / (ms * 1e-3) / 1e9
-    r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+    r = {"bound": bound, "roof": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
          "traffic": None, "kernel": "%s -> %s" % (entry, kernel), "launches_timed": launches, "avg_launch_ms": ms,
          "algorithmic_bytes_per_launch": bytes_per_launch}
     if note:
@@ -131,7 +133,7 @@ def cfg1(device, steps=50, warmup=10):
            "dtype": "f32",
            "roofline": _hbm_roofline("affine tile kernel", "fc_affine", ms, launches, 40 * n,
                                      "B = 4*d_t*(P+2)+8 = 40 B per sample and layer (SURVEY 8d); at N = 4096 the launch "
-                                     "is latency-bound: 164 KB per launch cannot load 256 CUs"),
+                                     "is latency-bound: 164 KB per launch cannot load 256 CUs", bound="launch_latency"),
            "parity": {"max_abs_dlog_prob": _maxdiff(lp, ref), "max_abs_dlog_prob_graphed": _maxdiff(lp_g, ref),
                       "rows": n},
            "cpu_baseline": _cpu_baseline(lambda: O.flow_log_prob(flow_cpu, xc), n, "4096 samples per call")}
@@ -170,7 +172,7 @@ def cfg2(device, steps=20, warmup=5):
            "roofline": _hbm_roofline("resnet_hidden_kernel (coupling tail)", "fc_affine_coupling_resnet", a_ms, a_n, 264 * n,
                                      "one kernel per coupling layer (hidden stack + final Linear + affine bijector); "
                                      "B = 4*16*(2+2)+8 = 264 B per sample and layer (SURVEY 8d; the kernel itself moves "
-                                     "x in + y out + logabsdet = 264 B: the parameters never exist in memory)"),
+                                     "x in + y out + logabsdet = 264 B: the parameters never exist in memory)", bound="mfma_issue"),
            "parity": {"max_rel_dsamples": float(((z.cpu().double() - z_ref.double()).abs()
                                                  / z_ref.double().abs().clamp_min(1.0)).max()),
                       "max_abs_dlogabsdet": _maxdiff(lad, lad_ref), "rows": 2048},
@@ -350,7 +352,67 @@ def nsf_k10_h256(device, steps=5, warmup=2, log2n=18, layers=16, hidden=256, bin
     return out
 
 
-ALL = {"cfg1": cfg1, "cfg2": cfg2, "cfg5_shared": cfg5_shared, "cfg5_per_sample": cfg5_per_sample,
+def cfg3_sample(device, steps=5, warmup=2, log2n=20):
+    """The INVERSE direction of the headline flow (north star: "forward + inverse"): ``Flow.sample(2^20)`` and
+    ``Flow.sample_and_log_prob(2^20)`` of BASELINE.json configs[2]'s 32-layer RQ-NSF flow (flows/base.py:50-105 of the
+    reference) -- base draws on the device, 32 coupling layers inverted last to first in the same fused kernels
+    instantiated with the inverse spline (root of the rational-quadratic bin, rational_quadratic.py:133-160)."""
+    import copy
+
+    import bench
+    from oracle import torch_oracle as O
+
+    flow_cpu = bench.build_flow()
+    flow = copy.deepcopy(flow_cpu).to(device).eval()
+    n = 1 << log2n
+    torch.manual_seed(4321)
+    step_s, x = _time_gpu(lambda: flow.sample(n), steps, warmup)
+    step_lp_s, (x2, lp2) = _time_gpu(lambda: flow.sample_and_log_prob(n), steps, warmup)
+    km = _kernel_ms(lambda: flow.sample(n), ["fc_rq_spline_fused_linear", "fc_resnet_hidden"])
+    out = {"workload": "Flow.sample / sample_and_log_prob, 32-layer RQ-NSF coupling flow D=64 K=8 (BASELINE.json configs[2]), "
+                       "N=2^%d draws" % log2n,
+           "metric": "samples drawn per second", "unit": "samples/s", "value": n / step_s, "ms_per_step": step_s * 1e3,
+           "sample_and_log_prob": {"value": n / step_lp_s, "unit": "samples/s", "ms_per_step": step_lp_s * 1e3},
+           "dtype": "f32 results; conditioner products = 3-term split-f16 MFMA"}
+    f_ms, f_n = km["fc_rq_spline_fused_linear"]
+    if f_ms:
+        out["roofline"] = _hbm_roofline("fc::rq_fused_linear_kernel3<true (inverse), 64, 2, true, true>", "fc_rq_spline_fused_linear",
+                                        f_ms, f_n, (4 * 64 + 8 * 64 + 4) * n,
+                                        note="binding resource: VALU issue (the inverse spline adds a square root and a "
+                                             "division per element to the forward evaluation)", bound="valu_issue")
+    h_ms, h_n = km["fc_resnet_hidden"]
+    if h_ms:
+        out["roofline_hidden"] = _hbm_roofline("fc::resnet_hidden_kernel", "fc_resnet_hidden", h_ms, h_n, (4 * 64 + 4 * 64) * n,
+                                               bound="mfma_issue")
+    with torch.no_grad():
+        # draws pushed forward again land on the noise they came from; densities agree with log_prob of the draws
+        z_back, lad = flow._transform(x2)
+        lp_fwd = flow.log_prob(x2)
+        z0 = torch.randn(2048, 64, generator=torch.Generator().manual_seed(5))
+        x_ref, lad_ref = O.transform_apply(flow_cpu._transform, z0.clone(), inverse=True)
+        x_gpu, lad_gpu = flow._transform.inverse(z0.to(device))
+        x64, lad64 = O.transform_apply(copy.deepcopy(flow_cpu._transform).double(), z0.double(), inverse=True)
+
+    def rel(a, b):
+        return float(((a.double().cpu() - b.double()).abs() / b.double().abs().clamp_min(1.0)).max())
+
+    out["parity"] = {"max_abs_log_prob_sample_vs_forward": _maxdiff(lp2, lp_fwd),
+                     "finite": bool(torch.isfinite(x2).all() and torch.isfinite(lp2).all()),
+                     "inverse_vs_oracle_rows": 2048,
+                     "max_rel_dsamples": rel(x_gpu, x_ref), "max_abs_dlogabsdet": _maxdiff(lad_gpu, lad_ref),
+                     "vs_float64": {"gpu_max_rel_dsamples": rel(x_gpu, x64), "cpu_f32_oracle_max_rel_dsamples": rel(x_ref, x64),
+                                    "gpu_max_abs_dlogabsdet": _maxdiff(lad_gpu, lad64),
+                                    "cpu_f32_oracle_max_abs_dlogabsdet": _maxdiff(lad_ref, lad64)}}
+    del z_back, lad
+    sample = 1 << 13
+    zc = torch.randn(sample, 64, generator=torch.Generator().manual_seed(99))
+    out["cpu_baseline"] = _cpu_baseline(lambda: O.transform_apply(flow_cpu._transform, zc.clone(), inverse=True), sample,
+                                        "inverse of the 32-layer stack on 2^13 noise rows per call (the oracle)")
+    out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+ALL = {"cfg3_sample": cfg3_sample, "cfg1": cfg1, "cfg2": cfg2, "cfg5_shared": cfg5_shared, "cfg5_per_sample": cfg5_per_sample,
        "nsf_k10_h256": nsf_k10_h256}
 
 
