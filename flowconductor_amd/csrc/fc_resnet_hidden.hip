@@ -489,6 +489,9 @@ __global__ __launch_bounds__(512, (kCtx || BPW > 1 || kTail) ? 2 : 4) void resne
               const float v = softplus_lean(u, 1.f) + 1e-3f;
               sc = v < 0.f ? 0.f : (v > 3.f ? 3.f : v);      // torch.clamp: a NaN stays a NaN
               ls = log_lean(sc);
+            } else if (a.affine_act == FC_AFFINE_MAF_SOFTPLUS) {   // autoregressive.py:97-129 (rows re-ordered by the packer)
+              sc = softplus_lean(u, 1.f) + 1e-3f;
+              ls = log_lean(sc);
             }
             wrow[tc[e]] = a.inverse ? div_lean(xv - shift, sc) : xv * sc + shift;
             ladsum += a.inverse ? -ls : ls;
@@ -797,9 +800,11 @@ extern "C" int fc_affine_coupling_resnet(const float* x, float* y, const int32_t
                                          int32_t hidden, int32_t num_blocks, int32_t scale_activation, int32_t inverse,
                                          int32_t accumulate, void* stream) {
   if (n < 0 || d <= 0 || hidden != fc::kHid || num_blocks < 0 || num_blocks > 3) return hipErrorInvalidValue;
-  if (in_features <= 0 || in_features > 64 || d_t <= 0 || d_t > 32 || in_features + d_t > d || d > 128) return hipErrorInvalidValue;
+  // (a coupling layer has in_features + d_t <= d; a masked-autoregressive layer in its density direction reads and transforms
+  //  ALL columns: the kernel picks every input from the wave's row tile before it writes any result into it)
+  if (in_features <= 0 || in_features > 64 || d_t <= 0 || d_t > 32 || in_features > d || d_t > d || d > 128) return hipErrorInvalidValue;
   if (scale_activation != FC_AFFINE_SIGMOID_PLUS2 && scale_activation != FC_AFFINE_SOFTPLUS_CLAMP3 &&
-      scale_activation != FC_AFFINE_ADDITIVE)
+      scale_activation != FC_AFFINE_ADDITIVE && scale_activation != FC_AFFINE_MAF_SOFTPLUS)
     return hipErrorInvalidValue;
   if (n % 16 != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;

@@ -81,10 +81,25 @@ __device__ __forceinline__ float group_allmax(float m, int lane) {
 //  waiting for weight fragments from L2: 0.79 -> 0.73 ms per 2^20 rows at K = 8 / hidden 64; K = 10 needs 171 registers)
 constexpr int gen_waves_per_simd(int k, int hq) { return (k <= 8 && hq <= 2) ? 4 : 2; }
 
+// Round 3: PARTLY RESIDENT weights at hidden 64 for the shapes that live at two waves per SIMD anyway (K >= 9: the
+// reference's default K = 10).  Those kernels used 157 - 219 of their 256 registers and spent most of their time waiting
+// for the same 16 - 24 KB of weight fragments from L2 on every 32-row tile (K = 10: 0.97 ms per 2^20 rows against 0.43 ms
+// of the fully resident K = 8 kernel).  The first `gen_resident_pairs` (hi, lo) fragment pairs of a wave now stay in
+// registers for the whole kernel; only the rest is streamed, all of it requested at the top of the product phase.
+// T tiles x 2 k-steps pairs in all; 8 registers per pair; chosen so that no instantiation spills (tools/kernel_stats.py).
+constexpr int gen_resident_pairs(int t, int hq, int k) {
+  if (hq != 1 || k <= 8) return 0;
+  // what fits without spills next to two accumulator sets, the bias rows and the evaluation's temporaries (tools/kernel_stats.py):
+  // K = 9: 10 of 14 pairs, K = 10: 7 of 16, K = 11: 3 of 16 / 18; from K = 12 on nothing is left
+  (void)t;
+  return k == 9 ? 10 : k == 10 ? 7 : k == 11 ? 3 : 0;
+}
+
 template <int K, bool kTails, int HQ>
 __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fused_general_kernel(RQOp<K> op, GenArgs a) {
   using S = GenShape<K, kTails>;
   constexpr int PP = S::PP, T = S::T, TC = S::TC;
+  constexpr int RES = gen_resident_pairs(T, HQ, K);
   constexpr int R = kGenRows;
   constexpr int H = 64 * HQ, KS = H / 32, HB = H + 16;   // row stride 32 mod 64 bytes: conflict-free b128 fragment reads (tools/lds_conflicts.py)
   constexpr int kRowLanes = H / 4;                       // threads that share a row of the h tile
@@ -115,6 +130,15 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
   const f32x4* bw = reinterpret_cast<const f32x4*>(bias_lds + (grp * 4 + g) * PP);
   const float w_un = a.wun[grp];
   const f16x8* wsrc = a.wfrag + (size_t)grp * KS * T * 2 * 64 + lane;
+
+  f16x8 rh[RES > 0 ? RES : 1], rl[RES > 0 ? RES : 1];       // resident pairs: index i = ks * T + t, the image's own order
+  if constexpr (RES > 0) {
+#pragma unroll
+    for (int i = 0; i < RES; ++i) {
+      rh[i] = wsrc[(i * 2 + 0) * 64];
+      rl[i] = wsrc[(i * 2 + 1) * 64];
+    }
+  }
 
   uint32_t err = 0;
   const int xvec = R * D / 4;                     // float4 per x tile (R * D is a multiple of 4)
@@ -192,6 +216,42 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (RES > 0) {
+        // The streamed pairs come in chunks of <= CH requests, a chunk's requests all out before its first product; the
+        // resident pairs are multiplied between the first chunk's requests and its products (they cover that L2 round trip).
+        constexpr int NP = KS * T, NS = NP - RES, CH = NS <= 8 ? NS : (NS + 1) / 2 <= 8 ? (NS + 1) / 2 : 8;
+        f16x8 bh0, bl0, bh1, bl1;
+        auto products = [&](int i, const f16x8& ah, const f16x8& al) __attribute__((always_inline)) {
+          const int ks = i / T, t = i - ks * T;
+          if (t == 0 || i == RES) {       // (re-)read the h^T fragments of this k-step
+            bh0 = hfrag(buf, 0, 0, ks); bl0 = hfrag(buf, 0, 1, ks);
+            bh1 = hfrag(buf, 1, 0, ks); bl1 = hfrag(buf, 1, 1, ks);
+          }
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh0, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh1, acc[1][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl0, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl1, acc[1][t], 0, 0, 0);
+          acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh0, acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, acc[1][t], 0, 0, 0);
+        };
+#pragma unroll
+        for (int c0 = 0; c0 < NS; c0 += CH) {
+          f16x8 sh[CH], sl[CH];
+#pragma unroll
+          for (int i = 0; i < CH; ++i)
+            if (c0 + i < NS) {
+              sh[i] = wsrc[((RES + c0 + i) * 2 + 0) * 64];
+              sl[i] = wsrc[((RES + c0 + i) * 2 + 1) * 64];
+            }
+          if (c0 == 0) {
+#pragma unroll
+            for (int i = 0; i < RES; ++i) products(i, rh[i], rl[i]);
+          }
+#pragma unroll
+          for (int i = 0; i < CH; ++i)
+            if (c0 + i < NS) products(RES + c0 + i, sh[i], sl[i]);
+        }
+      } else
 #pragma unroll 1
       for (int ks = 0; ks < KS; ++ks) {
         const f16x8 bh0 = hfrag(buf, 0, 0, ks), bl0 = hfrag(buf, 0, 1, ks);

@@ -198,17 +198,8 @@ class ResidualNet(ops.RuntimeCaches, nn.Module):
         return tuple(p.data_ptr() for p in self._param_list())
 
     def _param_list(self):
-        """``tuple(self.parameters())`` kept on the module (walking the module tree on every call was a third of the
-        per-layer host time) together with WHERE each one hangs: the memo is valid only while every slot still holds
-        the same Parameter object (``lin.weight = nn.Parameter(...)``, ``load_state_dict(assign=True)`` and late
-        parametrizations replace objects without touching versions or pointers of the orphans); also dropped by
-        ``_apply`` (.to / .cuda / .float) and when the cache epoch moves."""
-        memo = self.__dict__.get("_fc_param_list")
-        epoch = ops.cache_epoch()
-        if memo is None or memo[0] != epoch or not all(m._parameters.get(n) is p for m, n, p in memo[2]):
-            slots = tuple((m, n, p) for m in self.modules() for n, p in m._parameters.items() if p is not None)
-            memo = self.__dict__["_fc_param_list"] = (epoch, tuple(self.parameters()), slots)
-        return memo[1]
+        """``ops.param_list``: the memoised parameter tuple, valid while every slot holds the same Parameter object."""
+        return ops.param_list(self)
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float(): new storages (and possibly new Parameter objects)

@@ -207,6 +207,19 @@ class RuntimeCaches:
         return state
 
 
+def param_list(module):
+    """``tuple(module.parameters())`` memoised on the module (walking the module tree on every call is a third of the
+    per-layer host time of a small batch) together with WHERE each parameter hangs: the memo is valid only while every slot
+    still holds the same Parameter object (``lin.weight = nn.Parameter(...)``, ``load_state_dict(assign=True)`` and late
+    parametrizations replace objects without touching versions or pointers of the orphans) and the cache epoch stands;
+    modules drop it in ``_apply`` (.to / .cuda / .float)."""
+    memo = module.__dict__.get("_fc_param_list")
+    if memo is None or memo[0] != _cache_epoch or not all(m._parameters.get(n) is p for m, n, p in memo[2]):
+        slots = tuple((m, n, p) for m in module.modules() for n, p in m._parameters.items() if p is not None)
+        memo = module.__dict__["_fc_param_list"] = (_cache_epoch, tuple(module.parameters()), slots)
+    return memo[1]
+
+
 def has_hooks(module):
     """True when ``module`` or a sub-module carries forward (pre-)hooks (old-style weight_norm refreshes ``weight``
     in one): the fast paths read the weights directly and never go through ``__call__``, so they step aside.
@@ -757,6 +770,48 @@ def device_pack_affine_coupling(net, d_t, additive):
     return pack, (w_frag, w_un, bias_acc)
 
 
+def device_pack_made_affine(made, features):
+    """The LDS image of ``fc_affine_coupling_resnet`` for the DENSITY direction of a masked-autoregressive affine layer
+    (autoregressive.py:97-129): every layer of the MADE with its mask multiplied in (staging copies, refreshed before each
+    pack launch), the final masked Linear re-ordered from the interleaved [D, (u, shift)] rows to rows 0..31 = shift of dims
+    0..31, rows 32..63 = u.  Returns ``(pack, packed)`` like ``device_pack_affine_coupling``."""
+    dev = made.initial_layer.weight.device
+    hidden_layers = [made.initial_layer] + [lin for block in made.blocks for lin in block.linear_layers]
+    n_layers = len(hidden_layers) + 1
+    k0s = 1
+    frag0, frag_l = k0s * 4 * 2 * 64 * 8, 2 * 4 * 2 * 64 * 8
+    w_frag = torch.empty(frag0 + (n_layers - 1) * frag_l, dtype=torch.float16, device=dev)
+    w_un = torch.empty(n_layers, dtype=torch.float32, device=dev)
+    bias_acc = torch.empty(n_layers, 64, dtype=torch.float32, device=dev)
+    final = made.final_layer
+    stage_w = [torch.zeros(64, 32 if i == 0 else 64, dtype=torch.float32, device=dev) for i in range(n_layers)]
+    stage_b = [torch.zeros(64, dtype=torch.float32, device=dev) for _ in range(n_layers)]
+
+    def stage():
+        with torch.no_grad():
+            for i, lin in enumerate(hidden_layers):
+                stage_w[i][:lin.out_features, :lin.in_features].copy_(lin.weight * lin.mask)
+                stage_b[i][:lin.out_features].copy_(lin.bias)
+            w = final.weight * final.mask
+            hf = final.in_features
+            stage_w[-1][:features, :hf].copy_(w[1::2])            # shift rows (parameter 1 of every dim)
+            stage_w[-1][32:32 + features, :hf].copy_(w[0::2])     # unconstrained-scale rows (parameter 0)
+            stage_b[-1][:features].copy_(final.bias[1::2])
+            stage_b[-1][32:32 + features].copy_(final.bias[0::2])
+
+    pack = DevicePack(dev)
+    off = 0
+    for i in range(n_layers):
+        size = frag0 if i == 0 else frag_l
+        pack.add(PACK_HIDDEN, stage_w[i], stage_b[i], w_frag[off:off + size], w_un[i:i + 1], bias_acc[i],
+                 nks=k0s if i == 0 else 2, nt=4, track=False)
+        off += size
+    for lin in hidden_layers + [final]:
+        pack.sources += [lin.weight, lin.bias]
+    pack.prepare.append(stage)
+    return pack, (w_frag, w_un, bias_acc)
+
+
 def affine_tail_fits(in_features, num_blocks, d):
     """LDS budget of ``fc_affine_coupling_resnet``: the weight image (initial layer, 2 per block, the final Linear) + one
     [16, D | 1] float tile per wave next to it, 160 KB per CU; D <= 128, <= 3 blocks."""
@@ -768,7 +823,7 @@ def affine_tail_fits(in_features, num_blocks, d):
 
 def affine_tail_activation(code):
     """Scale activations ``fc_affine_coupling_resnet`` evaluates itself."""
-    return code in (AFFINE_SIGMOID_PLUS2, AFFINE_SOFTPLUS_CLAMP3, AFFINE_ADDITIVE)
+    return code in (AFFINE_SIGMOID_PLUS2, AFFINE_SOFTPLUS_CLAMP3, AFFINE_ADDITIVE, AFFINE_MAF_SOFTPLUS)
 
 
 def affine_coupling_resnet(inputs, id_cols, tr_cols, packed, in_features, num_blocks, activation, inverse=False,

@@ -160,6 +160,60 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
     def _output_dim_multiplier(self):
         return 2
 
+    # ---- density direction in ONE kernel (round 3) ------------------------------------------------------------------
+    # One MADE pass yields the parameters of all dims, so the forward map is a coupling layer that reads and transforms
+    # every column: hidden stack, masked final Linear and the affine bijector run in fc_affine_coupling_resnet on
+    # pre-masked weights (the README flow, examples/toy_2d.py: 3 launches per layer instead of ~7).
+    def _one_kernel_ok(self, inputs, context):
+        net = self.autoregressive_net
+        return (context is None and isinstance(net, made_module.MADE) and inputs.dim() == 2 and inputs.is_cuda
+                and inputs.dtype == torch.float32 and inputs.shape[0] >= ops.HIDDEN_ROWS and inputs.shape[1] <= 32
+                and inputs.shape[1] == net.initial_layer.in_features
+                and options.get("fused_hidden") and options.get("fused_final_layer")
+                and not hasattr(net, "context_layer") and len(net.blocks) <= 3 and net.hip_hidden_supported(None)
+                and ops.activation_code(net.activation) is not None
+                and ops.activation_code(net.activation)[0] == ops.ACT_RELU
+                and ops.affine_tail_fits(inputs.shape[1], len(net.blocks), inputs.shape[1])
+                and not ops.has_hooks(net) and not self._needs_grad(inputs))
+
+    def _one_kernel(self, inputs, total=None):
+        net = self.autoregressive_net
+        features = inputs.shape[1]
+        where = tuple(p.data_ptr() for p in ops.param_list(net))
+        plan = getattr(self, "_tail_image", None)
+        if plan is None or plan[0] != where:
+            pack, packed = ops.device_pack_made_affine(net, features)
+            cols = torch.arange(features, dtype=torch.int32, device=inputs.device)
+            plan = self._tail_image = [where, pack, packed, cols]
+        plan[1].refresh()
+        n = inputs.shape[0]
+        body = n - n % ops.HIDDEN_ROWS
+        args = (plan[3], plan[3], plan[2], features, len(net.blocks), ops.AFFINE_MAF_SOFTPLUS)
+        if body == n:
+            return ops.affine_coupling_resnet(inputs, *args, logabsdet_accum=total)
+        out_a, lad_a = ops.affine_coupling_resnet(inputs[:body], *args,
+                                                  logabsdet_accum=None if total is None else total[:body])
+        rest = inputs[body:].contiguous()          # the < 16 leftover rows: conditioner on PyTorch + the stand-alone kernel
+        out_b, lad_b = self._elementwise_forward(rest, net(rest, None))
+        outputs = torch.cat((out_a, out_b))
+        if total is None:
+            return outputs, torch.cat((lad_a, lad_b))
+        total[body:] += lad_b
+        return outputs, total
+
+    def forward(self, inputs, context=None):
+        if self._one_kernel_ok(inputs, context):
+            return self._one_kernel(inputs)
+        return super().forward(inputs, context)
+
+    def _apply_accumulate(self, inputs, context, inverse, total):
+        """CompositeTransform fast path: the kernel adds this layer's logabsdet onto ``total`` itself."""
+        if not inverse and self._one_kernel_ok(inputs, context):
+            return self._one_kernel(inputs, total)[0]
+        outputs, logabsdet = self.inverse(inputs, context) if inverse else self.forward(inputs, context)
+        total += logabsdet
+        return outputs
+
     def _elementwise_forward(self, inputs, autoregressive_params):
         return ops.affine_coupling(inputs, autoregressive_params, None,
                                    activation=ops.AFFINE_MAF_SOFTPLUS, inverse=False)

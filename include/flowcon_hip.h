@@ -173,7 +173,9 @@ int fc_resnet_hidden_packed(const float* x, float* h, const int32_t* id_cols, co
  *   w_frag / w_unscale / bias_acc: the image of fc_resnet_hidden_packed with ONE MORE 64 x 64 layer, the final Linear
  *   re-ordered as rows 0..31 = its shift rows of dims 0..31, rows 32..63 = its scale rows (zero rows beyond d_t; additive:
  *   no scale rows), i.e. L = 2 + 2 num_blocks layers.
- * scale_activation: FC_AFFINE_SIGMOID_PLUS2, FC_AFFINE_SOFTPLUS_CLAMP3 or FC_AFFINE_ADDITIVE.  ReLU conditioner, hidden == 64
+ * scale_activation: FC_AFFINE_SIGMOID_PLUS2, FC_AFFINE_SOFTPLUS_CLAMP3, FC_AFFINE_ADDITIVE, or FC_AFFINE_MAF_SOFTPLUS (the density
+ * direction of a masked-autoregressive affine layer, autoregressive.py:97-129: id_cols = tr_cols = all columns, weights pre-masked,
+ * final-layer rows in the same [shift 32 | scale 32] order).  ReLU conditioner, hidden == 64
  * (narrower: zero-padded), num_blocks <= 3, in_features <= 64, d_t <= 32, d <= 128, n % 16 == 0; the weight image and the
  * waves' row tiles (8 x 16 x (d | 1) floats) must fit the CU's 160 KB of LDS (else hipErrorInvalidConfiguration). */
 int fc_affine_coupling_resnet(const float* x, float* y, const int32_t* id_cols, const int32_t* tr_cols,

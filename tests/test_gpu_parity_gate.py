@@ -1,9 +1,9 @@
 """The parity gate of the north star, encoded ("Next round" #4):
 
 * BASELINE.json configs[2] at its FULL size (N = 2^20): oracle spot check + size-independent properties on all rows;
-* the 32-layer flow with default and with trained-like weights:  GPU error against the float64 truth <= 1.5 x the
-  reference-f32 path's own error against it, and >= 99 % of the transformed samples within 1e-5 (relative) of the
-  f32 reference -- the 1e-5 target sits at the reference's own float32 noise floor, so this pair of
+* the 32-layer flow with default and with trained-like weights:  rms / p99 / p99.99 of the GPU error against the float64
+  truth <= 1.1 x (max <= 1.5 x) the reference-f32 path's own, and >= 99 % of the transformed samples within 1e-5
+  (relative) of the f32 reference -- the 1e-5 target sits at the reference's own float32 noise floor, so this pair of
   assertions IS the target, not a widened tolerance;
 * the reference's known answers on the GPU kernels (identity initialisation, the linspace bin search), and inputs exactly
   on interior knots against vectors generated from the imported reference (tests/golden/make_golden.py);
@@ -45,20 +45,28 @@ def _rel(a, b):
 
 @pytest.mark.parametrize("weights", ["default_init", "trained_like"])
 def test_cfg3_parity_gate_against_float64(weights, cfg3_flows, device):
-    """err(GPU vs f64) <= 1.5 x err(reference-f32 vs f64), and >= 99 % of sample elements within 1e-5 of the f32
-    reference, after all 32 layers."""
+    """After all 32 layers, on 8 192 rows: the DISTRIBUTION of the GPU path's error against float64 is no worse than the
+    float32 reference path's own -- rms, p99 and p99.99 within 1.1 x (measured 0.60 - 0.72 x, tools/probe/parity_stats.py:
+    the two-sided knot sums beat ATen's cumsum), the maximum (one realisation of a heavy tail) within 1.5 x -- and >= 99 %
+    of the sample elements within 1e-5 (relative) of the f32 reference."""
     flow_cpu = cfg3_flows[0 if weights == "default_init" else 1]
     gen = torch.Generator().manual_seed(7)
-    x = torch.randn(2048, 64, generator=gen)
+    x = torch.randn(8192, 64, generator=gen)
     stack_cpu = flow_cpu._transform
     with torch.no_grad():
         z32, lad32 = O.transform_apply(stack_cpu, x.clone())
         z64, lad64 = O.transform_apply(copy.deepcopy(stack_cpu).double(), x.double())
         z, lad = copy.deepcopy(stack_cpu).to(device).eval()(x.to(device))
-    gpu_z, ref_z = float(_rel(z, z64).max()), float(_rel(z32, z64).max())
-    gpu_l, ref_l = float(_rel(lad, lad64).max()), float(_rel(lad32, lad64).max())
-    assert gpu_z <= 1.5 * ref_z, ("samples vs f64: GPU %.3g, reference f32 %.3g" % (gpu_z, ref_z))
-    assert gpu_l <= 1.5 * ref_l, ("logabsdet vs f64: GPU %.3g, reference f32 %.3g" % (gpu_l, ref_l))
+
+    def stats(e):
+        e = e.flatten()
+        return {"rms": float(e.pow(2).mean().sqrt()), "p99": float(e.kthvalue(int(e.numel() * 0.99)).values),
+                "p99.99": float(e.kthvalue(int(e.numel() * 0.9999)).values), "max": float(e.max())}
+
+    for what, got, ref32, ref64 in (("samples", z, z32, z64), ("logabsdet", lad, lad32, lad64)):
+        gpu, ref = stats(_rel(got, ref64)), stats(_rel(ref32, ref64))
+        for key, factor in (("rms", 1.1), ("p99", 1.1), ("p99.99", 1.1), ("max", 1.5)):
+            assert gpu[key] <= factor * ref[key], ("%s vs f64, %s: GPU %.3g, reference f32 %.3g" % (what, key, gpu[key], ref[key]))
     within = float((_rel(z, z32) <= 1e-5).double().mean())
     assert within >= 0.99, "only %.4f of the sample elements within 1e-5 of the f32 reference" % within
     # max |delta logabsdet| (BASELINE.json's second metric), relative to totals of order 100

@@ -193,3 +193,46 @@ def test_paranoid_caches_see_data_writes_without_invalidation(device, hidden, bi
             y_ref, lad_ref = t(x)                  # conditioner on PyTorch kernels: always the live weights
     assert float((y0 - y_ref).abs().max()) > 1e-3, "the weight change must be visible"
     assert float((y1 - y_ref).abs().max()) <= 2e-5 and float((lad1 - lad_ref).abs().max()) <= 3e-4
+
+
+@pytest.mark.parametrize("features,hidden,blocks,n", [(2, 4, 2, 4096), (12, 32, 2, 257), (32, 64, 3, 1000), (7, 50, 0, 64)])
+def test_maf_affine_density_direction_in_one_kernel(device, features, hidden, blocks, n):
+    """Round 3: the forward (density) direction of MaskedAffineAutoregressiveTransform runs hidden stack + masked final
+    Linear + bijector in fc_affine_coupling_resnet on pre-masked weights (README flow: BASELINE.json configs[0]).
+    Against the oracle, against the three-kernel path, with leftover rows, inside a CompositeTransform (in-kernel
+    logabsdet accumulation), and after a weight update."""
+    from flowconductor_amd import ops, options
+    from oracle import torch_oracle as O
+
+    torch.manual_seed(features + hidden)
+    t_cpu = T.MaskedAffineAutoregressiveTransform(features=features, hidden_features=hidden, num_blocks=blocks).eval()
+    with torch.no_grad():
+        for p in t_cpu.parameters():
+            p.mul_(1.5)
+    t = copy.deepcopy(t_cpu).to(device)
+    x = torch.randn(n, features)
+    with torch.no_grad():
+        y_ref, lad_ref = O.transform_apply(t_cpu, x.clone())
+        with ops.KernelTimer("fc_affine_coupling_resnet") as one, ops.KernelTimer("fc_affine") as plain:
+            y, lad = t(x.to(device))
+        assert len(one.pairs) == 1 and len(plain.pairs) == (1 if n % 16 else 0)
+        with options.override(fused_final_layer=False):
+            y3, lad3 = t(x.to(device))
+        comp = T.CompositeTransform([t, T.ReversePermutation(features), t])
+        z, total = comp(x.to(device))
+        z_ref, total_ref = O.transform_apply(T.CompositeTransform([t_cpu, T.ReversePermutation(features), t_cpu]), x.clone())
+        xb, lad_b = t.inverse(y)
+    scale = max(1.0, float(y_ref.abs().max()))
+    assert float((y.cpu() - y_ref).abs().max()) <= 2e-5 * scale and float((lad.cpu() - lad_ref).abs().max()) <= 1e-4
+    assert float((y - y3).abs().max()) <= 2e-5 * scale and float((lad - lad3).abs().max()) <= 1e-4
+    assert float((z.cpu() - z_ref).abs().max()) <= 1e-4 * max(1.0, float(z_ref.abs().max()))
+    assert float((total.cpu() - total_ref).abs().max()) <= 3e-4
+    assert float((xb - x.to(device)).abs().max()) <= 1e-3 and float((lad + lad_b).abs().max()) <= 1e-3
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(0.5)                            # in-place update: version counters move, the image is re-packed
+        for p in t_cpu.parameters():
+            p.mul_(0.5)
+        y2, _ = t(x.to(device))
+        y2_ref, _ = O.transform_apply(t_cpu, x.clone())
+    assert float((y2.cpu() - y2_ref).abs().max()) <= 2e-5 * max(1.0, float(y2_ref.abs().max()))

@@ -113,8 +113,12 @@ for c in range(cases):
         with torch.no_grad():
             back, _ = td.inverse(y)
             rb, _ = O.transform_apply(t, ry.clone(), inverse=True)
-        ok = ~(torch.isnan(rb) | torch.isnan(back.cpu()))
-        assert int((~ok).sum()) <= 2, (kind, "nan", d, k, n)
+        # the reference itself returns NaN where its inverse has no real root in float32 (e.g. the cubic spline's a -> 0
+        # fallback: the quadratic part alone cannot reach y, cubic.py:235-241 -- 72 elements in seed 4 / case 33); the
+        # kernel may add at most a couple of borderline ones to those
+        nan_ref, nan_gpu = torch.isnan(rb), torch.isnan(back.cpu())
+        assert int((nan_gpu & ~nan_ref).sum()) <= 2, (kind, "nan", d, k, n, int(nan_gpu.sum()), int(nan_ref.sum()))
+        ok = ~(nan_ref | nan_gpu)
         rt, rt_ref = md(back.cpu()[ok], x[ok]), md(rb[ok], x[ok])
         assert rt <= 5e-4 * max(1.0, float(x.abs().max())) + 8 * rt_ref, (kind, "round trip", d, k, n, hidden, rt, rt_ref)
     worst[kind] = max(worst.get(kind, 0.0), ey / by, el / bl)
