@@ -79,6 +79,7 @@ __host__ __device__ inline size_t bwd_lds_bytes(int d, int role) {
   return b;
 }
 
+
 template <int K, bool kTails, int kRole>
 __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams q, float inv_div, BwdArgs a) {
   using S = GenShape<K, kTails>;
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   constexpr int PP8 = (PP + 7) / 8 * 8, KK = PP8 / 8;       // role 0: k-steps of the W^T product (8 parameters per lane)
   constexpr int R = kBwdR, H = kBwdH, KS = 2, TS = kBwdTS;
   constexpr bool kDx = kRole != 1, kDw = kRole != 0, kMerged = kRole == 2;    // role 2: both products from one G
+  constexpr bool kBlockwise = kRole == 1 && T > 6;
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   const int D = a.D;
   const int HB = bwd_hb(D, kRole);
@@ -217,10 +219,114 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
     const bool has_next = tile + stride < a.tiles;
     // vmcnt retires in order: rows requested ahead of the fragment loads make the first product wait out an HBM round trip
     // instead of an L2 one, so the roles that have the registers ask for them after their recompute (role 0; role 1 up to K = 8)
-    constexpr bool kFetchLate = kRole == 0 || (kRole == 1 && T <= 6);
+    constexpr bool kFetchLate = kRole == 0 || (kRole == 1 && T <= 6) || kBlockwise;   // (blockwise: between its two blocks)
     if (!kFetchLate && has_next) fetch(tile + stride);
     if (active) {
-      f32x4 acc[2][T];
+      float gp[kBlockwise ? 1 : 2][PP8];
+      auto spline_block = [&](int b, const f32x4 (&accb)[T], float (&gpb)[PP8]) __attribute__((always_inline)) {
+        __builtin_amdgcn_sched_barrier(0);     // the two blocks' register-hungry spline code must not interleave
+        const int row = 16 * b + s16;
+        const int col = cs[(4 * wave + g) & 31];
+        const float xin = xbuf[buf * R * (D + 4) + row * XS + col];
+        float* gslot = gbuf + buf * R * (D + 4) + row * XS + col;
+        const float gyv = *gslot, glr = glb[buf * R + row];
+        const float c = hscale[buf * R + row] * w_un;
+        float p[PP];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const f32x4 bt = bw[t];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p[4 * t + r] = __builtin_fmaf(accb[t][r], c, bt[r]);
+        }
+        float gxv, gpe[3 * K + 1];
+        rq_backward_element_fast<K, kTails>(q, inv_div, p, xin, gyv, glr, gxv, gpe);
+#pragma unroll
+        for (int i = 0; i < PP8; ++i) gpb[i] = (i < P && dim_ok) ? gpe[i < P ? i : 0] : 0.f;
+        if constexpr (kDx) {
+          if (dim_ok) *gslot = gxv;
+#pragma unroll
+          for (int i = 0; i < PP; ++i) gbacc[i] += gpb[i];
+        }
+      };
+      if constexpr (kBlockwise) {
+        // Role 1 at T > 6 (K >= 9): next to the wave's gW accumulators (16 T registers) the two blocks' parameter
+        // accumulators and gradients no longer fit (K = 10: 296 B of spills, 3.15 ms per 2^20 rows against role 0's 1.63).
+        // Here the blocks take turns: product of block b (its own pass over the fragments: they come from L2), its spline
+        // backward, then the next block -- one set of parameter accumulators alive at a time.
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          f32x4 accb[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t) accb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 bh = hfrag(buf, b, 0, ks), bl = hfrag(buf, b, 1, ks);
+            const f16x8* wk_ = wgrp + (size_t)ks * T * 2 * 64;
+            asm volatile("" : "+s"(wk_));
+            const GlobalFrags wk = (GlobalFrags)wk_;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const f16x8 ah = wk[(t * 2 + 0) * 64 + lane], al = wk[(t * 2 + 1) * 64 + lane];
+              accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, accb[t], 0, 0, 0);
+              accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, accb[t], 0, 0, 0);
+              accb[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, accb[t], 0, 0, 0);
+            }
+          }
+          spline_block(b, accb, gp[0]);
+          // ---- this block's share of the gW slice: contraction over ITS 16 samples (v_mfma_f32_16x16x16_f16: lane holds
+          // row / column l & 15, k = 4 (l >> 4) + j) -- same strip and h^T images as the two-block form below
+          const float un_s = hscale[buf * R + 16 * b + s16];
+#pragma unroll
+          for (int i = 0; i < PP; ++i) {
+            gp[0][i] *= un_s;
+            const float m = row16_allmax(fabsf(gp[0][i]));
+            const uint32_t e = (__float_as_uint(m) >> 23) & 255u;
+            const int sh8 = 8 * (i & 3);
+            uint32_t cur = (fsh[i >> 2] >> sh8) & 255u;
+            const uint32_t want = (e >= 11u && e < 255u) ? 265u - e : cur;
+            if (want < cur) {
+              if (cur != 255u) {
+                const int dlt = (int)want - (int)cur;
+                const float resc = dlt < -126 ? 0.f : __uint_as_float((uint32_t)(127 + dlt) << 23);
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) dw[i >> 2][ht][i & 3] *= resc;
+              }
+              fsh[i >> 2] = (fsh[i >> 2] & ~(255u << sh8)) | (want << sh8);
+              cur = want;
+            }
+            gp[0][i] *= cur == 255u ? 1.f : __uint_as_float((cur - 1u) << 23);
+          }
+          _Float16* strip = strips + (size_t)wave * 2 * 16 * TS;
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              _Float16 ph, pl;
+              split2(gp[0][4 * t + r], ph, pl);
+              strip[(size_t)(4 * g + r) * TS + 16 * b + s16] = ph;
+              strip[(size_t)(16 + 4 * g + r) * TS + 16 * b + s16] = pl;
+            }
+            const f16x4 ah = *reinterpret_cast<const f16x4*>(strip + (size_t)s16 * TS + 16 * b + 4 * g);
+            const f16x4 al = *reinterpret_cast<const f16x4*>(strip + (size_t)(16 + s16) * TS + 16 * b + 4 * g);
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+              const _Float16* hb = htbuf + ((size_t)(buf * 2) * H + 16 * ht + s16) * TS + 16 * b + 4 * g;
+              const f16x4 bh = *reinterpret_cast<const f16x4*>(hb);
+              const f16x4 bl = *reinterpret_cast<const f16x4*>(hb + (size_t)H * TS);
+              dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, dw[t][ht], 0, 0, 0);
+              dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, dw[t][ht], 0, 0, 0);
+              dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, dw[t][ht], 0, 0, 0);
+            }
+          }
+          if (b == 0) {      // the next tile's rows: requested half-way, so that they are not carried through block 0
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) fetch(tile + stride);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      f32x4 acc[kBlockwise ? 1 : 2][T];
+      if constexpr (!kBlockwise) {
       // ---- recompute the parameters of both blocks against each weight fragment (the forward kernel's product: one
       // pass over the wave's 24 KB of fragments per tile -- they stream from L2, whose bandwidth bounds this kernel when
       // every block fetches them again) -----------------------------------------------------------------------------
@@ -284,38 +390,16 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
           acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh1, acc[1][t], 0, 0, 0);
         }
       }
-      if constexpr (kFetchLate) {
+      }   // !kBlockwise
+      if constexpr (kFetchLate && !kBlockwise) {
         __builtin_amdgcn_sched_barrier(0);
         if (has_next) fetch(tile + stride);
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---- spline backward of this lane's two elements -> G in registers ------------------------------------------
-      float gp[2][PP8];
+      if constexpr (!kBlockwise) {
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        __builtin_amdgcn_sched_barrier(0);     // the two blocks' register-hungry spline code must not interleave
-        const int row = 16 * b + s16;
-        const int col = cs[(4 * wave + g) & 31];
-        const float xin = xbuf[buf * R * (D + 4) + row * XS + col];
-        float* gslot = gbuf + buf * R * (D + 4) + row * XS + col;
-        const float gyv = *gslot, glr = glb[buf * R + row];
-        const float c = hscale[buf * R + row] * w_un;
-        float p[PP];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const f32x4 bt = bw[t];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) p[4 * t + r] = __builtin_fmaf(acc[b][t][r], c, bt[r]);
-        }
-        float gxv, gpe[3 * K + 1];
-        rq_backward_element_fast<K, kTails>(q, inv_div, p, xin, gyv, glr, gxv, gpe);
-#pragma unroll
-        for (int i = 0; i < PP8; ++i) gp[b][i] = (i < P && dim_ok) ? gpe[i < P ? i : 0] : 0.f;
-        if constexpr (kDx) {
-          if (dim_ok) *gslot = gxv;
-#pragma unroll
-          for (int i = 0; i < PP; ++i) gbacc[i] += gp[b][i];
-        }
+        for (int b = 0; b < 2; ++b) spline_block(b, acc[b], gp[b]);
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (kDx) {
@@ -398,7 +482,7 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
           }
         }
       }
-      if constexpr (kDw) {
+      if constexpr (kDw && !kBlockwise) {
         // ---- gW slice of this wave: (G 2^-T_s)^T x (h 2^T_s), contraction over the tile's 32 samples ---------------
 #pragma unroll
         for (int b = 0; b < 2; ++b) {

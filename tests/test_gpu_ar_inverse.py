@@ -142,7 +142,9 @@ def test_rq_autoregressive_forward_on_fused_kernels(features, n, device, monkeyp
 
 def test_readme_maf_flow_runs_its_made_on_the_hidden_kernel(device):
     """BASELINE configs[0] (the README flow: 2 x [MAF(features=2, hidden_features=4), RandomPermutation]): a MADE with
-    4 hidden units runs zero-padded in the 64-wide hidden-layer kernel; log_prob and samples against the oracle."""
+    4 hidden units runs zero-padded in the 64-wide matrix-core kernels -- the density direction as ONE kernel per layer
+    (fc_affine_coupling_resnet on pre-masked weights, round 3), the sampling direction's D passes on fc_resnet_hidden;
+    log_prob and samples against the oracle."""
     from flowconductor_amd import distributions, flows, ops, transforms
 
     torch.manual_seed(0)
@@ -161,11 +163,13 @@ def test_readme_maf_flow_runs_its_made_on_the_hidden_kernel(device):
     flow = flow.to(device)
     with torch.no_grad():
         assert flow._transform._transforms[0].autoregressive_net.hip_hidden_supported()
-        with ops.KernelTimer("fc_resnet_hidden") as timer:
+        with ops.KernelTimer("fc_affine_coupling_resnet") as timer, ops.KernelTimer("fc_resnet_hidden") as hidden_timer:
             lp = flow.log_prob(x.to(device))
-        assert len(timer.pairs) == 2, "the MADE hidden stacks did not run in fc_resnet_hidden"
+        assert len(timer.pairs) == 2 and not hidden_timer.pairs, "the MAF layers did not run as one kernel each"
         z, _ = flow._transform(x.to(device))
-        back, _ = flow._transform.inverse(z)
+        with ops.KernelTimer("fc_resnet_hidden") as hidden_timer:
+            back, _ = flow._transform.inverse(z)
+        assert len(hidden_timer.pairs) == 4, "the MADE hidden stacks of the inverse passes did not run in fc_resnet_hidden"
     assert maxdiff(lp, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
     assert maxdiff(z, z_ref) <= 2e-5 * max(1.0, float(z_ref.abs().max()))
     assert maxdiff(back, x) <= 1e-4 * max(1.0, float(x.abs().max()))

@@ -121,8 +121,8 @@ def cfg1(device, steps=50, warmup=10):
     eager_s, lp = _time_gpu(lambda: flow.log_prob(x), steps, warmup)
     graphed = GraphedCall(flow.log_prob, x, clone=False)
     graph_s, lp_g = _time_gpu(lambda: graphed(x), steps, warmup)
-    km = _kernel_ms(lambda: flow.log_prob(x), ["fc_affine"])
-    ms, launches = km["fc_affine"]
+    km = _kernel_ms(lambda: flow.log_prob(x), ["fc_affine_coupling_resnet"])
+    ms, launches = km["fc_affine_coupling_resnet"]
     with torch.no_grad():
         ref = O.flow_log_prob(flow_cpu, x.cpu())
     xc = x.cpu()
@@ -131,9 +131,11 @@ def cfg1(device, steps=50, warmup=10):
            "eager": {"value": n / eager_s, "ms_per_step": eager_s * 1e3},
            "hip_graph": {"value": n / graph_s, "ms_per_step": graph_s * 1e3, "launches_per_replay": 1},
            "dtype": "f32",
-           "roofline": _hbm_roofline("affine tile kernel", "fc_affine", ms, launches, 40 * n,
-                                     "B = 4*d_t*(P+2)+8 = 40 B per sample and layer (SURVEY 8d); at N = 4096 the launch "
-                                     "is latency-bound: 164 KB per launch cannot load 256 CUs", bound="launch_latency"),
+           "roofline": _hbm_roofline("resnet_hidden_kernel (coupling tail, MAF rows)", "fc_affine_coupling_resnet", ms, launches,
+                                     40 * n,
+                                     "one kernel per MAF layer (pre-masked MADE + affine bijector); B = 4*d_t*(P+2)+8 = 40 B per "
+                                     "sample and layer (SURVEY 8d); at N = 4096 the launch is latency-bound: 164 KB per launch "
+                                     "cannot load 256 CUs", bound="launch_latency"),
            "parity": {"max_abs_dlog_prob": _maxdiff(lp, ref), "max_abs_dlog_prob_graphed": _maxdiff(lp_g, ref),
                       "rows": n},
            "cpu_baseline": _cpu_baseline(lambda: O.flow_log_prob(flow_cpu, xc), n, "4096 samples per call")}
