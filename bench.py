@@ -50,7 +50,7 @@ def build_flow():
     return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([FEATURES])).eval()
 
 
-TRAFFIC_PROFILE = "profiles/r02c_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"
 # kernel symbol (substring) each C-ABI entry launches in this flow: the committed PMC profile must have counted THAT
 # kernel, or its number does not belong in this line
 EXPECTED_KERNELS = {"fc_rq_spline_fused_linear": "rq_fused_linear_kernel3", "fc_resnet_hidden": "resnet_hidden_kernel",
@@ -417,10 +417,10 @@ def main():
                                "algorithmic_bytes_per_launch": f_bytes,
                                "share_of_step": sum(fused_ms) / (1e3 * elapsed / args.steps),
                                "binding_resource": "valu_issue",
-                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r02c_fused_sq_counters.txt; "
+                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r03_fused_sq_counters.txt; "
                                           "`frac` is the distance to the HBM roof the contract asks for, "
                                           "`issue_bound.frac` the share of the SIMDs' issue cycles in use",
-                               "issue_bound": issue_bound("profiles/r02c_fused_sq_counters.txt", f_avg, rows_per_launch, 3.6),
+                               "issue_bound": issue_bound("profiles/r03_fused_sq_counters.txt", f_avg, rows_per_launch, 3.6),
                                # BASELINE.md section 4 prices a coupling bijector at B = 4 d_t (P + 2) + 8 bytes per
                                # sample and layer (parameters read from HBM).  The fused kernel never moves them; in
                                # that accounting it delivers:
@@ -448,7 +448,7 @@ def main():
                                           "algorithmic_bytes_per_launch": h_bytes,
                                           "share_of_step": sum(hidden_ms) / (1e3 * elapsed / args.steps),
                                           "binding_resource": "mfma_issue / dependent-latency (a wave walks the layers serially)",
-                                          "issue_bound": issue_bound("profiles/r02c_hidden_sq_counters.txt", h_avg,
+                                          "issue_bound": issue_bound("profiles/r03_hidden_sq_counters.txt", h_avg,
                                                                      rows_per_launch, 2.6),
                                           "matrix_pipe": {"algorithmic_tflops": hflops / (h_avg * 1e-3) / 1e12,
                                                           "executed_tflops": 3.0 * hflops / (h_avg * 1e-3) / 1e12,

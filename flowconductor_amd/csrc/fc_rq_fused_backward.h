@@ -61,9 +61,13 @@ struct BwdArgs {
 // compiler otherwise emits flat loads, which also count on lgkmcnt and are waited for before every LDS read
 typedef const __attribute__((address_space(1))) f16x8* GlobalFrags;
 
-// row strides of the images read as b128 fragments are 32 mod 64 bytes (conflict-free under ds_read_b128's four non-contiguous
-// 16-lane groups, tools/lds_conflicts.py): h rows 160 B, transposed images (TS f16 per row) 96 B
-constexpr int kBwdH = 64, kBwdR = kGenRows, kBwdTS = 32 + 16;
+// LDS strides (tools/lds_conflicts.py; ds_read_b128 is served in four non-contiguous 16-lane groups: conflict-free rows need a
+// stride of 32 mod 64 bytes): h rows 160 B; the transposed h image [hidden][32 samples] 96 B (TSh: its 48 fragment reads per tile
+// conflict-free, its 8 transposing 16-bit stores 32-way; at 80 B the reads are 2-way, which costs more in all); the wave-private
+// G^T strips 80 B (TS: their 96 16-bit stores per tile conflict-free, their 12 fragment reads 2-way; at 96 B the stores are 2-way).
+// Tried and dropped: 64-byte rows with the 16-byte chunks XOR-swizzled by the row (conflict-free reads, 8-way stores) -- the
+// address arithmetic costs the registers role 1 does not have (K = 10: +52 B of spills, 2.64 -> 2.85 ms).
+constexpr int kBwdH = 64, kBwdR = kGenRows, kBwdTS = 32 + 8, kBwdTSh = 32 + 16;
 // f16 per h row: 80 (160 B, conflict-free); role 0 at D > 124 keeps the 144 B of rounds 1-2 (2-way on the fragment reads):
 // its 68 KB of partial gh tiles leave no room for the wider rows next to a 128-column x / gy tile pair
 __host__ __device__ inline int bwd_hb(int d, int role) { return (role == 0 && d > 124) ? kBwdH + 8 : kBwdH + 16; }
@@ -75,7 +79,7 @@ __host__ __device__ inline size_t bwd_lds_bytes(int d, int role) {
   b += 32 * 4 + (size_t)32 * 52 * 4;                        // cols, bias image
   if (role == 0) b += (size_t)8 * kBwdR * (kBwdH + 4) * 4;  // partial gh tiles of the 8 waves
   if (role == 2) b += (size_t)2 * kBwdR * kBwdH * 4;        // merged: gh tiles summed by LDS atomics, ring of two
-  if (role != 0) b += (size_t)2 * 2 * kBwdH * kBwdTS * 2 + (size_t)8 * 2 * 16 * kBwdTS * 2;   // h^T [buf][piece][64][40], G^T strips
+  if (role != 0) b += (size_t)2 * 2 * kBwdH * kBwdTSh * 2 + (size_t)8 * 2 * 16 * kBwdTS * 2;   // h^T [buf][piece][64][40], G^T strips
   return b;
 }
 
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   using S = GenShape<K, kTails>;
   constexpr int P = S::P, PP = S::PP, T = S::T;
   constexpr int PP8 = (PP + 7) / 8 * 8, KK = PP8 / 8;       // role 0: k-steps of the W^T product (8 parameters per lane)
-  constexpr int R = kBwdR, H = kBwdH, KS = 2, TS = kBwdTS;
+  constexpr int R = kBwdR, H = kBwdH, KS = 2, TS = kBwdTS, TSh = kBwdTSh;
   constexpr bool kDx = kRole != 1, kDw = kRole != 0, kMerged = kRole == 2;    // role 2: both products from one G
   constexpr bool kBlockwise = kRole == 1 && T > 6;
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
   float* bias_lds = reinterpret_cast<float*>(cs + 32);                            // [8][4][PP] (<= 32 * 52)
   float* part = bias_lds + 32 * 52;                                               // role 0: [8][R][H + 4]; role 2: [2][R][H]
   _Float16* htbuf = reinterpret_cast<_Float16*>(bias_lds + 32 * 52 + (kMerged ? 2 * R * H : 0));   // roles 1, 2: [2][2][H][TS]
-  _Float16* strips = htbuf + (size_t)2 * 2 * H * TS;                              // roles 1, 2: [8 waves][2][16][TS]
+  _Float16* strips = htbuf + (size_t)2 * 2 * H * TSh;                             // roles 1, 2: [8 waves][2][16][TS]
 
   // (the wave index as a scalar: fragment, bias and strip addresses then are SGPR bases + one lane offset instead of two dozen
   //  64-bit VGPR pointers -- those were spilled, and every fragment load of the recompute waited for its address reload)
@@ -166,11 +170,11 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
       *reinterpret_cast<f16x4*>(dst) = p0;
       *reinterpret_cast<f16x4*>(dst + (size_t)R * HB) = p1;
       if constexpr (kDw) {   // the same scaled pieces, transposed: [hidden][sample]
-        _Float16* dt = htbuf + ((size_t)(buf * 2) * H + c) * TS + r;
+        _Float16* dt = htbuf + ((size_t)(buf * 2) * H + c) * TSh + r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          dt[(size_t)j * TS] = p0[j];
-          dt[((size_t)H + j) * TS] = p1[j];
+          dt[(size_t)j * TSh] = p0[j];
+          dt[((size_t)H + j) * TSh] = p1[j];
         }
       }
       if ((tid & 15) == 0) hscale[buf * R + r] = un;
@@ -310,9 +314,9 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
             const f16x4 al = *reinterpret_cast<const f16x4*>(strip + (size_t)(16 + s16) * TS + 16 * b + 4 * g);
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
-              const _Float16* hb = htbuf + ((size_t)(buf * 2) * H + 16 * ht + s16) * TS + 16 * b + 4 * g;
+              const _Float16* hb = htbuf + ((size_t)(buf * 2) * H + 16 * ht + s16) * TSh + 16 * b + 4 * g;
               const f16x4 bh = *reinterpret_cast<const f16x4*>(hb);
-              const f16x4 bl = *reinterpret_cast<const f16x4*>(hb + (size_t)H * TS);
+              const f16x4 bl = *reinterpret_cast<const f16x4*>(hb + (size_t)H * TSh);
               dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, dw[t][ht], 0, 0, 0);
               dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, dw[t][ht], 0, 0, 0);
               dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, dw[t][ht], 0, 0, 0);
@@ -531,9 +535,9 @@ __global__ __launch_bounds__(kGenThreads) void rq_fused_backward_kernel(RQParams
           const f16x8 al = *reinterpret_cast<const f16x8*>(strip + (size_t)(16 + s16) * TS + 8 * g);
 #pragma unroll
           for (int ht = 0; ht < 4; ++ht) {
-            const _Float16* hb = htbuf + ((size_t)(buf * 2) * H + 16 * ht + s16) * TS + 8 * g;
+            const _Float16* hb = htbuf + ((size_t)(buf * 2) * H + 16 * ht + s16) * TSh + 8 * g;
             const f16x8 bh = *reinterpret_cast<const f16x8*>(hb);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(hb + (size_t)H * TS);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(hb + (size_t)H * TSh);
             dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, dw[t][ht], 0, 0, 0);
             dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, dw[t][ht], 0, 0, 0);
             dw[t][ht] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, dw[t][ht], 0, 0, 0);

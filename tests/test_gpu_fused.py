@@ -457,9 +457,12 @@ def test_made_hidden_stack_on_hip_kernel(kind, inverse, device, monkeypatch):
     fn = t.inverse if inverse else t.forward
     with torch.no_grad():
         assert t.autoregressive_net.hip_hidden_supported()
-        with ops.KernelTimer("fc_resnet_hidden") as timer:
+        with ops.KernelTimer("fc_resnet_hidden") as timer, ops.KernelTimer("fc_affine_coupling_resnet") as one:
             y, lad = fn(x.to(device))
-        assert len(timer.pairs) == (6 if inverse else 1), "the hidden-layer kernel did not run"
+        if kind == "maf" and not inverse:      # round 3: the affine form's density direction is ONE kernel (hidden stack inside)
+            assert len(one.pairs) == 1 and not timer.pairs, "the one-kernel MAF path did not run"
+        else:
+            assert len(timer.pairs) == (6 if inverse else 1), "the hidden-layer kernel did not run"
         monkeypatch.setitem(options._values, "fused_hidden", False)
         y2, lad2 = fn(x.to(device))
     scale = max(1.0, float(ref_y.abs().max()))
