@@ -105,9 +105,10 @@ struct HiddenLds {
 // as their matrix and vector instructions take to issue, and the reads sit right before the MFMAs that need them.
 // kTail: the affine coupling layer's final Linear + bijector as a tail of the stack (one kernel per coupling layer; the
 // image is 16 KB larger and every wave stages its 16 rows in LDS: one workgroup per CU).
-template <int NB, int K0S, int kCtx, int kAct, int BPW, int kTail = 0>
+// XVT: 16-byte pieces of a 16-row chunk of x per lane the tail kernels keep in registers (D <= 16 XVT)
+template <int NB, int K0S, int kCtx, int kAct, int BPW, int kTail = 0, int XVT = 8>
 __global__ __launch_bounds__(512, (kCtx || BPW > 1 || kTail) ? 2 : 4) void resnet_hidden_kernel(HiddenArgs a) {
-  static_assert(!kTail || (kCtx == 0 && BPW == 1), "the coupling tail: no context, one block per wave");
+  static_assert(!kTail || kCtx == 0, "the coupling tail: no context");
   using L = HiddenLds<NB, K0S, kCtx, kTail>;
   constexpr bool kPrefetchX = FC_HIDDEN_PREFETCH_X && (K0S == 1 || kCtx != 0 || BPW > 1);   // (16 more live registers spill in the 64-input kernels without a context at one block per wave: 128-register budget)
   extern __shared__ __attribute__((aligned(16))) unsigned char hsmem[];
@@ -383,14 +384,17 @@ __global__ __launch_bounds__(512, (kCtx || BPW > 1 || kTail) ? 2 : 4) void resne
   };
   if constexpr (kTail) {
     // ---- one affine coupling layer per launch -------------------------------------------------------------------------
-    // The wave's 16 rows (one contiguous 64 D-byte chunk of x) pass through a wave-private LDS tile: coalesced 16-byte
+    // The wave's BPW x 16 rows (contiguous 64 D-byte chunks of x) pass through wave-private LDS tiles: coalesced 16-byte
     // loads in, the conditioner's inputs and the transformed columns picked from the tile, the results written back into
     // it, coalesced 16-byte stores out -- the identity columns ride along.  (Per-lane 4-byte gathers / scatters at a
     // column stride cost more address-path time than the whole stack.)  Row stride D | 1: conflict-free column reads.
+    // BPW = 2 (round 3): the kernel lives at two waves per SIMD anyway (its weight image leaves room for one workgroup
+    // per CU); two blocks per wave give every serial layer chain a second, independent one to overlap with, and every
+    // weight fragment read from LDS serves both.
     const int TS = D | 1, wrap = TS - D;
-    float* tile = reinterpret_cast<float*>(hsmem + ((L::kBytes + 15) & ~size_t(15))) + (size_t)wave * 16 * TS;
+    float* tile = reinterpret_cast<float*>(hsmem + ((L::kBytes + 15) & ~size_t(15))) + (size_t)wave * BPW * 16 * TS;
     const int chunk4 = 4 * D;                        // float4 per 16-row chunk; this lane owns pieces lane + 64 k
-    constexpr int XV = 8;                            // D <= 128
+    constexpr int XV = XVT;                          // D <= 16 XV (D <= 128)
     int toff[XV], tcol[XV];
 #pragma unroll
     for (int k = 0; k < XV; ++k) {
@@ -404,112 +408,152 @@ __global__ __launch_bounds__(512, (kCtx || BPW > 1 || kTail) ? 2 : 4) void resne
       for (int k = 0; k < XV; ++k)
         if (lane + 64 * k < chunk4) raw[k] = src[lane + 64 * k];
     };
+    const int64_t groups = (a.blocks16 + BPW - 1) / BPW;
     const int64_t nw = (int64_t)gridDim.x * (kHidThreads / 64);
     const int64_t first = (int64_t)blockIdx.x * (kHidThreads / 64) + wave;
-    float4 raw[XV];
-    if (first < a.blocks16) fetch_rows(first, raw);
-    for (int64_t blk = first; blk < a.blocks16; blk += nw) {
+    // block b of group grp; the last group of an odd count repeats its first block (computed twice, stored once)
+    auto blk_of = [&](int64_t grp, int b) {
+      const int64_t blk = grp * BPW + b;
+      return blk < a.blocks16 ? blk : a.blocks16 - 1;
+    };
+    float4 raw[BPW][XV];
+    if (first < groups) {
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) fetch_rows(blk_of(first, b), raw[b]);
+    }
+    int tc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int dim = 8 * g + e;
+      tc[e] = a.tr_cols[dim < a.d_t ? dim : 0];
+    }
+    for (int64_t grp = first; grp < groups; grp += nw) {
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k = 0; k < XV; ++k)
-        if (lane + 64 * k < chunk4) {
-          const float v[4] = {raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+      for (int b = 0; b < BPW; ++b)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) tile[toff[k] + j + (tcol[k] + j >= D ? wrap : 0)] = v[j];
-        }
-      __builtin_amdgcn_wave_barrier();
-      if (blk + nw < a.blocks16) fetch_rows(blk + nw, raw);        // the next block's rows, one iteration ahead
-      const float* trow = tile + s16 * TS;
-      f32x4 xin[1][4];
+        for (int k = 0; k < XV; ++k)
+          if (lane + 64 * k < chunk4) {
+            const float v[4] = {raw[b][k].x, raw[b][k].y, raw[b][k].z, raw[b][k].w};
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ks = t >> 1, j = 4 * (t & 1) + r;
-          float v = 0.f;
-          if (ks < K0S) {
-            const int c = mycol[ks < K0S ? ks : 0][j];
-            v = c >= 0 ? trow[c] : 0.f;
+            for (int j = 0; j < 4; ++j) tile[b * 16 * TS + toff[k] + j + (tcol[k] + j >= D ? wrap : 0)] = v[j];
           }
-          xin[0][t][r] = v;
-        }
-      float xt[8];
-      int tc[8];
+      __builtin_amdgcn_wave_barrier();
+      if (grp + nw < groups) {                                      // the next group's rows, one iteration ahead
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int dim = 8 * g + e;
-        tc[e] = a.tr_cols[dim < a.d_t ? dim : 0];
-        xt[e] = trow[tc[e]];
+        for (int b = 0; b < BPW; ++b) fetch_rows(blk_of(grp + nw, b), raw[b]);
       }
-      f16x8 bh[1][2], bl[1][2];
-      f32x4 acc[1][4], h[1][4], tmid[1][4];
-      float un = make_operand(xin[0], bh[0], bl[0]);
-      layer(0, K0S, bh, bl, acc);
-      finish(0, un, acc[0], h[0]);
+      f32x4 xin[BPW][4];
+      float xt[BPW][8];
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        f32x4 act[4];
-        activate16(h[0], act);
-        un = make_operand(act, bh[0], bl[0]);
-        layer(L::kFrag0 + (2 * nb) * L::kFragL, 2, bh, bl, acc);
-        finish(1 + 2 * nb, un, acc[0], tmid[0]);
-        activate16(tmid[0], act);
-        un = make_operand(act, bh[0], bl[0]);
-        layer(L::kFrag0 + (2 * nb + 1) * L::kFragL, 2, bh, bl, acc);
-        finish(2 + 2 * nb, un, acc[0], tmid[0]);
+      for (int b = 0; b < BPW; ++b) {
+        const float* trow = tile + (b * 16 + s16) * TS;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) h[0][t][r] += tmid[0][t][r];
+          for (int r = 0; r < 4; ++r) {
+            const int ks = t >> 1, j = 4 * (t & 1) + r;
+            float v = 0.f;
+            if (ks < K0S) {
+              const int c = mycol[ks < K0S ? ks : 0][j];
+              v = c >= 0 ? trow[c] : 0.f;
+            }
+            xin[b][t][r] = v;
+          }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xt[b][e] = trow[tc[e]];
+      }
+      f16x8 bh[BPW][2], bl[BPW][2];
+      f32x4 acc[BPW][4], h[BPW][4], tmid[BPW][4];
+      float un[BPW];
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) un[b] = make_operand(xin[b], bh[b], bl[b]);
+      layer(0, K0S, bh, bl, acc);
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) finish(0, un[b], acc[b], h[b]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+          f32x4 act[4];
+          activate16(h[b], act);
+          un[b] = make_operand(act, bh[b], bl[b]);
+        }
+        layer(L::kFrag0 + (2 * nb) * L::kFragL, 2, bh, bl, acc);
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+          finish(1 + 2 * nb, un[b], acc[b], tmid[b]);
+          f32x4 act[4];
+          activate16(tmid[b], act);
+          un[b] = make_operand(act, bh[b], bl[b]);
+        }
+        layer(L::kFrag0 + (2 * nb + 1) * L::kFragL, 2, bh, bl, acc);
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+          finish(2 + 2 * nb, un[b], acc[b], tmid[b]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[b][t][r] += tmid[b][t][r];
+        }
       }
       // final Linear: one more 64 x 64 product on the residual stream (no activation in front: resnet.py:99)
-      un = make_operand(h[0], bh[0], bl[0]);
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) un[b] = make_operand(h[b], bh[b], bl[b]);
       layer(L::kFrag0 + 2 * NB * L::kFragL, 2, bh, bl, acc);
-      f32x4 prm[4];
-      finish(1 + 2 * NB, un, acc[0], prm);
-      // lane (s, g): dims 8g + e, e = 4t + r (t < 2): shift = prm[t][r], raw scale = prm[2 + t][r]
-      float ladsum = 0.f;
-      float* wrow = tile + s16 * TS;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int b = 0; b < BPW; ++b) {
+        f32x4 prm[4];
+        finish(1 + 2 * NB, un[b], acc[b], prm);
+        // lane (s, g): dims 8g + e, e = 4t + r (t < 2): shift = prm[t][r], raw scale = prm[2 + t][r]
+        float ladsum = 0.f;
+        float* wrow = tile + (b * 16 + s16) * TS;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int e = 4 * t + r;
-          if (8 * g + e < a.d_t) {
-            const float xv = xt[e], shift = prm[t][r], u = prm[2 + t][r];
-            float sc = 1.f, ls = 0.f;
-            // (the lean primitives of fc_math.h: hardware exp2 / log2 / rcp + one correction step, <= 1-2 ulp)
-            if (a.affine_act == FC_AFFINE_SIGMOID_PLUS2) {
-              const float v = u + 2.f;
-              const float ex = exp_lean(-fabsf(v));
-              const float rcp = div_lean(1.f, 1.f + ex);
-              sc = (v >= 0.f ? rcp : ex * rcp) + 1e-3f;
-              ls = log_lean(sc);
-            } else if (a.affine_act == FC_AFFINE_SOFTPLUS_CLAMP3) {
-              const float v = softplus_lean(u, 1.f) + 1e-3f;
-              sc = v < 0.f ? 0.f : (v > 3.f ? 3.f : v);      // torch.clamp: a NaN stays a NaN
-              ls = log_lean(sc);
-            } else if (a.affine_act == FC_AFFINE_MAF_SOFTPLUS) {   // autoregressive.py:97-129 (rows re-ordered by the packer)
-              sc = softplus_lean(u, 1.f) + 1e-3f;
-              ls = log_lean(sc);
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = 4 * t + r;
+            if (8 * g + e < a.d_t) {
+              const float xv = xt[b][e], shift = prm[t][r], u = prm[2 + t][r];
+              float sc = 1.f, ls = 0.f;
+              // (the lean primitives of fc_math.h: hardware exp2 / log2 / rcp + one correction step, <= 1-2 ulp)
+              if (a.affine_act == FC_AFFINE_SIGMOID_PLUS2) {
+                const float v = u + 2.f;
+                const float ex = exp_lean(-fabsf(v));
+                const float rcp = div_lean(1.f, 1.f + ex);
+                sc = (v >= 0.f ? rcp : ex * rcp) + 1e-3f;
+                ls = log_lean(sc);
+              } else if (a.affine_act == FC_AFFINE_SOFTPLUS_CLAMP3) {
+                const float v = softplus_lean(u, 1.f) + 1e-3f;
+                sc = v < 0.f ? 0.f : (v > 3.f ? 3.f : v);      // torch.clamp: a NaN stays a NaN
+                ls = log_lean(sc);
+              } else if (a.affine_act == FC_AFFINE_MAF_SOFTPLUS) {   // autoregressive.py:97-129 (rows re-ordered by the packer)
+                sc = softplus_lean(u, 1.f) + 1e-3f;
+                ls = log_lean(sc);
+              }
+              wrow[tc[e]] = a.inverse ? div_lean(xv - shift, sc) : xv * sc + shift;
+              ladsum += a.inverse ? -ls : ls;
             }
-            wrow[tc[e]] = a.inverse ? div_lean(xv - shift, sc) : xv * sc + shift;
-            ladsum += a.inverse ? -ls : ls;
           }
-        }
-      const float l = rows4_allsum(ladsum, lane);
-      const int64_t row = blk * 16 + s16;
-      if (g == 0) a.lad[row] = a.accumulate ? a.lad[row] + l : l;
+        const float l = rows4_allsum(ladsum, lane);
+        const bool real = grp * BPW + b < a.blocks16;          // (the repeated block of an odd tail is not stored twice)
+        const int64_t row = blk_of(grp, b) * 16 + s16;
+        if (g == 0 && real) a.lad[row] = a.accumulate ? a.lad[row] + l : l;
+      }
       __builtin_amdgcn_wave_barrier();
-      float4* dst = reinterpret_cast<float4*>(a.y + blk * 16 * D);
 #pragma unroll
-      for (int k = 0; k < XV; ++k)
-        if (lane + 64 * k < chunk4) {
-          float v[4];
+      for (int b = 0; b < BPW; ++b) {
+        if (grp * BPW + b >= a.blocks16) continue;
+        float4* dst = reinterpret_cast<float4*>(a.y + blk_of(grp, b) * 16 * D);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = tile[toff[k] + j + (tcol[k] + j >= D ? wrap : 0)];
-          dst[lane + 64 * k] = float4{v[0], v[1], v[2], v[3]};
-        }
+        for (int k = 0; k < XV; ++k)
+          if (lane + 64 * k < chunk4) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = tile[b * 16 * TS + toff[k] + j + (tcol[k] + j >= D ? wrap : 0)];
+            dst[lane + 64 * k] = float4{v[0], v[1], v[2], v[3]};
+          }
+      }
       __builtin_amdgcn_wave_barrier();
     }
     return;
@@ -674,37 +718,55 @@ __global__ __launch_bounds__(512, (kCtx || BPW > 1 || kTail) ? 2 : 4) void resne
 #undef FC_EACH_BLOCK
 }
 
-template <int NB, int K0S, int kCtx, int kAct, int BPW, int kTail = 0>
+template <int NB, int K0S, int kCtx, int kAct, int BPW, int kTail = 0, int XVT = 8>
 hipError_t launch_hidden(const HiddenArgs& a, int64_t grid, hipStream_t s) {
   using L = HiddenLds<NB, K0S, kCtx, kTail>;
   static PerDeviceOnce attr;
   const hipError_t ea = ensure_max_dynamic_lds(
-      attr, reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx, kAct, BPW, kTail>), 160 * 1024);
+      attr, reinterpret_cast<const void*>(&resnet_hidden_kernel<NB, K0S, kCtx, kAct, BPW, kTail, XVT>), 160 * 1024);
   if (ea != hipSuccess) return ea;
+  if (kTail && a.D > 16 * XVT) return hipErrorInvalidValue;
   // (tail kernels: + a [16][D | 1] float tile per wave)
-  const size_t lds = kTail ? ((L::kBytes + 15) & ~size_t(15)) + (size_t)(kHidThreads / 64) * 16 * (a.D | 1) * 4 : L::kBytes;
+  const size_t lds = kTail ? ((L::kBytes + 15) & ~size_t(15)) + (size_t)(kHidThreads / 64) * BPW * 16 * (a.D | 1) * 4 : L::kBytes;
   if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
-  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S, kCtx, kAct, BPW, kTail>), dim3((unsigned)grid), dim3(kHidThreads), lds,
+  hipLaunchKernelGGL((resnet_hidden_kernel<NB, K0S, kCtx, kAct, BPW, kTail, XVT>), dim3((unsigned)grid), dim3(kHidThreads), lds,
                      s, a);
   return hipGetLastError();
 }
 
 // the affine coupling layer in one kernel: ReLU conditioner, <= 3 blocks (the image of 4 blocks + the final layer
 // would not fit in LDS), one workgroup per CU
-inline hipError_t dispatch_coupling_tail(const HiddenArgs& a, int num_blocks, hipStream_t s) {
-  int64_t grid = device_cu_count();
-  const int64_t need = (a.blocks16 + 7) / 8;
+template <int NB, int K0S>
+inline hipError_t launch_coupling_tail(const HiddenArgs& a, hipStream_t s) {
+  // two blocks per wave when there is work for them (>= two rounds of single blocks over the chip) and the second row
+  // tile fits next to the weight image; the last group of an odd block count computes its block twice
+  using L = HiddenLds<NB, K0S, 0, 1>;
+  const int64_t cus = device_cu_count();
+  const size_t lds2 = ((L::kBytes + 15) & ~size_t(15)) + (size_t)(kHidThreads / 64) * 2 * 16 * (a.D | 1) * 4;
+  const bool pairs = a.blocks16 >= 2 * cus * 8 && lds2 <= 160 * 1024 && a.D <= 64;   // (wider rows: the second block's pieces spill)
+  const int64_t units = pairs ? (a.blocks16 + 1) / 2 : a.blocks16;
+  int64_t grid = cus;
+  const int64_t need = (units + 7) / 8;
   if (grid > need) grid = need;
+  if (!pairs) return launch_hidden<NB, K0S, 0, 0, 1, 1>(a, grid, s);
+  // (the two-block kernels carry 2 x XVT row pieces per lane across the layers: instantiated per input width)
+  if (a.D <= 32) return launch_hidden<NB, K0S, 0, 0, 2, 1, 2>(a, grid, s);
+  return launch_hidden<NB, K0S, 0, 0, 2, 1, 4>(a, grid, s);
+}
+
+// the affine coupling layer in one kernel: ReLU conditioner, <= 3 blocks (the image of 4 blocks + the final layer
+// would not fit in LDS), one workgroup per CU
+inline hipError_t dispatch_coupling_tail(const HiddenArgs& a, int num_blocks, hipStream_t s) {
   const bool wide = a.k0 > 32;
   switch (num_blocks * 2 + (wide ? 1 : 0)) {
-    case 0: return launch_hidden<0, 1, 0, 0, 1, 1>(a, grid, s);
-    case 1: return launch_hidden<0, 2, 0, 0, 1, 1>(a, grid, s);
-    case 2: return launch_hidden<1, 1, 0, 0, 1, 1>(a, grid, s);
-    case 3: return launch_hidden<1, 2, 0, 0, 1, 1>(a, grid, s);
-    case 4: return launch_hidden<2, 1, 0, 0, 1, 1>(a, grid, s);
-    case 5: return launch_hidden<2, 2, 0, 0, 1, 1>(a, grid, s);
-    case 6: return launch_hidden<3, 1, 0, 0, 1, 1>(a, grid, s);
-    case 7: return launch_hidden<3, 2, 0, 0, 1, 1>(a, grid, s);
+    case 0: return launch_coupling_tail<0, 1>(a, s);
+    case 1: return launch_coupling_tail<0, 2>(a, s);
+    case 2: return launch_coupling_tail<1, 1>(a, s);
+    case 3: return launch_coupling_tail<1, 2>(a, s);
+    case 4: return launch_coupling_tail<2, 1>(a, s);
+    case 5: return launch_coupling_tail<2, 2>(a, s);
+    case 6: return launch_coupling_tail<3, 1>(a, s);
+    case 7: return launch_coupling_tail<3, 2>(a, s);
     default: return hipErrorInvalidValue;
   }
 }

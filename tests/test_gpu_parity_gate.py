@@ -304,3 +304,28 @@ def test_loglik_allreduce_through_the_c_abi_single_rank(device):
     mean = parallel.sharded_log_prob_mean(lambda v: v.sum(dim=1), torch.ones(10, 3, device=device), reducer=reducer)
     assert mean == 3.0
     reducer.close()
+
+
+def test_cfg4_total_batch_2_23_on_one_gpu_equals_its_eight_shards(cfg3_flows, device):
+    """BASELINE.json configs[3]: 2^23 rows batch-sharded over 8 GPUs.  One GPU per box here, so the 8 contiguous shards of
+    `parallel.rank_plan(..., "strong", total_rows=2^23)` are evaluated one after the other on the same device and compared
+    with ONE launch over all 2^23 rows (2 GB of inputs): per-row results bitwise equal (a row's result does not depend on
+    its shard), {sum, count} as the ranks would all-reduce it equal to the single-launch mean."""
+    from flowconductor_amd import parallel
+
+    flow = copy.deepcopy(cfg3_flows[0]).to(device).eval()
+    n = 1 << 23
+    x = torch.randn(n, 64, device=device, generator=torch.Generator(device=device).manual_seed(99))
+    with torch.no_grad():
+        whole = flow.log_prob(x)
+        assert torch.isfinite(whole).all()
+        total, count = 0.0, 0.0
+        for rank in range(8):
+            plan = parallel.rank_plan(rank, 8, rank, "strong", total_rows=n)
+            assert plan["n_local"] == 1 << 20
+            part = flow.log_prob(x[plan["row_lo"]:plan["row_hi"]])
+            assert torch.equal(part, whole[plan["row_lo"]:plan["row_hi"]])
+            s, c = parallel.allreduce_sum_count(part, group=None)
+            total, count = total + s, count + c
+    assert count == n
+    assert abs(total / count - float(whole.double().mean())) <= 1e-9 * max(1.0, abs(total / count))
