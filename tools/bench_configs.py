@@ -354,7 +354,7 @@ def nsf_k10_h256(device, steps=5, warmup=2, log2n=18, layers=16, hidden=256, bin
     return out
 
 
-def cfg3_sample(device, steps=5, warmup=2, log2n=20):
+def cfg3_sample(device, steps=8, warmup=5, log2n=20):      # (warm-up: the caching allocator settles after ~4 calls)
     """The INVERSE direction of the headline flow (north star: "forward + inverse"): ``Flow.sample(2^20)`` and
     ``Flow.sample_and_log_prob(2^20)`` of BASELINE.json configs[2]'s 32-layer RQ-NSF flow (flows/base.py:50-105 of the
     reference) -- base draws on the device, 32 coupling layers inverted last to first in the same fused kernels
