@@ -190,7 +190,7 @@ def cache_key(*tensors, extra=()):
 RUNTIME_CACHE_ATTRS = frozenset((
     "_hip_packed", "_hip_packed_wide", "_hip_packed_bwd", "_hip_image", "_final_padded", "_tail_image", "_train_pack",
     "_packed", "_masked_final", "_mm_cache", "_dense_cache", "_sp_cache", "_all_cols", "_ctx_cols", "_cols_cache",
-    "_id_cols_cache", "_fc_param_list", "_fc_module_list"))
+    "_id_cols_cache", "_fc_param_list", "_fc_module_list", "_fc_static_ok"))
 
 
 class RuntimeCaches:
@@ -217,6 +217,17 @@ def param_list(module):
     if memo is None or memo[0] != _cache_epoch or not all(m._parameters.get(n) is p for m, n, p in memo[2]):
         slots = tuple((m, n, p) for m in module.modules() for n, p in m._parameters.items() if p is not None)
         memo = module.__dict__["_fc_param_list"] = (_cache_epoch, tuple(module.parameters()), slots)
+    return memo[1]
+
+
+def static_memo(module, slot, key, compute):
+    """``compute()`` memoised on ``module`` under ``slot`` for as long as ``key`` and the cache epoch stand -- for the parts of
+    a fast-path predicate that only depend on how the module is built (layer types, widths, activations, training flag):
+    re-deriving them on every call was a fifth of the host time of a small batch."""
+    memo = module.__dict__.get(slot)
+    full = (_cache_epoch,) + tuple(key)
+    if memo is None or memo[0] != full:
+        memo = module.__dict__[slot] = (full, compute())
     return memo[1]
 
 

@@ -166,14 +166,19 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
     # pre-masked weights (the README flow, examples/toy_2d.py: 3 launches per layer instead of ~7).
     def _one_kernel_ok(self, inputs, context):
         net = self.autoregressive_net
-        return (context is None and isinstance(net, made_module.MADE) and inputs.dim() == 2 and inputs.is_cuda
-                and inputs.dtype == torch.float32 and inputs.shape[0] >= ops.HIDDEN_ROWS and inputs.shape[1] <= 32
-                and inputs.shape[1] == net.initial_layer.in_features
-                and options.get("fused_hidden") and options.get("fused_final_layer")
-                and not hasattr(net, "context_layer") and len(net.blocks) <= 3 and net.hip_hidden_supported(None)
-                and ops.activation_code(net.activation) is not None
-                and ops.activation_code(net.activation)[0] == ops.ACT_RELU
-                and ops.affine_tail_fits(inputs.shape[1], len(net.blocks), inputs.shape[1])
+        if not (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and inputs.shape[0] >= ops.HIDDEN_ROWS and inputs.shape[1] <= 32
+                and options.get("fused_hidden") and options.get("fused_final_layer")):
+            return False
+
+        def structure_ok():        # what only depends on how the conditioner is built
+            return (isinstance(net, made_module.MADE) and inputs.shape[1] == net.initial_layer.in_features
+                    and not hasattr(net, "context_layer") and len(net.blocks) <= 3 and net.hip_hidden_supported(None)
+                    and ops.activation_code(net.activation) is not None
+                    and ops.activation_code(net.activation)[0] == ops.ACT_RELU
+                    and ops.affine_tail_fits(inputs.shape[1], len(net.blocks), inputs.shape[1]))
+
+        return (ops.static_memo(self, "_fc_static_ok", (inputs.shape[1], net.training), structure_ok)
                 and not ops.has_hooks(net) and not self._needs_grad(inputs))
 
     def _one_kernel(self, inputs, total=None):

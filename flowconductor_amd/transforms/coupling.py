@@ -209,15 +209,19 @@ class AffineCouplingTransform(CouplingTransform):
         no batch norm / active dropout, no hooks), <= 32 transformed dims, a scale activation the kernel knows, 2-D float32
         inputs on the device, inference only."""
         net = self.transform_net
-        n = inputs.shape[0] if inputs.dim() == 2 else 0
-        return (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
-                and n >= ops.HIDDEN_ROWS and self.unconditional_transform is None and self.num_transform_features <= 32
-                and options.get("fused_hidden") and options.get("fused_final_layer")
-                and ops.affine_tail_activation(self._activation_code())
-                and _is_plain_resnet(net) and not ops.has_hooks(net)
-                and ops.affine_tail_fits(net.initial_layer.in_features, len(net.blocks), inputs.shape[1])
-                and net.hip_hidden_supported(inputs.shape[1], None)
-                and all(ops.activation_code(b.activation)[0] == ops.ACT_RELU for b in net.blocks)
+        if not (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and inputs.shape[0] >= ops.HIDDEN_ROWS and options.get("fused_hidden") and options.get("fused_final_layer")):
+            return False
+
+        def structure_ok():        # what only depends on how the layer and its conditioner are built (and the input width)
+            return (self.unconditional_transform is None and self.num_transform_features <= 32
+                    and ops.affine_tail_activation(self._activation_code()) and _is_plain_resnet(net)
+                    and ops.affine_tail_fits(net.initial_layer.in_features, len(net.blocks), inputs.shape[1])
+                    and net.hip_hidden_supported(inputs.shape[1], None)
+                    and all(ops.activation_code(b.activation)[0] == ops.ACT_RELU for b in net.blocks))
+
+        return (ops.static_memo(self, "_fc_static_ok", (inputs.shape[1], net.training), structure_ok)
+                and not ops.has_hooks(net)
                 and not (torch.is_grad_enabled()
                          and (inputs.requires_grad or any(p.requires_grad for p in net.parameters()))))
 
