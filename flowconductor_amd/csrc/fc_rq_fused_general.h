@@ -337,6 +337,10 @@ hipError_t launch_general(const RQParams& q, const GenArgs& a, hipStream_t strea
   }
 }
 
+// fc_rq_fused4.hip: the resident-weight kernel for the bin counts it is instantiated for (hidden 64, linear tails)
+bool fused4_takes(const RQParams& q, const GenArgs& a);
+hipError_t launch_fused4(const RQParams& q, const GenArgs& a, hipStream_t stream);
+
 // defined in fc_rq_fused_general_tails.hip / _box.hip (one translation unit per tail mode: they build in parallel)
 hipError_t launch_general_tails(int K, const RQParams& q, const GenArgs& a, hipStream_t stream);
 hipError_t launch_general_box(int K, const RQParams& q, const GenArgs& a, hipStream_t stream);

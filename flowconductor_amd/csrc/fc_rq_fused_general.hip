@@ -26,5 +26,7 @@ extern "C" int fc_rq_spline_fused_general(const float* x, float* y, const float*
   fc::GenArgs a{x, y, h, static_cast<const fc::f16x8*>(w_frag), w_unscale, bias_pad, cols, logabsdet, err_flag,
                 n / fc::kGenRows, d, hidden, d_t, (cfg->flags & FC_RQ_ACCUMULATE_LOGABSDET) ? 1 : 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // bin counts with a resident-weight instance (fc_rq_fused4_body.h: hidden 64, linear tails) run there
+  if (!(cfg->flags & FC_RQ_STREAMED_WEIGHTS) && fc::fused4_takes(q, a)) return fc::launch_fused4(q, a, s);
   return q.tails ? fc::launch_general_tails(q.K, q, a, s) : fc::launch_general_box(q.K, q, a, s);
 }

@@ -1206,10 +1206,12 @@ def fused_backward_supported(n, d, d_t, hidden, num_bins, tails):
 def rq_spline_fused_general(inputs, hidden, w_frag, w_unscale, bias_pad, cols, *, num_bins, tails, tail_bound=1.0,
                             left=0.0, right=1.0, bottom=0.0, top=1.0, min_bin_width=DEFAULT_MIN_BIN_WIDTH,
                             min_bin_height=DEFAULT_MIN_BIN_HEIGHT, min_derivative=DEFAULT_MIN_DERIVATIVE,
-                            wh_divisor=1.0, inverse=False, logabsdet_accum=None, enable_identity_init=False):
+                            wh_divisor=1.0, inverse=False, logabsdet_accum=None, enable_identity_init=False,
+                            streamed_weights=False):
     """RQ-spline coupling bijector with the conditioner's final Linear fused in, general shapes (rows a multiple of
     32; ``hidden`` [N, 64 / 128 / 256] zero-padded; packed weights from ``pack_final_layer_general``).  Semantics and
-    return values as ``rq_spline_fused_linear``; without tails inputs outside the box raise InputOutsideDomain."""
+    return values as ``rq_spline_fused_linear``; without tails inputs outside the box raise InputOutsideDomain.
+    ``streamed_weights``: never the resident-weight instances (A/B measurements and tests)."""
     lib = _hip.load()
     x = _prep_2d(inputs, align16=True)
     h = _aligned16(_hip.dev_f32(hidden, "hidden"))
@@ -1231,6 +1233,8 @@ def rq_spline_fused_general(inputs, hidden, w_frag, w_unscale, bias_pad, cols, *
         cfg.flags = 1  # FC_RQ_ACCUMULATE_LOGABSDET
     else:
         lad = torch.empty(n, dtype=torch.float32, device=x.device)
+    if streamed_weights:
+        cfg.flags |= 8  # FC_RQ_STREAMED_WEIGHTS
     err = _err_word(x.device, True)
     _call("fc_rq_spline_fused_general", lib.fc_rq_spline_fused_general, x.device, _hip.ptr(x), _hip.ptr(y),
           _hip.ptr(h), _hip.ptr(w_frag), _hip.ptr(w_unscale), _hip.ptr(bias_pad), _hip.ptr(cols), _hip.ptr(lad),

@@ -45,6 +45,8 @@ int fc_abi_version(void);
                               measurements; the results are the same) */
 #define FC_RQ_RAW_WEIGHTS 4 /* fc_rq_spline_fused_linear: w_pad / bias_pad are the final nn.Linear's tensors as they
                                are, [d_t * 23, 64] and [d_t * 23] (no padding rows; same results) */
+#define FC_RQ_STREAMED_WEIGHTS 8 /* fc_rq_spline_fused_general: always the streamed-weight kernel, never the
+                                    resident-weight instances of fc_rq_fused4 (A/B measurements and tests) */
 
 typedef struct fc_rq_config {
   int32_t num_bins;       /* K */
@@ -95,7 +97,9 @@ int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const fl
  *             (group, k-step, tile t, piece hi/lo): lane l holds 2^S W[dim 4 group + ((l&15)>>2)][param 4t + (l&3)]
  *             [k = 32 kstep + 8 (l>>4) + j], j < 8
  *   w_unscale f32 [groups] = 2^-S;  bias_pad f32 [groups][4][4T]
- * cfg->flags: FC_RQ_ACCUMULATE_LOGABSDET.  Without tails, inputs outside [left, right] set FC_ERR_OUTSIDE_DOMAIN. */
+ * cfg->flags: FC_RQ_ACCUMULATE_LOGABSDET, FC_RQ_STREAMED_WEIGHTS.  Without tails, inputs outside [left, right] set
+ * FC_ERR_OUTSIDE_DOMAIN.  hidden == 64 with linear tails and K = 10 (the reference's default num_bins) runs with both
+ * weight pieces resident in registers and a hand-scheduled evaluation (fc_rq_fused4_body.h), same results contract. */
 int fc_rq_spline_fused_general(const float* x, float* y, const float* h, const void* w_frag,
                                const float* w_unscale, const float* bias_pad, const int32_t* cols,
                                float* logabsdet, uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t,

@@ -15,8 +15,13 @@ flowcon/transforms/splines/rational_quadratic.py:26-38 (tails) and :78-188 (spli
 import os
 import sys
 
-K = 8
-HOOKS = 36
+# K = 8 (default): the kernel-3 file, two accumulator sets, 36 hooks spread over the whole evaluation.
+# --bins K: fc_rq_fused4_eval_k<K>.inc for the K-generic kernel (fc_rq_fused4.hip): ONE accumulator set, so the next
+# block's MFMAs (6 per 16-row tile of 4 parameters) may only start once the last raw parameter has left the
+# accumulators -- its hooks are spread over the part of the evaluation that follows.
+K = int(sys.argv[sys.argv.index("--bins") + 1]) if "--bins" in sys.argv else 8
+SINGLE_ACC = K != 8
+HOOKS = 6 * ((3 * K - 1 + 3) // 4)
 chunks = []  # (code, weight ~ VALU issue slots)
 
 
@@ -33,6 +38,7 @@ for i in range(K):
 # the derivative logits leave the accumulators early, so the next block's MFMAs can reuse those registers
 for j in range(K - 1):
     add("FC_DER_ST(%d, FC_UD(%d));" % (j + 1, j), 1)
+READS_END = len(chunks)   # the accumulators are free from here on
 add("const FC_F2 m = {mx, my};", 0)
 # Software scheduling (the hooks pin the order, so independent work is laid out by hand): all subtractions first,
 # then the 16 exponentials, then the running sum -- a dependent instruction is never the next one issued (packed
@@ -52,9 +58,13 @@ for i in range(K):
 # accumulates in double on the CPU and in float on the GPU.)
 H = K // 2
 add("const FC_F2 l0 = t0, r%d = t%d;" % (K - 2, K - 1), 0)
-for i in range(1, H):
-    add("const FC_F2 l%d = l%d + t%d;" % (i, i - 1, i), 1)
-    add("const FC_F2 r%d = r%d + t%d;" % (K - 2 - i, K - 1 - i, K - 1 - i), 1)
+lchain = ["const FC_F2 l%d = l%d + t%d;" % (i, i - 1, i) for i in range(1, H)]
+rchain = ["const FC_F2 r%d = r%d + t%d;" % (j, j + 1, j + 1) for j in range(K - 3, H - 2, -1)]
+for i in range(max(len(lchain), len(rchain))):     # (odd K: the right chain is one longer)
+    if i < len(lchain):
+        add(lchain[i], 1)
+    if i < len(rchain):
+        add(rchain[i], 1)
 add("const FC_F2 tot = l%d + r%d;" % (H - 1, H - 1), 1)
 add("const float rsx = div_lean(1.f, tot.x);", 5)
 add("const float rsy = div_lean(1.f, tot.y);\nconst FC_F2 gk = sc1 * FC_F2{rsx, rsy};\nint idx = 0;", 6)
@@ -116,18 +126,23 @@ if constexpr (!kInv) {
 }""", 8)
 add("y = inside ? ys : x;\nlad = inside ? (kInv ? -lval : lval) : 0.f;", 3)
 
-total = sum(w for _, w in chunks)
 out = ["// GENERATED by tools/gen_fused_eval.py -- do not edit by hand.",
        "// Straight-line RQ-spline evaluation (K = %d, linear tails) of one element with %d MFMA hook points." % (K, HOOKS),
        "// Expects in scope: FC_WH(i) / FC_UD(j) (logits of the element), FC_KNOT_ST / FC_KNOT_LD / FC_DER_ST / FC_DER_LD",
        "// (lane-private LDS tables of K + 1 knots and K + 1 derivative logits), FC_F2, x, q, inv_beta, err, the knot",
        "// constants sc1, kc0 .. kc%d (FC_F2: x = widths axis, y = heights axis), kInv (constexpr bool), outputs y / lad," % (K - 2),
        "// FC_COUNT_GE(count, a, b): count += (a >= b), and FC_HOOK(n).  FC_WH(i) is expected in log2 units (logit * log2(e))."]
+if SINGLE_ACC:
+    out.append("// One accumulator set: no hook before the last FC_WH / FC_UD read.")
 # hook placement: hook k sits where the accumulated weight passes (k + 1 - SHIFT) / HOOKS of the total
 # (FC_GEN_SHIFT: probe knob for tools/probe/search_hooks.sh; the committed file uses 0)
 SHIFT = float(os.environ.get("FC_GEN_SHIFT", "0"))
 acc = 0.0
 hook = 0
+if SINGLE_ACC:
+    out.extend(code for code, _ in chunks[:READS_END])
+    chunks = chunks[READS_END:]
+total = sum(w for _, w in chunks)
 for code, w in chunks:
     out.append(code)
     acc += w
@@ -138,7 +153,7 @@ while hook < HOOKS:
     out.append("FC_HOOK(%d)" % hook)
     hook += 1
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flowconductor_amd", "csrc",
-                    "fc_rq_fused3_eval.inc")
+                    "fc_rq_fused4_eval_k%d.inc" % K if SINGLE_ACC else "fc_rq_fused3_eval.inc")
 text = "\n".join(out) + "\n"
 if "--check" in sys.argv:      # tests/test_host_logic.py: the committed file is what this script generates
     sys.exit(0 if open(path).read() == text else 1)
