@@ -16,7 +16,10 @@
 //     kernel streams (fc_pack_fragments FC_PACK_FINAL: scaled by a power of two per group of 4 dims, two f16 pieces),
 //     each lane picking the fragment rows of ITS accumulator slots -- width and height logit i in adjacent slots 2i,
 //     2i + 1, so the packed (width, height) arithmetic reads register pairs as they are;
-//   * 32-row tiles (the lane-private bin tables take 8 (K + 1) 768 bytes: 66 KB at K = 10).
+//   * 32-row tiles (the lane-private bin tables take 8 (K + 1) 768 bytes: 66 KB at K = 10, which rules out kernel 3's
+//     64 rows).  48-row tiles -- one accumulator set does not need an even number of blocks -- were measured and are no
+//     faster: the tile hand-over (park, barrier, write-out) is work per ROW, 40 of the 244 cycles a row takes at either
+//     size (tools/probe/fused4_clock.py).
 // Everything else -- transposed product, split-f16 terms, rings, one barrier per tile, priority sawtooth -- is kernel 3's.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -278,6 +281,18 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
       a.logabsdet[t * R + tid] = a.accumulate ? a.logabsdet[t * R + tid] + l : l;
     }
   };
+#ifdef FC_F4_STAMP   // probe builds (tools/probe/fused4_clock.py): cycles each wave spends in the phases of the loop
+  const uint64_t stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+  uint64_t phase_cyc[6] = {0, 0, 0, 0, 0, 0}, phase_t = stamp_c0;
+#define FC_PHASE(k)                                              \
+  do {                                                           \
+    const uint64_t now = __builtin_amdgcn_s_memtime();           \
+    phase_cyc[k] += now - phase_t;                               \
+    phase_t = now;                                               \
+  } while (0)
+#else
+#define FC_PHASE(k)
+#endif
   fetch(tile0);
   park(0, 0);
   __syncthreads();
@@ -287,20 +302,37 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
   for (int64_t tile = tile0; tile < a.tiles; tile += stride) {
     const bool has_next = tile + stride < a.tiles;
     const int x3n = x3 == 2 ? 0 : x3 + 1, x3p = x3 == 0 ? 2 : x3 - 1;
+    FC_PHASE(0);
     if (has_next) fetch(tile + stride);
     if (active) step(acc, x3, 0, hb, 1);
+    FC_PHASE(1);
     if (has_next) park(hb ^ 1, x3n);
+    FC_PHASE(2);
     __syncthreads();
+    FC_PHASE(3);
     if (prev_tile >= 0) write_out(prev_tile, x3p);   // complete since every wave passed this barrier
+    FC_PHASE(4);
     // Last step: evaluate block 1, produce block 0 of the next tile (unconditional: on the last tile the MFMAs work on
     // stale h rows into accumulators nobody reads -- a branch would split the interleaved block).
     if (active) step(acc, x3, 1, hb ^ 1, 0);
+    FC_PHASE(5);
     prev_tile = tile;
     hb ^= 1;
     x3 = x3n;
   }
   __syncthreads();
   if (prev_tile >= 0) write_out(prev_tile, x3 == 0 ? 2 : x3 - 1);
+#ifdef FC_F4_STAMP   // the stamps overwrite outputs of the workgroup's first tile
+  if (tid == 0) {
+    a.y[tile0 * R * D] = (float)(__builtin_amdgcn_s_memtime() - stamp_c0);
+    a.y[tile0 * R * D + 1] = (float)(__builtin_amdgcn_s_memrealtime() - stamp_r0);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.y[tile0 * R * D + 4 + wave * 6 + k] = (float)phase_cyc[k];
+  }
+#endif
+#undef FC_PHASE
   if (err && a.err) atomicOr(a.err, err);
 }
 

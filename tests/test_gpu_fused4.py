@@ -1,5 +1,5 @@
-"""The resident-weight instance of the general fused final-Linear + RQ-spline entry (fc_rq_fused4_body.h: hidden 64,
-linear tails, K = 10 -- the reference's default num_bins, coupling.py:507): operator level against a float64 Linear in
+"""The resident-weight instances of the general fused final-Linear + RQ-spline entry (fc_rq_fused4_body.h: hidden 64,
+linear tails, K = 4..7 and 9..11; K = 10 is the reference's default num_bins, coupling.py:507): operator level against a float64 Linear in
 front of the oracle's spline, and against the streamed-weight kernel it replaces for this shape, over the kernel's
 variants (32 / fewer transformed dims, padded / unpadded x rows, one / two float4 of x per thread, both directions,
 running logabsdet total, more tiles than workgroups)."""
@@ -44,8 +44,20 @@ def _reference(x, h, w, b, cols, k, inverse):
 @pytest.mark.parametrize("n,d,d_t", [(256, 64, 32), (96, 64, 13), (160, 63, 32), (64, 37, 5), (128, 128, 32), (32, 126, 30),
                                      (32, 32, 32), (64, 2, 1)])
 def test_resident_k10_against_float64_linear_and_streamed(n, d, d_t, inverse, device):
-    k = 10
-    x, h, w, b, cols = _case(n, d, d_t, k, seed=n + d + d_t)
+    _check_against_float64_and_streamed(10, n, d, d_t, inverse, device)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+@pytest.mark.parametrize("k", [4, 5, 6, 7, 9, 11])
+@pytest.mark.parametrize("n,d,d_t", [(96, 64, 32), (64, 37, 5), (32, 128, 32)])
+def test_resident_other_bin_counts(k, n, d, d_t, inverse, device):
+    _check_against_float64_and_streamed(k, n, d, d_t, inverse, device)
+
+
+def _check_against_float64_and_streamed(k, n, d, d_t, inverse, device):
+    # (inverse direction: rows of h at one scale -- with five decades of row scales the steepest splines make the
+    #  inverse so ill-conditioned that the float32 oracle itself is off by more than any bound worth asserting)
+    x, h, w, b, cols = _case(n, d, d_t, k, seed=n + d + d_t + k, h_decades=not inverse)
     ref_y, ref_lad, floor_y, floor_lad = _reference(x, h, w, b, cols, k, inverse)
     packed = ops.pack_final_layer_general(w.to(device), b.to(device), k, "linear", 64)
     kw = dict(num_bins=k, tails="linear", tail_bound=3.0, wh_divisor=8.0, inverse=inverse)

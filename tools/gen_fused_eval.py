@@ -154,6 +154,7 @@ while hook < HOOKS:
     hook += 1
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flowconductor_amd", "csrc",
                     "fc_rq_fused4_eval_k%d.inc" % K if SINGLE_ACC else "fc_rq_fused3_eval.inc")
+path = os.environ.get("FC_GEN_OUT", path)     # probe builds (tools/probe/build_f4_variants.sh)
 text = "\n".join(out) + "\n"
 if "--check" in sys.argv:      # tests/test_host_logic.py: the committed file is what this script generates
     sys.exit(0 if open(path).read() == text else 1)

@@ -22,11 +22,13 @@ h = torch.randn(n, 64, device=dev)
 w = torch.randn(d_t * 23, 64, device=dev) * 0.2
 b = torch.randn(d_t * 23, device=dev) * 0.1
 wp, bp = ops.pack_final_layer(w, b)
+total = torch.zeros(n, device=dev) if "--accumulate" in sys.argv else None   # the flow's running logabsdet total
 t0 = time.time()
 with torch.no_grad():
     while time.time() - t0 < 2.5:   # >= 2 s of back-to-back launches before reading the stamps
         for _ in range(50):
-            y, lad = ops.rq_spline_fused_linear(x, h, wp, bp, cols, num_bins=k, tail_bound=3.0, wh_divisor=8.0)
+            y, lad = ops.rq_spline_fused_linear(x, h, wp, bp, cols, num_bins=k, tail_bound=3.0, wh_divisor=8.0,
+                                                logabsdet_accum=total)
         torch.cuda.synchronize()
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 yy = y.view(-1, 64 * d)[:cus, :60].double().cpu()
