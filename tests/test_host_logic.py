@@ -198,6 +198,9 @@ def test_generated_fused_eval_is_current():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rc = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_fused_eval.py"), "--check"]).returncode
     assert rc == 0, "run python tools/gen_fused_eval.py and commit the result"
+    for k in (4, 5, 6, 7, 9, 10, 11):       # the K-generic kernel's files (fc_rq_fused4_k<K>.hip)
+        rc = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_fused_eval.py"), "--bins", str(k), "--check"]).returncode
+        assert rc == 0, "run python tools/gen_fused_eval.py --bins %d and commit the result" % k
 
 
 def test_pack_final_layer_pads_dims_to_groups_of_four():

@@ -1,5 +1,5 @@
 """The BASELINE.json configurations other than the headline one, as bench.py's ``configs`` block (and on their own:
-``python tools/bench_configs.py [cfg3_sample cfg1 cfg2 cfg5_shared cfg5_per_sample nsf_k10_h256]``, one JSON object per line).
+``python tools/bench_configs.py [cfg3_sample cfg1 cfg2 cfg5_shared cfg5_per_sample nsf_k10_h256 nsf_k10_h64]``, one JSON object per line).
 
 Every entry carries what the headline line carries: throughput, the dominant kernel's ``roofline`` (algorithmic bytes or
 flops of SURVEY.md 8d per launch / the average launch duration from HIP events on the launch stream), ``cpu_baseline``
@@ -311,7 +311,8 @@ def nsf_k10_h256(device, steps=5, warmup=2, log2n=18, layers=16, hidden=256, bin
     n = 1 << log2n
     x = torch.randn(n, 64, device=device, generator=torch.Generator(device=device).manual_seed(1234))
     step_s, _ = _time_gpu(lambda: flow.log_prob(x), steps, warmup)
-    names = ["fc_rq_spline_fused_general", "fc_resnet_hidden_wide", "fc_rq_spline"]
+    hidden_entry = "fc_resnet_hidden" if hidden == 64 else "fc_resnet_hidden_wide"
+    names = ["fc_rq_spline_fused_general", hidden_entry, "fc_rq_spline"]
     km = _kernel_ms(lambda: flow.log_prob(x), names)
     p = 3 * bins - 1
     out = {"workload": "%d-layer RQ-NSF coupling flow, D=64, K=%d (reference default), linear tails, "
@@ -319,7 +320,11 @@ def nsf_k10_h256(device, steps=5, warmup=2, log2n=18, layers=16, hidden=256, bin
            "metric": "log_prob samples/sec", "unit": "samples/s", "value": n / step_s, "ms_per_step": step_s * 1e3,
            "dtype": "f32 results; conditioner products = 3-term split-f16 MFMA"}
     f_ms, f_n = km["fc_rq_spline_fused_general"]
-    if f_ms:
+    if f_ms and hidden == 64:
+        # resident weights: VALU-issue bound like the K = 8 kernel; algorithmic bytes of SURVEY 8d with P = 3K - 1
+        out["roofline"] = _hbm_roofline("fc::f4k%d::rq_fused_linear_kernel4 (resident weights, one accumulator set)" % bins,
+                                        "fc_rq_spline_fused_general", f_ms, f_n, (4 * 32 * (p + 2) + 8) * n, bound="valu_issue")
+    elif f_ms:
         flops = 2.0 * hidden * 32 * p * n
         tf = flops / (f_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
@@ -333,8 +338,11 @@ def nsf_k10_h256(device, steps=5, warmup=2, log2n=18, layers=16, hidden=256, bin
         if s_ms:
             out["roofline"] = _hbm_roofline("rq spline kernel (unfused path)", "fc_rq_spline", s_ms, s_n,
                                             (4 * 32 * (p + 2) + 8) * n)
-    h_ms, h_n = km["fc_resnet_hidden_wide"]
-    if h_ms:
+    h_ms, h_n = km[hidden_entry]
+    if h_ms and hidden == 64:
+        out["roofline_hidden"] = _hbm_roofline("fc::resnet_hidden_kernel", "fc_resnet_hidden", h_ms, h_n, (4 * 64 + 4 * 64) * n,
+                                               bound="mfma_issue")
+    elif h_ms:
         hflops = 2.0 * (hidden * 32 + 4 * hidden * hidden) * n
         out["roofline_hidden"] = {"bound": "mfma", "achieved": hflops / (h_ms * 1e-3) / 1e12,
                                   "peak": MFMA_F16_PEAK_TFLOPS / 3.0, "unit": "TFLOP/s",
@@ -352,6 +360,12 @@ def nsf_k10_h256(device, steps=5, warmup=2, log2n=18, layers=16, hidden=256, bin
     out["cpu_baseline"] = _cpu_baseline(lambda: O.flow_log_prob(flow_cpu, xc), sample, "2^13 samples per call")
     out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     return out
+
+
+def nsf_k10_h64(device):
+    """BASELINE.json configs[2] with the reference's DEFAULT bin count: 32 layers, D = 64, ResidualNet(64, 2 blocks),
+    K = 10 (coupling.py:507), N = 2^20 -- the fused layer on the resident-weight K = 10 kernel (fc_rq_fused4_body.h)."""
+    return nsf_k10_h256(device, steps=5, warmup=3, log2n=20, layers=32, hidden=64, bins=10)
 
 
 def cfg3_sample(device, steps=8, warmup=5, log2n=20):      # (warm-up: the caching allocator settles after ~4 calls)
@@ -415,7 +429,7 @@ def cfg3_sample(device, steps=8, warmup=5, log2n=20):      # (warm-up: the cachi
 
 
 ALL = {"cfg3_sample": cfg3_sample, "cfg1": cfg1, "cfg2": cfg2, "cfg5_shared": cfg5_shared, "cfg5_per_sample": cfg5_per_sample,
-       "nsf_k10_h256": nsf_k10_h256}
+       "nsf_k10_h256": nsf_k10_h256, "nsf_k10_h64": nsf_k10_h64}
 
 
 def run(device, which=None, log=None):
