@@ -1,6 +1,7 @@
 // Fused final-Linear + RQ-spline kernel, fourth structure: kernel 3 (fc_rq_fused3.hip) for bin counts other than 8,
-// written once and compiled per K (one translation unit per bin count, fc_rq_fused4_k<K>.hip, which defines FC_F4_K and
-// FC_F4_EVAL_INC before including this file).  hidden_features = 64, linear tails, up to 32 transformed dims.  gfx950.
+// written once and compiled per shape (one translation unit per bin count and tail mode, fc_rq_fused4_k<K>[_box].hip, which
+// defines FC_F4_K, FC_F4_TAILS, FC_F4_NAME and FC_F4_EVAL_INC before including this file).  hidden_features = 64, linear
+// tails or none (coupling.py:543-547: 3K - 1 or 3K + 1 parameters per dim), up to 32 transformed dims.  gfx950.
 //
 //   params[n, :] = W h[n, :] + b        (flowcon/nn/nets/resnet.py:91,99; num_bins defaults to 10, coupling.py:507)
 //   y, logabsdet = rq_spline(x, params) (flowcon/transforms/coupling.py:279-293,549-582; rational_quadratic.py:13-181)
@@ -37,11 +38,12 @@
 #define FC_F4_CAT(a, b) FC_F4_CAT2(a, b)
 
 namespace fc {
-namespace FC_F4_CAT(f4k, FC_F4_K) {
+namespace FC_F4_CAT(f4, FC_F4_NAME) {
 
 #define FC_F2 f2
 constexpr int K = FC_F4_K;
-constexpr int P = 3 * K - 1;            // parameters per dim (linear tails)
+constexpr bool kTails = FC_F4_TAILS != 0;
+constexpr int P = kTails ? 3 * K - 1 : 3 * K + 1;   // parameters per dim
 constexpr int CT = (P + 3) / 4;         // 16-feature tiles per wave: 4 dims x 4 CT padded parameters
 constexpr int PP = 4 * CT;
 constexpr int NM = 6 * CT;              // MFMAs per 16-sample block: 3 split terms x 2 k-steps x CT tiles
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
   const int64_t stride = gridDim.x;
   const int64_t tile0 = blockIdx.x;
   if (tile0 >= a.tiles) return;
-  if (tid < 32) cs[tid] = tid < a.dt ? a.cols[tid] : 0;
+  // (lanes of dims beyond dt evaluate the first transformed column again, results dropped: an error they flag is that
+  //  column's own -- column 0 may be an identity feature outside the box, which the reference never checks)
+  if (tid < 32) cs[tid] = a.cols[tid < a.dt ? tid : 0];
   const int WD = kFull ? 8 : (a.dt + 3) >> 2;          // dim groups = waves with spline work
   const bool dim_ok = kFull || 4 * wave + g < a.dt;
   const bool active = kFull || wave < WD;
@@ -130,14 +134,17 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
            kc8 = {q.kcx[8], q.kcy[8]}, kc9 = {q.kcx[9], q.kcy[9]};
   (void)kc0; (void)kc1; (void)kc2; (void)kc3; (void)kc4; (void)kc5; (void)kc6; (void)kc7; (void)kc8; (void)kc9;
 
-  // Lane-private bin tables: slots 0 and K are the interval ends / the linear-tail derivative constant
-  // (rational_quadratic.py:33-36) and never change; slots 1..K-1 are rewritten per element.  [slot][lane] layout.
+  // Lane-private bin tables: knot slots 0 and K are the interval ends and never change, slots 1..K-1 are rewritten per
+  // element; derivative slots 0 and K hold the linear-tail constant (rational_quadratic.py:33-36) -- without tails all
+  // K + 1 derivative logits come from the conditioner.  [slot][lane] layout.
   float* ktab = tabs + wave * (kKnotFloats + kDerFloats) + lane * 2;
   float* dtab = tabs + wave * (kKnotFloats + kDerFloats) + kKnotFloats + lane;
   *reinterpret_cast<f2*>(ktab) = f2{q.left, q.bottom};
   *reinterpret_cast<f2*>(ktab + K * 128) = f2{q.right, q.top};
-  dtab[0] = q.tail_const * q.beta;
-  dtab[K * 64] = q.tail_const * q.beta;
+  if constexpr (kTails) {
+    dtab[0] = q.tail_const * q.beta;
+    dtab[K * 64] = q.tail_const * q.beta;
+  }
 
   uint32_t err = 0;
   const int xvec = R * D / 4;     // float4 per x tile: thread tid owns slots tid + 512 k, k < XV
@@ -356,11 +363,11 @@ static hipError_t launch_one(const RQOp<K>& op, const GenArgs& a, hipStream_t st
   return a.dt == 32 ? launch_cfg<kInv, XV, true, true>(op, a, stream) : launch_cfg<kInv, XV, false, true>(op, a, stream);
 }
 
-}  // namespace f4k<K>
+}  // namespace f4<name>
 
-// a.tiles counts 32-row tiles; a.H == 64, linear tails, q.K == FC_F4_K
-hipError_t FC_F4_CAT(launch_fused4_k, FC_F4_K)(const RQParams& q, const GenArgs& a, hipStream_t stream) {
-  using namespace FC_F4_CAT(f4k, FC_F4_K);
+// a.tiles counts 32-row tiles; a.H == 64, q.K == FC_F4_K, q.tails == FC_F4_TAILS
+hipError_t FC_F4_CAT(launch_fused4_, FC_F4_NAME)(const RQParams& q, const GenArgs& a, hipStream_t stream) {
+  using namespace FC_F4_CAT(f4, FC_F4_NAME);
   RQOp<K> op;
   op.q = q;
   op.inv_div = 1.f / q.wh_div;
@@ -369,6 +376,6 @@ hipError_t FC_F4_CAT(launch_fused4_k, FC_F4_K)(const RQParams& q, const GenArgs&
   if (R * a.D / 4 <= 512) return inv ? launch_one<true, 1>(op, a, stream) : launch_one<false, 1>(op, a, stream);
   return inv ? launch_one<true, 2>(op, a, stream) : launch_one<false, 2>(op, a, stream);
 }
-size_t FC_F4_CAT(fused4_lds_bytes_k, FC_F4_K)(int d) { return FC_F4_CAT(f4k, FC_F4_K)::lds_bytes(d); }
+size_t FC_F4_CAT(fused4_lds_bytes_, FC_F4_NAME)(int d) { return FC_F4_CAT(f4, FC_F4_NAME)::lds_bytes(d); }
 
 }  // namespace fc

@@ -1,4 +1,6 @@
-// K = 4 instance of the K-generic resident-weight fused kernel (fc_rq_fused4_body.h).
+// K = 4, linear tails: instance of the K-generic resident-weight fused kernel (fc_rq_fused4_body.h).
 #define FC_F4_K 4
+#define FC_F4_TAILS 1
+#define FC_F4_NAME k4
 #define FC_F4_EVAL_INC "fc_rq_fused4_eval_k4.inc"
 #include "fc_rq_fused4_body.h"

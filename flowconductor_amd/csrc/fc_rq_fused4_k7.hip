@@ -1,4 +1,6 @@
-// K = 7 instance of the K-generic resident-weight fused kernel (fc_rq_fused4_body.h).
+// K = 7, linear tails: instance of the K-generic resident-weight fused kernel (fc_rq_fused4_body.h).
 #define FC_F4_K 7
+#define FC_F4_TAILS 1
+#define FC_F4_NAME k7
 #define FC_F4_EVAL_INC "fc_rq_fused4_eval_k7.inc"
 #include "fc_rq_fused4_body.h"

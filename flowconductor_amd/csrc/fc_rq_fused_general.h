@@ -118,7 +118,9 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
   const int s16 = lane & 15, g = lane >> 4;
   const int64_t stride = gridDim.x, tile0 = blockIdx.x;
   if (tile0 >= a.tiles) return;
-  if (tid < 32) cs[tid] = tid < a.dt ? a.cols[tid] : 0;
+  // (lanes of dims beyond dt evaluate the first transformed column again, results dropped: whatever error they flag is that
+  //  column's own -- column 0 may be an identity feature outside the box, which the reference never checks, coupling.py:79-88)
+  if (tid < 32) cs[tid] = a.cols[tid < a.dt ? tid : 0];
   const int WD = (a.dt + 3) >> 2;                 // waves with spline work
   const bool active = wave < WD;
   const bool dim_ok = 4 * wave + g < a.dt;

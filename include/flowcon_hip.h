@@ -98,8 +98,9 @@ int fc_rq_spline_fused_linear(const float* x, float* y, const float* h, const fl
  *             [k = 32 kstep + 8 (l>>4) + j], j < 8
  *   w_unscale f32 [groups] = 2^-S;  bias_pad f32 [groups][4][4T]
  * cfg->flags: FC_RQ_ACCUMULATE_LOGABSDET, FC_RQ_STREAMED_WEIGHTS.  Without tails, inputs outside [left, right] set
- * FC_ERR_OUTSIDE_DOMAIN.  hidden == 64 with linear tails and K = 10 (the reference's default num_bins) runs with both
- * weight pieces resident in registers and a hand-scheduled evaluation (fc_rq_fused4_body.h), same results contract. */
+ * FC_ERR_OUTSIDE_DOMAIN.  hidden == 64 with K = 4..7, 9..11 (linear tails) or 4..10 (no tails) -- K = 10 is the
+ * reference's default num_bins -- runs with both weight pieces resident in registers and a hand-scheduled evaluation
+ * (fc_rq_fused4_body.h), same results contract. */
 int fc_rq_spline_fused_general(const float* x, float* y, const float* h, const void* w_frag,
                                const float* w_unscale, const float* bias_pad, const int32_t* cols,
                                float* logabsdet, uint32_t* err_flag, int64_t n, int32_t d, int32_t d_t,

@@ -201,6 +201,9 @@ def test_generated_fused_eval_is_current():
     for k in (4, 5, 6, 7, 9, 10, 11):       # the K-generic kernel's files (fc_rq_fused4_k<K>.hip)
         rc = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_fused_eval.py"), "--bins", str(k), "--check"]).returncode
         assert rc == 0, "run python tools/gen_fused_eval.py --bins %d and commit the result" % k
+    for k in (4, 5, 6, 7, 8, 9, 10):        # ... and of the form without tails
+        rc = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_fused_eval.py"), "--bins", str(k), "--box", "--check"]).returncode
+        assert rc == 0, "run python tools/gen_fused_eval.py --bins %d --box and commit the result" % k
 
 
 def test_pack_final_layer_pads_dims_to_groups_of_four():

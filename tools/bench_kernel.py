@@ -1,5 +1,5 @@
 """Times one bijector kernel in isolation on the BASELINE.json cfg-3 layer shape and prints achieved
-algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [--lib path.so] [--log2n 20] [rq|rq_inv|rq_bwd|affine|fused|fused_inv|hidden|general|general_k<K>[_streamed|_inv]|general_h256|fused_bwd|fused_bwd_k10|hidden_bwd|hidden_wide|hidden_wide128]"""
+algorithmic GB/s (HIP events on the launch stream).  Usage: python tools/bench_kernel.py [--lib path.so] [--log2n 20] [rq|rq_inv|rq_bwd|affine|fused|fused_inv|hidden|general|general_k<K>[_box][_streamed|_inv]|general_h256|fused_bwd|fused_bwd_k10|hidden_bwd|hidden_wide|hidden_wide128]"""
 import os
 import re
 import sys
@@ -52,17 +52,20 @@ def main():
         kw = dict(num_bins=k, tails="linear", tail_bound=3.0, wh_divisor=8.0)
         fn = lambda: ops.rq_spline_backward(x, params, cols, gy, gl, **kw)  # noqa: E731
         name = "fc_rq_spline_backward"
-    elif which in ("general", "general_h256") or re.fullmatch(r"general_k\d+(_streamed|_inv)?", which):
+    elif which in ("general", "general_h256") or re.fullmatch(r"general_k\d+(_box)?(_streamed|_inv)?", which):
         # the general fused final-layer kernel: K = 8 / hidden 64 (the headline shape on the general structure),
         # K = 10 / hidden 64, K = 10 / hidden 256
         # (K = 10 / hidden 64 runs on the resident-weight instance, fc_rq_fused4; `_streamed`: the streamed-weight kernel)
         kk, hid = (8, 64) if which == "general" else (10, 256) if which == "general_h256" else (int(re.findall(r"\d+", which)[0]), 64)
-        p = 3 * kk - 1
+        gtails = None if "_box" in which else "linear"
+        p = 3 * kk + 1 if gtails is None else 3 * kk - 1
         h = torch.randn(n, hid, device=dev)
         w = torch.randn(d_t * p, hid, device=dev) * (1.0 / hid ** 0.5)
         b = torch.randn(d_t * p, device=dev) * 0.1
-        packed = ops.pack_final_layer_general(w, b, kk, "linear", hid)
-        fn = lambda: ops.rq_spline_fused_general(x, h, *packed, cols, num_bins=kk, tails="linear", tail_bound=3.0,  # noqa: E731
+        if gtails is None:
+            x = torch.rand(n, d, device=dev)
+        packed = ops.pack_final_layer_general(w, b, kk, gtails, hid)
+        fn = lambda: ops.rq_spline_fused_general(x, h, *packed, cols, num_bins=kk, tails=gtails, tail_bound=3.0,  # noqa: E731
                                                  wh_divisor=float(hid) ** 0.5, inverse=which.endswith("_inv"),
                                                  streamed_weights=which.endswith("_streamed"))
         name = "fc_rq_spline_fused_general"

@@ -19,9 +19,12 @@ import sys
 # --bins K: fc_rq_fused4_eval_k<K>.inc for the K-generic kernel (fc_rq_fused4.hip): ONE accumulator set, so the next
 # block's MFMAs (6 per 16-row tile of 4 parameters) may only start once the last raw parameter has left the
 # accumulators -- its hooks are spread over the part of the evaluation that follows.
+# --box: the form without tails (tails=None, coupling.py:543-547: 3K + 1 parameters, all K + 1 knot derivatives from the
+# conditioner, inputs outside the box are an error), fc_rq_fused4_eval_k<K>_box.inc.
 K = int(sys.argv[sys.argv.index("--bins") + 1]) if "--bins" in sys.argv else 8
-SINGLE_ACC = K != 8
-HOOKS = 6 * ((3 * K - 1 + 3) // 4)
+BOX = "--box" in sys.argv
+SINGLE_ACC = K != 8 or BOX
+HOOKS = 6 * ((3 * K + (1 if BOX else -1) + 3) // 4)
 chunks = []  # (code, weight ~ VALU issue slots)
 
 
@@ -30,14 +33,16 @@ def add(code, w):
 
 
 add("const bool inside = (x >= q.left) && (x <= q.right);\nconst float xc = inside ? x : q.left;", 3)
+if BOX:       # rational_quadratic.py:81-82 (the same interval in both directions); the element passes through unchanged
+    add("if (!inside) err |= kErrOutsideDomain;", 1)
 add("float mx = -INFINITY, my = -INFINITY;", 1)
 # FC_WH(i) hands out the width / height logits in LOG2 units (the kernel folds log2(e) into the constants of the
 # fma that undoes the operand scaling), so exp_softmax(d) is a bare v_exp_f32 of the difference.
 for i in range(K):
     add("FC_F2 t%d = FC_F2{FC_WH(%d), FC_WH(%d)};\nmx = fmaxf(mx, t%d.x);\nmy = fmaxf(my, t%d.y);" % (i, i, K + i, i, i), 3)
 # the derivative logits leave the accumulators early, so the next block's MFMAs can reuse those registers
-for j in range(K - 1):
-    add("FC_DER_ST(%d, FC_UD(%d));" % (j + 1, j), 1)
+for j in range(K + 1 if BOX else K - 1):
+    add("FC_DER_ST(%d, FC_UD(%d));" % (j if BOX else j + 1, j), 1)
 READS_END = len(chunks)   # the accumulators are free from here on
 add("const FC_F2 m = {mx, my};", 0)
 # Software scheduling (the hooks pin the order, so independent work is laid out by hand): all subtractions first,
@@ -127,7 +132,8 @@ if constexpr (!kInv) {
 add("y = inside ? ys : x;\nlad = inside ? (kInv ? -lval : lval) : 0.f;", 3)
 
 out = ["// GENERATED by tools/gen_fused_eval.py -- do not edit by hand.",
-       "// Straight-line RQ-spline evaluation (K = %d, linear tails) of one element with %d MFMA hook points." % (K, HOOKS),
+       "// Straight-line RQ-spline evaluation (K = %d, %s) of one element with %d MFMA hook points."
+       % (K, "no tails" if BOX else "linear tails", HOOKS),
        "// Expects in scope: FC_WH(i) / FC_UD(j) (logits of the element), FC_KNOT_ST / FC_KNOT_LD / FC_DER_ST / FC_DER_LD",
        "// (lane-private LDS tables of K + 1 knots and K + 1 derivative logits), FC_F2, x, q, inv_beta, err, the knot",
        "// constants sc1, kc0 .. kc%d (FC_F2: x = widths axis, y = heights axis), kInv (constexpr bool), outputs y / lad," % (K - 2),
@@ -153,7 +159,7 @@ while hook < HOOKS:
     out.append("FC_HOOK(%d)" % hook)
     hook += 1
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flowconductor_amd", "csrc",
-                    "fc_rq_fused4_eval_k%d.inc" % K if SINGLE_ACC else "fc_rq_fused3_eval.inc")
+                    "fc_rq_fused4_eval_k%d%s.inc" % (K, "_box" if BOX else "") if SINGLE_ACC else "fc_rq_fused3_eval.inc")
 path = os.environ.get("FC_GEN_OUT", path)     # probe builds (tools/probe/build_f4_variants.sh)
 text = "\n".join(out) + "\n"
 if "--check" in sys.argv:      # tests/test_host_logic.py: the committed file is what this script generates
