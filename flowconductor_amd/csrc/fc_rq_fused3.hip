@@ -41,7 +41,7 @@
 #include "../../include/flowcon_hip.h"
 
 // tools/probe/build_fused_variants.sh only: ablation builds (1 no evaluation, 4 no MFMAs, 8 loads from L2,
-// 16 clock stamps).
+// 16 clock stamps, 32 no h conversion).
 #ifndef FC_ABL
 #define FC_ABL 0
 #endif
@@ -233,6 +233,15 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   // thread tid holds h[row (tid >> 4) + 32 k][4 (tid & 15) ..]: the 16 threads of a row are 16 adjacent lanes
   auto park_h = [&](int buf, int xbuf3, int k, const float4& hvk) __attribute__((always_inline)) {
     const int c = (tid & 15) * 4, r = (tid >> 4) + 32 * k;
+#if FC_ABL & 32   // ablation: the tile arrives already split (no conversion arithmetic): upper bound of what a producer-side split buys
+    {
+      _Float16* dst = hbuf + (buf * 2 * R + r) * kHB + c;
+      *reinterpret_cast<u32x2*>(dst) = u32x2{__float_as_uint(hvk.x) & 0x3bff3bffu, __float_as_uint(hvk.y) & 0x3bff3bffu};
+      *reinterpret_cast<u32x2*>(dst + kHPiece) = u32x2{__float_as_uint(hvk.z) & 0x3bff3bffu, __float_as_uint(hvk.w) & 0x3bff3bffu};
+      if ((tid & 15) == 0) hscale[xbuf3 * R + r] = 1.f;
+      return;
+    }
+#endif
     const float v[4] = {hvk.x, hvk.y, hvk.z, hvk.w};
     const float m = row16_allmax(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     float sc, un;
