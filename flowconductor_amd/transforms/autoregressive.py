@@ -309,40 +309,58 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
     # ---- density direction on the fused kernels ------------------------------------------------------------------
     # One MADE pass yields the parameters of all D dims, so the forward is a coupling layer that transforms every
     # column: hidden stack in fc_resnet_hidden (pre-masked weights), masked final Linear + spline in
-    # fc_rq_spline_fused_linear -- the [N, D (3K-1)] parameter tensor never reaches HBM.  Shapes: D <= 32, hidden 64,
-    # K = 8, linear tails (the fused kernel's), inference only.
-    def _fused_forward_ok(self, inputs, context):
+    # fc_rq_spline_fused_linear (K = 8, linear tails) or fc_rq_spline_fused_general (the reference's defaults --
+    # num_bins = 10, tails = None on the [-1.2, 1.2] box, autoregressive.py:536,595 -- and every other K = 4..16) -- the
+    # [N, D (3K-/+1)] parameter tensor never reaches HBM.  Shapes: D <= 32, hidden <= 64, inference only.
+    def _fused_forward_mode(self, inputs, context):
+        """None, "k8" or "general"."""
         net = self.autoregressive_net
-        return (inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+        if not (inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
                 and options.get("fused_final_layer") and options.get("fused_hidden")
                 and isinstance(net, made_module.MADE) and not hasattr(net, "hidden_features")
                 and net.final_layer.in_features <= 64 and net.hip_hidden_supported(context)
-                and inputs.shape[0] >= ops.FUSED_ROWS
-                and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], inputs.shape[1],
-                                               net.final_layer.in_features, self.num_bins, self.tails)
-                and not ops.has_hooks(net) and not self._needs_grad(inputs))
+                and inputs.shape[0] >= ops.FUSED_ROWS and not ops.has_hooks(net) and not self._needs_grad(inputs)):
+            return None
+        n, d = inputs.shape
+        if ops.fused_linear_supported(n, d, d, net.final_layer.in_features, self.num_bins, self.tails):
+            return "k8"
+        if ops.fused_general_supported(n, d, d, 64, self.num_bins, self.tails):
+            return "general"
+        return None
 
-    def _packed_final_layer(self, device):
+    def _fused_forward_ok(self, inputs, context):
+        return self._fused_forward_mode(inputs, context) is not None
+
+    def _packed_final_layer(self, device, mode="k8"):
         lin = self.autoregressive_net.final_layer
         key = ops.cache_key(lin.weight, lin.bias)
-        if getattr(self, "_packed", None) is None or self._packed[0] != key:
+        if getattr(self, "_packed", None) is None or self._packed[0] != (key, mode):
             masked = (lin.weight * lin.mask).detach()
-            w_pad, b_pad = ops.pack_final_layer(masked, lin.bias, self.num_bins)
-            cols = torch.arange(lin.out_features // (3 * self.num_bins - 1), dtype=torch.int32, device=device)
-            self._packed = (key, masked, w_pad, b_pad, cols)
+            if mode == "k8":
+                packed = ops.pack_final_layer(masked, lin.bias, self.num_bins)
+            else:
+                packed = ops.pack_final_layer_general(masked, lin.bias, self.num_bins, self.tails, 64)
+            cols = torch.arange(lin.out_features // self._output_dim_multiplier(), dtype=torch.int32, device=device)
+            self._packed = ((key, mode), masked) + tuple(packed) + (cols,)
         return self._packed[1:]
 
     def forward(self, inputs, context=None):
-        if not self._fused_forward_ok(inputs, context):
+        mode = self._fused_forward_mode(inputs, context)
+        if mode is None:
             return super().forward(inputs, context)
         hidden = self._hidden(inputs, context)
-        _, w_pad, b_pad, cols = self._packed_final_layer(inputs.device)
         kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                   min_bin_height=self.min_bin_height, min_derivative=self.min_derivative, wh_divisor=1.0,
                   enable_identity_init=True)
         n = inputs.shape[0]
         body = n - n % ops.FUSED_ROWS
-        outputs, logabsdet = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_pad, b_pad, cols, **kw)
+        if mode == "k8":
+            _, w_pad, b_pad, cols = self._packed_final_layer(inputs.device)
+            outputs, logabsdet = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_pad, b_pad, cols, **kw)
+        else:
+            _, w_frag, w_un, b_pad, cols = self._packed_final_layer(inputs.device, "general")
+            outputs, logabsdet = ops.rq_spline_fused_general(inputs[:body], hidden[:body], w_frag, w_un, b_pad, cols,
+                                                             tails=self.tails, left=-1.2, right=1.2, bottom=-1.2, top=1.2, **kw)
         if body < n:   # the < 32 leftover rows: masked final Linear + the stand-alone kernel
             out_b, lad_b = self._elementwise_forward(inputs[body:], self._final(hidden[body:]))
             outputs, logabsdet = torch.cat((outputs, out_b)), torch.cat((logabsdet, lad_b))

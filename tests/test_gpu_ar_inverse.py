@@ -140,6 +140,45 @@ def test_rq_autoregressive_forward_on_fused_kernels(features, n, device, monkeyp
     assert maxdiff(y, y_unfused) <= tol_y and maxdiff(lad, lad_unfused) <= tol_l
 
 
+@pytest.mark.parametrize("bins,tails,features,n", [(10, None, 6, 1000), (5, None, 32, 4096), (10, "linear", 17, 77),
+                                                    (16, None, 3, 64), (10, None, 4, 40)])
+def test_rq_autoregressive_forward_general_shapes(bins, tails, features, n, device, monkeypatch):
+    """The reference's DEFAULT AR-RQ layer (num_bins = 10, tails = None: the [-1.2, 1.2] box, autoregressive.py:536,595)
+    and other bin counts: masked final Linear + spline in fc_rq_spline_fused_general.  Against the oracle in
+    float32 / float64 and the unfused path; outside the box the layer raises like the reference."""
+    from flowconductor_amd import ops, transforms as T
+
+    torch.manual_seed(bins + features)
+    t = T.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(features, 64, num_bins=bins, tails=tails, tail_bound=3.0,
+                                                                  num_blocks=2).eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n, features, generator=g) * 1.4 if tails == "linear" else torch.rand(n, features, generator=g) * 2.3 - 1.15
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(t, x.clone())
+        ref_y64, ref_lad64 = O.transform_apply(copy.deepcopy(t).double(), x.double())
+    t = t.to(device)
+    with torch.no_grad():
+        with ops.KernelTimer("fc_rq_spline_fused_general") as timer:
+            y, lad = t(x.to(device))
+        assert len(timer.pairs) == 1, "the general fused final-layer + spline kernel did not run"
+        monkeypatch.setitem(options._values, "fused_final_layer", False)
+        y_unfused, lad_unfused = t(x.to(device))
+        monkeypatch.setitem(options._values, "fused_final_layer", True)
+    tol_y = 2e-5 * max(1.0, float(ref_y.abs().max())) + 4 * maxdiff(ref_y, ref_y64)
+    tol_l = 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10) + 4 * maxdiff(ref_lad, ref_lad64)
+    assert maxdiff(y, ref_y64) <= tol_y and maxdiff(lad, ref_lad64) <= tol_l
+    assert maxdiff(y, y_unfused) <= tol_y and maxdiff(lad, lad_unfused) <= tol_l
+    if tails is None:
+        bad = x.clone()
+        bad[3, 1] = 1.3
+        with pytest.raises(T.InputOutsideDomain):
+            with torch.no_grad():
+                t(bad.to(device))
+
+
 def test_readme_maf_flow_runs_its_made_on_the_hidden_kernel(device):
     """BASELINE configs[0] (the README flow: 2 x [MAF(features=2, hidden_features=4), RandomPermutation]): a MADE with
     4 hidden units runs zero-padded in the 64-wide matrix-core kernels -- the density direction as ONE kernel per layer
