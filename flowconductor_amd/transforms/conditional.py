@@ -392,31 +392,49 @@ class ConditionalPiecewiseRationalQuadraticTransform(ConditionalTransform):
     def _inverse_given_params(self, inputs, autoregressive_params):
         return self._elementwise(inputs, autoregressive_params, inverse=True)
 
-    # K = 8, linear tails, <= 32 features, ResidualNet(hidden <= 64): final Linear + spline in one kernel, both
-    # directions in one pass (the parameters depend on the context only)
-    def _fused_ok(self, inputs, context):
-        return (context is not None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+    # <= 32 features, ResidualNet(hidden <= 64): final Linear + spline in one kernel, both directions in one pass (the
+    # parameters depend on the context only) -- fc_rq_spline_fused_linear at K = 8 with linear tails,
+    # fc_rq_spline_fused_general for the other shapes (the constructor's defaults num_bins = 10, tails = None included)
+    def _fused_mode(self, inputs, context):
+        """None, "k8" or "general"."""
+        if not (context is not None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
                 and inputs.shape[0] == context.shape[0] and options.get("fused_final_layer")
-                and self._hip_hidden_ok(context) and not (torch.is_grad_enabled() and inputs.requires_grad)
-                and ops.fused_linear_supported(inputs.shape[0], inputs.shape[1], inputs.shape[1],
-                                               self.conditional_net.hidden_features, self.num_bins, self.tails))
+                and self._hip_hidden_ok(context) and not (torch.is_grad_enabled() and inputs.requires_grad)):
+            return None
+        n, d = inputs.shape
+        hidden = self.conditional_net.hidden_features
+        if ops.fused_linear_supported(n, d, d, hidden, self.num_bins, self.tails):
+            return "k8"
+        if hidden <= 64 and ops.fused_general_supported(n, d, d, 64, self.num_bins, self.tails):
+            return "general"
+        return None
+
+    def _fused_ok(self, inputs, context):
+        return self._fused_mode(inputs, context) is not None
 
     def _fused(self, inputs, context, inverse):
+        mode = self._fused_mode(inputs, context)
         net = self.conditional_net
         lin = net.final_layer
-        key = ops.cache_key(lin.weight, lin.bias)
+        key = (ops.cache_key(lin.weight, lin.bias), mode)
         if getattr(self, "_packed", None) is None or self._packed[0] != key:
-            w_pad, b_pad = ops.pack_final_layer(lin.weight, lin.bias, self.num_bins)
+            if mode == "k8":
+                packed = ops.pack_final_layer(lin.weight, lin.bias, self.num_bins)
+            else:
+                packed = ops.pack_final_layer_general(lin.weight, lin.bias, self.num_bins, self.tails, 64)
             cols = torch.arange(self.features, dtype=torch.int32, device=lin.weight.device)
-            self._packed = (key, w_pad, b_pad, cols)
-        _, w_pad, b_pad, cols = self._packed
+            self._packed = (key,) + tuple(packed) + (cols,)
         hidden = self._hidden(context)
         kw = dict(num_bins=self.num_bins, tail_bound=self.tail_bound, min_bin_width=self.min_bin_width,
                   min_bin_height=self.min_bin_height, min_derivative=self.min_derivative,
                   wh_divisor=float(np.sqrt(net.hidden_features)), enable_identity_init=True, inverse=inverse)
         n = inputs.shape[0]
         body = n - n % ops.FUSED_ROWS
-        outputs, logabsdet = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], w_pad, b_pad, cols, **kw)
+        if mode == "k8":
+            outputs, logabsdet = ops.rq_spline_fused_linear(inputs[:body], hidden[:body], *self._packed[1:], **kw)
+        else:
+            outputs, logabsdet = ops.rq_spline_fused_general(inputs[:body], hidden[:body], *self._packed[1:], tails=self.tails,
+                                                             left=-1.2, right=1.2, bottom=-1.2, top=1.2, **kw)
         if body < n:
             out_b, lad_b = self._elementwise(inputs[body:].contiguous(), net.final_from_padded(hidden[body:]), inverse)
             outputs, logabsdet = torch.cat((outputs, out_b)), torch.cat((logabsdet, lad_b))

@@ -181,11 +181,12 @@ def test_conditional_autoregressive_flow(kind, device, monkeypatch):
     assert maxdiff(back, x) <= 3e-4 * max(1.0, float(x.abs().max())) + 4 * floor
 
 
-@pytest.mark.parametrize("kind", ["rq", "rq_k5", "sos", "lu", "shift"])
+@pytest.mark.parametrize("kind", ["rq", "rq_k5", "rq_default", "sos", "lu", "shift"])
 def test_hyper_network_transforms_on_the_matrix_core_kernels(kind, device, monkeypatch):
     """Conditional ("hyper-network") transforms (conditional.py): the ResidualNet on the context runs its hidden stack in
-    fc_resnet_hidden, and for the RQ form with K = 8 / linear tails the final Linear + spline run fused, forward and
-    inverse in one pass each.  Against the oracle and the PyTorch hyper-network."""
+    fc_resnet_hidden, and for the RQ form the final Linear + spline run fused, forward and inverse in one pass each
+    (K = 8 / linear tails: fc_rq_spline_fused_linear; other shapes, the constructor's defaults num_bins = 10 / tails = None
+    on the [-1.2, 1.2] box included: fc_rq_spline_fused_general).  Against the oracle and the PyTorch hyper-network."""
     from flowconductor_amd import transforms as T
 
     torch.manual_seed(23)
@@ -194,6 +195,8 @@ def test_hyper_network_transforms_on_the_matrix_core_kernels(kind, device, monke
         t = T.ConditionalPiecewiseRationalQuadraticTransform(d, 48, ctx_f, num_bins=8, tails="linear", tail_bound=3.0)
     elif kind == "rq_k5":
         t = T.ConditionalPiecewiseRationalQuadraticTransform(d, 64, ctx_f, num_bins=5, tails="linear", tail_bound=3.0)
+    elif kind == "rq_default":
+        t = T.ConditionalPiecewiseRationalQuadraticTransform(d, 64, ctx_f)
     elif kind == "sos":
         t = T.ConditionalSumOfSigmoidsTransform(d, 32, ctx_f, n_sigmoids=8)
     elif kind == "lu":
@@ -205,16 +208,18 @@ def test_hyper_network_transforms_on_the_matrix_core_kernels(kind, device, monke
         for p in t.parameters():
             if p.is_floating_point():
                 p.mul_(1.3)
-    x = torch.randn(n, d) * 1.1
+    x = torch.rand(n, d) * 2.3 - 1.15 if kind == "rq_default" else torch.randn(n, d) * 1.1
     c = torch.randn(n, ctx_f)
     with torch.no_grad():
         ref_y, ref_lad = O.transform_apply(t, x.clone(), c)
     t = t.to(device)
     with torch.no_grad():
-        with ops.KernelTimer("fc_resnet_hidden") as hid, ops.KernelTimer("fc_rq_spline_fused_linear") as fused:
+        with ops.KernelTimer("fc_resnet_hidden") as hid, ops.KernelTimer("fc_rq_spline_fused_linear") as fused, \
+                ops.KernelTimer("fc_rq_spline_fused_general") as general:
             y, lad = t(x.to(device), c.to(device))
         assert len(hid.pairs) == 1, "the hyper-network's hidden stack did not run in fc_resnet_hidden"
         assert len(fused.pairs) == (1 if kind == "rq" else 0)
+        assert len(general.pairs) == (1 if kind in ("rq_k5", "rq_default") else 0)
         back, lad_inv = t.inverse(y, c.to(device))
         monkeypatch.setitem(options._values, "fused_hidden", False)
         y_torch, lad_torch = t(x.to(device), c.to(device))
