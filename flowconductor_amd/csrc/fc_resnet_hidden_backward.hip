@@ -69,7 +69,8 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
   constexpr bool kWtLds = K0S == 1;
   f16x8* wts = reinterpret_cast<f16x8*>(ids + 32 * K0S);                           // [16 fragments][64 lanes]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (the wave index as a scalar: tile and strip addresses derived from it stay SGPR bases)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int s16 = lane & 15, g = lane >> 4;
   const int D = a.D, k0 = a.k0;
   if ((int64_t)blockIdx.x >= a.rounds) return;
