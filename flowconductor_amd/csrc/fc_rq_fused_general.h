@@ -60,10 +60,10 @@ struct GenShape {
   static constexpr int TC = T > 8 ? (T + 1) / 2 : T;   // fragments fetched per batch (register budget)
 };
 
-inline size_t gen_lds_bytes(int d, int h) {
-  const size_t hb = (size_t)2 * 2 * kGenRows * (h + 16) * 2;      // [buf][piece][row][H + 16] f16
-  const size_t xb = (size_t)2 * kGenRows * (d + 4) * 4;           // [buf][row][D + 4]
-  return hb + xb + 2 * kGenRows * 4 /* row scales */ + 2 * 8 * kGenRows * 4 /* logabsdet partials */ + 32 * 4 +
+inline size_t gen_lds_bytes(int d, int h, int rows = kGenRows) {
+  const size_t hb = (size_t)2 * 2 * rows * (h + 16) * 2;      // [buf][piece][row][H + 16] f16
+  const size_t xb = (size_t)2 * rows * (d + 4) * 4;           // [buf][row][D + 4]
+  return hb + xb + 2 * rows * 4 /* row scales */ + 2 * 8 * rows * 4 /* logabsdet partials */ + 32 * 4 +
          (size_t)32 * 52 * 4 /* bias image, PP <= 52 */;
 }
 
@@ -81,6 +81,19 @@ __device__ __forceinline__ float group_allmax(float m, int lane) {
 //  waiting for weight fragments from L2: 0.79 -> 0.73 ms per 2^20 rows at K = 8 / hidden 64; K = 10 needs 171 registers)
 constexpr int gen_waves_per_simd(int k, int hq) { return (k <= 8 && hq <= 2) ? 4 : 2; }
 
+// 16-sample blocks per tile.  A wave streams its weight fragments from L2 once per TILE, so at hidden 128 / 256 (64 / 128 KB
+// per wave and tile; K = 10 / hidden 256: 59 % of the wave cycles waiting on memory, profiles/r03_general_h256_sq_counters.txt)
+// three blocks per tile cut the stream by a third -- where the accumulators (T <= 8 tiles x 3 blocks) and the LDS image
+// (48-row h and x tiles, D <= 85) fit.  The last 48-row tile may be partial (the entry takes multiples of 32 rows).
+// (the 128-register kernels that share a CU in pairs -- K <= 8 at hidden 128 -- have no room for a third accumulator set)
+constexpr int gen_blocks_static(int k, int t, int hq) { return (hq >= 2 && t <= 8 && gen_waves_per_simd(k, hq) == 2) ? 3 : 2; }
+inline int gen_blocks(int k, int t, int hq, int d) {
+#ifdef FC_GEN_TWO_BLOCKS   // probe builds: A/B against the two-block tiles
+  return 2;
+#endif
+  return (gen_blocks_static(k, t, hq) == 3 && 48 * d / 4 <= 2 * kGenThreads && gen_lds_bytes(d, 64 * hq, 48) <= 160 * 1024) ? 3 : 2;
+}
+
 // Round 3: PARTLY RESIDENT weights at hidden 64 for the shapes that live at two waves per SIMD anyway (K >= 9: the
 // reference's default K = 10).  Those kernels used 157 - 219 of their 256 registers and spent most of their time waiting
 // for the same 16 - 24 KB of weight fragments from L2 on every 32-row tile (K = 10: 0.97 ms per 2^20 rows against 0.43 ms
@@ -95,12 +108,16 @@ constexpr int gen_resident_pairs(int t, int hq, int k) {
   return k == 9 ? 10 : k == 10 ? 7 : k == 11 ? 3 : 0;
 }
 
-template <int K, bool kTails, int HQ>
+template <int K, bool kTails, int HQ, int NBK = 2>
 __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fused_general_kernel(RQOp<K> op, GenArgs a) {
   using S = GenShape<K, kTails>;
-  constexpr int PP = S::PP, T = S::T, TC = S::TC;
-  constexpr int RES = gen_resident_pairs(T, HQ, K);
-  constexpr int R = kGenRows;
+  constexpr int PP = S::PP, T = S::T;
+  [[maybe_unused]] constexpr int TC = S::TC;
+  constexpr int RES = NBK == 2 ? gen_resident_pairs(T, HQ, K) : 0;
+  constexpr int R = 16 * NBK;
+  constexpr bool kPartial = (R % kGenRows) != 0;         // the last tile may hold fewer rows
+  constexpr int HV = R * 16 * HQ / kGenThreads;          // float4 of the h tile per thread
+  static_assert(R * 16 * HQ % kGenThreads == 0, "h tile: whole float4 rounds");
   constexpr int H = 64 * HQ, KS = H / 32, HB = H + 16;   // row stride 32 mod 64 bytes: conflict-free b128 fragment reads (tools/lds_conflicts.py)
   constexpr int kRowLanes = H / 4;                       // threads that share a row of the h tile
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
@@ -117,7 +134,8 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int s16 = lane & 15, g = lane >> 4;
   const int64_t stride = gridDim.x, tile0 = blockIdx.x;
-  if (tile0 >= a.tiles) return;
+  const int64_t n_rows = a.tiles * kGenRows, tiles = (n_rows + R - 1) / R;
+  if (tile0 >= tiles) return;
   // (lanes of dims beyond dt evaluate the first transformed column again, results dropped: whatever error they flag is that
   //  column's own -- column 0 may be an identity feature outside the box, which the reference never checks, coupling.py:79-88)
   if (tid < 32) cs[tid] = a.cols[tid < a.dt ? tid : 0];
@@ -144,17 +162,26 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
 
   uint32_t err = 0;
   const int xvec = R * D / 4;                     // float4 per x tile (R * D is a multiple of 4)
-  float4 hv[HQ], xv0, xv1;
+  float4 hv[HV], xv0, xv1;
   xv0 = xv1 = float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < HQ; ++k) hv[k] = float4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < HV; ++k) hv[k] = float4{0.f, 0.f, 0.f, 0.f};
+  // rows of tile t that exist (a partial last tile: the missing rows are read as the tile's first float4 -- any finite
+  // values do --, evaluated like the others and never written out)
+  auto rows_of = [&](int64_t t) __attribute__((always_inline)) {
+    if constexpr (!kPartial) return R;
+    const int64_t left = n_rows - t * R;
+    return left < R ? (int)left : R;
+  };
   auto fetch = [&](int64_t t) __attribute__((always_inline)) {
+    const int rows = rows_of(t);
+    const int hvalid = rows * kRowLanes, xvalid = kPartial ? rows * D / 4 : xvec;
     const float4* hg = reinterpret_cast<const float4*>(a.h + t * R * H);
 #pragma unroll
-    for (int k = 0; k < HQ; ++k) hv[k] = hg[tid + kGenThreads * k];
+    for (int k = 0; k < HV; ++k) hv[k] = hg[(!kPartial || tid + kGenThreads * k < hvalid) ? tid + kGenThreads * k : 0];
     const float4* xg = reinterpret_cast<const float4*>(a.x + t * R * D);
-    xv0 = xg[tid < xvec ? tid : 0];
-    xv1 = xg[tid + kGenThreads < xvec ? tid + kGenThreads : 0];
+    xv0 = xg[tid < xvalid ? tid : 0];
+    xv1 = xg[tid + kGenThreads < xvalid ? tid + kGenThreads : 0];
   };
   auto xslot = [&](int buf, int i) __attribute__((always_inline)) {
     if (!pad_x) return reinterpret_cast<float4*>(xbuf + buf * R * (D + 4) + 4 * i);
@@ -165,7 +192,7 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
   // row are an aligned group of 16 / 32 / 64 lanes of one wave
   auto park = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < HQ; ++k) {
+    for (int k = 0; k < HV; ++k) {
       const int f = tid + kGenThreads * k, r = f / kRowLanes, c = (f % kRowLanes) * 4;
       const float v[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w};
       const float m = group_allmax<kRowLanes>(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), lane);
@@ -191,10 +218,12 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
     return *reinterpret_cast<const f16x8*>(hbuf + ((size_t)(buf * 2 + piece) * R + 16 * blk + s16) * HB + 32 * ks + 8 * g);
   };
   auto write_out = [&](int64_t t, int buf) __attribute__((always_inline)) {
+    const int rows = rows_of(t);
+    const int xvalid = kPartial ? rows * D / 4 : xvec;
     float4* yg = reinterpret_cast<float4*>(a.y + t * R * D);
-    if (tid < xvec) yg[tid] = *xslot(buf, tid);
-    if (tid + kGenThreads < xvec) yg[tid + kGenThreads] = *xslot(buf, tid + kGenThreads);
-    if (tid < R) {
+    if (tid < xvalid) yg[tid] = *xslot(buf, tid);
+    if (tid + kGenThreads < xvalid) yg[tid + kGenThreads] = *xslot(buf, tid + kGenThreads);
+    if (tid < rows) {
       const float* lp = lpart + buf * 8 * R + tid;
       float l = lp[0];
 #pragma unroll
@@ -208,14 +237,14 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
   park(0);
   __syncthreads();
   int buf = 0;
-  for (int64_t tile = tile0; tile < a.tiles; tile += stride) {
-    const bool has_next = tile + stride < a.tiles;
+  for (int64_t tile = tile0; tile < tiles; tile += stride) {
+    const bool has_next = tile + stride < tiles;
     if (has_next) fetch(tile + stride);
     if (active) {
-      // ---- parameters of both blocks: acc[b][t] = sum over k of (scaled W)(scaled h)^T, three split terms ------------
-      f32x4 acc[2][T];
+      // ---- parameters of all blocks: acc[b][t] = sum over k of (scaled W)(scaled h)^T, three split terms -------------
+      f32x4 acc[NBK][T];
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NBK; ++b)
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (RES > 0) {
@@ -253,37 +282,96 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
           for (int i = 0; i < CH; ++i)
             if (c0 + i < NS) products(RES + c0 + i, sh[i], sl[i]);
         }
-      } else
+      } else if constexpr (gen_waves_per_simd(K, HQ) == 4 || T > 10) {
+        // (the 128-register kernels: four waves per SIMD cover each other's fragment loads; T > 10: two fragment sets in
+        //  flight next to 2 T accumulators spill.  A k-step's fragments are requested together, in batches of TC)
+        static_assert(NBK == 2, "two blocks per tile");
 #pragma unroll 1
-      for (int ks = 0; ks < KS; ++ks) {
-        const f16x8 bh0 = hfrag(buf, 0, 0, ks), bl0 = hfrag(buf, 0, 1, ks);
-        const f16x8 bh1 = hfrag(buf, 1, 0, ks), bl1 = hfrag(buf, 1, 1, ks);
-        const f16x8* wk = wsrc + (size_t)ks * T * 2 * 64;
+        for (int ks = 0; ks < KS; ++ks) {
+          const f16x8 bh0 = hfrag(buf, 0, 0, ks), bl0 = hfrag(buf, 0, 1, ks);
+          const f16x8 bh1 = hfrag(buf, 1, 0, ks), bl1 = hfrag(buf, 1, 1, ks);
+          const f16x8* wk = wsrc + (size_t)ks * T * 2 * 64;
 #pragma unroll
-        for (int t0 = 0; t0 < T; t0 += TC) {
-          f16x8 ah[TC], al[TC];
+          for (int t0 = 0; t0 < T; t0 += TC) {
+            f16x8 ah[TC], al[TC];
 #pragma unroll
-          for (int t = 0; t < TC; ++t)
-            if (t0 + t < T) {
-              ah[t] = wk[((t0 + t) * 2 + 0) * 64];
-              al[t] = wk[((t0 + t) * 2 + 1) * 64];
-            }
+            for (int t = 0; t < TC; ++t)
+              if (t0 + t < T) {
+                ah[t] = wk[((t0 + t) * 2 + 0) * 64];
+                al[t] = wk[((t0 + t) * 2 + 1) * 64];
+              }
 #pragma unroll
-          for (int t = 0; t < TC; ++t)
-            if (t0 + t < T) {
-              // small products first; consecutive MFMAs alternate between the two blocks' accumulators
-              acc[0][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh0, acc[0][t0 + t], 0, 0, 0);
-              acc[1][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh1, acc[1][t0 + t], 0, 0, 0);
-              acc[0][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl0, acc[0][t0 + t], 0, 0, 0);
-              acc[1][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl1, acc[1][t0 + t], 0, 0, 0);
-              acc[0][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh0, acc[0][t0 + t], 0, 0, 0);
-              acc[1][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh1, acc[1][t0 + t], 0, 0, 0);
-            }
+            for (int t = 0; t < TC; ++t)
+              if (t0 + t < T) {
+                // small products first; consecutive MFMAs alternate between the two blocks' accumulators
+                acc[0][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh0, acc[0][t0 + t], 0, 0, 0);
+                acc[1][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh1, acc[1][t0 + t], 0, 0, 0);
+                acc[0][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl0, acc[0][t0 + t], 0, 0, 0);
+                acc[1][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl1, acc[1][t0 + t], 0, 0, 0);
+                acc[0][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh0, acc[0][t0 + t], 0, 0, 0);
+                acc[1][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh1, acc[1][t0 + t], 0, 0, 0);
+              }
+          }
+        }
+      } else {
+        // Each k-step's fragments come in two halves (tiles [0, C0) and [C0, T)); a half is requested while the other
+        // half's products issue -- the second half of k-step ks during the first half's MFMAs, the first half of ks + 1
+        // during the second's -- so a wave always has an L2 request in flight behind its matrix work (with the loads of
+        // a whole k-step requested and waited for together the kernel spent 59 % of its wave cycles waiting on memory,
+        // profiles/r03_general_h256_sq_counters.txt).
+        constexpr int C0 = (T + 1) / 2, C1 = T - C0;
+        f16x8 a0h[C0], a0l[C0], a1h[C1 > 0 ? C1 : 1], a1l[C1 > 0 ? C1 : 1];
+        auto request0 = [&](int ks) __attribute__((always_inline)) {
+          const f16x8* wk = wsrc + (size_t)ks * T * 2 * 64;
+#pragma unroll
+          for (int t = 0; t < C0; ++t) {
+            a0h[t] = wk[(t * 2 + 0) * 64];
+            a0l[t] = wk[(t * 2 + 1) * 64];
+          }
+        };
+        auto request1 = [&](int ks) __attribute__((always_inline)) {
+          const f16x8* wk = wsrc + (size_t)ks * T * 2 * 64;
+#pragma unroll
+          for (int t = 0; t < C1; ++t) {
+            a1h[t] = wk[((C0 + t) * 2 + 0) * 64];
+            a1l[t] = wk[((C0 + t) * 2 + 1) * 64];
+          }
+        };
+        request0(0);
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ++ks) {
+          f16x8 bh[NBK], bl[NBK];
+#pragma unroll
+          for (int b = 0; b < NBK; ++b) {
+            bh[b] = hfrag(buf, b, 0, ks);
+            bl[b] = hfrag(buf, b, 1, ks);
+          }
+          // small products first; consecutive MFMAs go round the blocks' accumulators
+          auto products = [&](int t, const f16x8& ah, const f16x8& al) __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[b], acc[b][t], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[b], acc[b][t], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[b], acc[b][t], 0, 0, 0);
+          };
+          // (sched_barrier: left alone the scheduler sinks every request to just before its first use -- one fragment pair,
+          //  nine MFMAs, ahead -- which covers a fifth of an L2 round trip)
+          request1(ks);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < C0; ++t) products(t, a0h[t], a0l[t]);
+          __builtin_amdgcn_sched_barrier(0);
+          request0(ks + 1 < KS ? ks + 1 : ks);      // (the last k-step asks for its own first half again: no branch in the stream)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < C1; ++t) products(C0 + t, a1h[t], a1l[t]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      // ---- the two elements of this lane: (sample 16 b + s16, dim 4 wave + g) --------------------------------------
+      // ---- the elements of this lane: (sample 16 b + s16, dim 4 wave + g) -------------------------------------------
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
+      for (int b = 0; b < NBK; ++b) {
         const int row = 16 * b + s16;
         float* xr = xbuf + buf * R * (D + 4) + row * XS + cs[(4 * wave + g) & 31];
         const float xin = *xr;
@@ -310,19 +398,27 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
   if (err && a.err) atomicOr(a.err, err);
 }
 
-template <int K, bool kTails, int HQ>
-hipError_t launch_general_hq(const RQOp<K>& op, const GenArgs& a, hipStream_t stream) {
-  const size_t lds = gen_lds_bytes(a.D, a.H);
+template <int K, bool kTails, int HQ, int NBK>
+hipError_t launch_general_nbk(const RQOp<K>& op, const GenArgs& a, hipStream_t stream) {
+  const size_t lds = gen_lds_bytes(a.D, a.H, 16 * NBK);
   if (lds > 160 * 1024) return hipErrorInvalidConfiguration;
   static PerDeviceOnce attr;
   const hipError_t ea = ensure_max_dynamic_lds(
-      attr, reinterpret_cast<const void*>(&rq_fused_general_kernel<K, kTails, HQ>), 160 * 1024);
+      attr, reinterpret_cast<const void*>(&rq_fused_general_kernel<K, kTails, HQ, NBK>), 160 * 1024);
   if (ea != hipSuccess) return ea;
-  const int64_t cus = device_cu_count();
+  const int64_t cus = device_cu_count(), tiles = (a.tiles * kGenRows + 16 * NBK - 1) / (16 * NBK);
   const int64_t wgs = cus * ((gen_waves_per_simd(K, HQ) == 4 && 2 * lds <= 160 * 1024) ? 2 : 1);
-  const unsigned grid = (unsigned)(wgs < a.tiles ? wgs : a.tiles);
-  hipLaunchKernelGGL((rq_fused_general_kernel<K, kTails, HQ>), dim3(grid), dim3(kGenThreads), lds, stream, op, a);
+  const unsigned grid = (unsigned)(wgs < tiles ? wgs : tiles);
+  hipLaunchKernelGGL((rq_fused_general_kernel<K, kTails, HQ, NBK>), dim3(grid), dim3(kGenThreads), lds, stream, op, a);
   return hipGetLastError();
+}
+
+template <int K, bool kTails, int HQ>
+hipError_t launch_general_hq(const RQOp<K>& op, const GenArgs& a, hipStream_t stream) {
+  if constexpr (gen_blocks_static(K, GenShape<K, kTails>::T, HQ) == 3) {
+    if (gen_blocks(K, GenShape<K, kTails>::T, HQ, a.D) == 3) return launch_general_nbk<K, kTails, HQ, 3>(op, a, stream);
+  }
+  return launch_general_nbk<K, kTails, HQ, 2>(op, a, stream);
 }
 
 template <int K, bool kTails>
