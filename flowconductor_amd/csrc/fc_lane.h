@@ -59,4 +59,34 @@ __device__ __forceinline__ float rows4_allmax(float v, int lane) {
 // max over all 64 lanes, every lane gets it
 __device__ __forceinline__ float wave64_allmax(float v, int lane) { return rows4_allmax(row16_allmax(v), lane); }
 
+// Eight wave sums at once.  v_permlane32_swap / v_permlane16_swap with two DIFFERENT registers are a merge step: after
+// swap(a, b) one result holds a's lower half next to b's lower half and the other the two upper halves, so their sum is
+// a's pair sums in one half of the wave and b's in the other -- two vectors become one per swap + add, no selects.  8 -> 4
+// (xor 32) -> 2 (xor 16), then the two vectors' 16-lane rows each hold one sum's partials: four DPP rotations each.
+// 6 swaps + 6 adds + 8 DPP adds for eight sums (eight separate wave64_allsum: 64 cross-lane steps).  The sums come back
+// wave-uniform (v_readlane).
+__device__ __forceinline__ void wave64_sum8(const float (&s)[8], float (&out)[8]) {
+#ifdef FC_SUM8_SIMPLE   // probe builds: eight separate reductions
+  for (int k = 0; k < 8; ++k) out[k] = wave64_allsum(s[k], threadIdx.x & 63);
+  return;
+#endif
+  // (inline asm: with two different operands that stay live, hipcc 7.2's __builtin_amdgcn_permlane32_swap hands back the
+  //  first result twice -- tools/probe/sum8_check.hip; the s_nop 1 is the VALU-write -> cross-lane-read hazard the compiler
+  //  cannot see inside an asm block)
+  auto merge32 = [](float a, float b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;     // lanes 0-31: a's pair sums, lanes 32-63: b's
+  };
+  auto merge16 = [](float a, float b) {
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;     // rows 0, 2: a's pair sums, rows 1, 3: b's
+  };
+  const float m01 = merge32(s[0], s[1]), m23 = merge32(s[2], s[3]), m45 = merge32(s[4], s[5]), m67 = merge32(s[6], s[7]);
+  // rows of the merged vectors: (s0, s2, s1, s3) and (s4, s6, s5, s7)
+  const float lo = row16_allsum(merge16(m01, m23)), hi = row16_allsum(merge16(m45, m67));
+  auto lane_of = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+  out[0] = lane_of(lo, 0);  out[2] = lane_of(lo, 16); out[1] = lane_of(lo, 32); out[3] = lane_of(lo, 48);
+  out[4] = lane_of(hi, 0);  out[6] = lane_of(hi, 16); out[5] = lane_of(hi, 32); out[7] = lane_of(hi, 48);
+}
+
 }  // namespace fc

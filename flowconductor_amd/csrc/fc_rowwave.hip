@@ -63,11 +63,11 @@ __device__ __forceinline__ void matvec_rows_upper(Row<E>& y, const Row<E>& x, co
                                                   int lane) {
 #pragma unroll
   for (int e = 0; e < E; ++e) y.v[e] = 0.f;
-  // eight rows per step: their loads are issued together (one row at a time the loop waits a full memory latency per
-  // row), then eight independent reductions
+  // Eight rows per step, the NEXT eight requested before the current eight are reduced (one step at a time the wave
+  // waits out a full HBM latency per step: 16 per mat-vec at D = 128), and their eight sums taken together
+  // (wave64_sum8: a third of the cross-lane steps of eight separate reductions).
   constexpr int kRows = 8;
-  for (int i0 = 0; i0 < d; i0 += kRows) {
-    float w[kRows][E];
+  auto request = [&](int i0, float (&w)[kRows][E]) __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
       const int i = i0 + k;
@@ -78,16 +78,75 @@ __device__ __forceinline__ void matvec_rows_upper(Row<E>& y, const Row<E>& x, co
         w[k][e] = (j >= i && j < d && i < d) ? row[j] : 0.f;
       }
     }
+  };
+  auto reduce = [&](int i0, const float (&w)[kRows][E]) __attribute__((always_inline)) {
+    float s[kRows], tot[kRows];
 #pragma unroll
     for (int k = 0; k < kRows; ++k) {
-      float s = 0.f;
+      s[k] = 0.f;
 #pragma unroll
-      for (int e = 0; e < E; ++e) s += w[k][e] * x.v[e];
-      s = wave_sum(s);
+      for (int e = 0; e < E; ++e) s[k] += w[k][e] * x.v[e];
+    }
+    wave64_sum8(s, tot);
+#pragma unroll
+    for (int k = 0; k < kRows; ++k)
 #pragma unroll
       for (int e = 0; e < E; ++e)
-        if (lane + 64 * e == i0 + k) y.v[e] = s;
+        if (lane + 64 * e == i0 + k) y.v[e] = tot[k];
+  };
+  float wa[kRows][E], wb[kRows][E];
+  request(0, wa);
+  for (int i0 = 0; i0 < d; i0 += 2 * kRows) {
+    request(i0 + kRows, wb);
+    __builtin_amdgcn_sched_barrier(0);
+    reduce(i0, wa);
+    request(i0 + 2 * kRows, wa);
+    __builtin_amdgcn_sched_barrier(0);
+    reduce(i0 + kRows, wb);
+  }
+}
+
+// The K reflections of a PER-SAMPLE q [K, d] (this row's block, from HBM): as householder() above, with the q rows
+// requested eight at a time and one batch ahead, and the eight |q|^2 of a batch in one batched reduction; only the
+// (x . q_k) chain is sequential.
+template <int E>
+__device__ __forceinline__ void householder_rows(Row<E>& x, const float* __restrict__ q, int k_count, int d, int lane,
+                                                 bool reverse) {
+  constexpr int kB = 8;
+  auto request = [&](int t0, Row<E> (&qv)[kB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < kB; ++j) {
+      const int t = t0 + j < k_count ? t0 + j : k_count - 1;
+      load_row<E>(qv[j], q + (int64_t)(reverse ? k_count - 1 - t : t) * d, d, lane);
     }
+  };
+  auto apply = [&](int t0, const Row<E> (&qv)[kB]) __attribute__((always_inline)) {
+    float s[kB], sq[kB];
+#pragma unroll
+    for (int j = 0; j < kB; ++j) {
+      s[j] = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) s[j] += qv[j].v[e] * qv[j].v[e];
+    }
+    wave64_sum8(s, sq);
+#pragma unroll
+    for (int j = 0; j < kB; ++j)
+      if (t0 + j < k_count) {
+        const float ip = dot_rows<E>(x, qv[j]);
+        const float c = div_lean(2.f, sq[j]);      // (v_rcp + one correction, <= 1 ulp: the IEEE division costs ten instructions)
+#pragma unroll
+        for (int e = 0; e < E; ++e) x.v[e] = x.v[e] - ip * (c * qv[j].v[e]);
+      }
+  };
+  Row<E> qa[kB], qb[kB];
+  request(0, qa);
+  for (int t0 = 0; t0 < k_count; t0 += 2 * kB) {
+    request(t0 + kB, qb);
+    __builtin_amdgcn_sched_barrier(0);
+    apply(t0, qa);
+    request(t0 + 2 * kB, qa);
+    __builtin_amdgcn_sched_barrier(0);
+    apply(t0 + kB, qb);
   }
 }
 
@@ -103,7 +162,8 @@ __global__ __launch_bounds__(256) void householder_kernel(const float* __restric
     Row<E> r;
     load_row<E>(r, x + row * d, d, lane);
     const float* qr = per_sample ? q + row * (int64_t)k_count * d : q;
-    householder<E>(r, qr, k_count, d, lane, reverse != 0);
+    if (per_sample) householder_rows<E>(r, qr, k_count, d, lane, reverse != 0);     // q from HBM: batched requests
+    else householder<E>(r, qr, k_count, d, lane, reverse != 0);
     store_row<E>(r, y + row * d, d, lane);
   }
 }
@@ -257,7 +317,8 @@ __global__ __launch_bounds__(256) void sylvester_kernel(const float* __restrict_
     const float* bb = per_sample ? bias + row * (int64_t)d : bias;
     const float* rd = per_sample ? rdiag + row * (int64_t)d : rdiag;
     t = z;
-    householder<E, !kPS>(t, qr, m, d, lane, true);          // Q^T z
+    if constexpr (kPS) householder_rows<E>(t, qr, m, d, lane, true);      // Q^T z
+    else householder<E, true>(t, qr, m, d, lane, true);
     if constexpr (kPS) matvec_rows_upper<E>(a, t, r1, d, lane);   // R1 Q^T z (row-major per-sample R, upper part only)
     else matvec<E>(a, t, r1, d, lane, 1);
     float ld = 0.f;
@@ -275,7 +336,8 @@ __global__ __launch_bounds__(256) void sylvester_kernel(const float* __restrict_
     ld = per_sample ? wave_sum(ld) : wave_sum_lds(ld);
     if constexpr (kPS) matvec_rows_upper<E>(t, a, r2, d, lane);   // R2 act
     else matvec<E>(t, a, r2, d, lane, 1);
-    householder<E, !kPS>(t, qr, m, d, lane, false);         // Q R2 act
+    if constexpr (kPS) householder_rows<E>(t, qr, m, d, lane, false);     // Q R2 act
+    else householder<E, true>(t, qr, m, d, lane, false);
 #pragma unroll
     for (int e = 0; e < E; ++e) z.v[e] = z.v[e] + t.v[e];
     store_row<E>(z, y + row * d, d, lane);
@@ -317,16 +379,22 @@ __global__ __launch_bounds__(256) void linear_per_sample_kernel(const float* __r
       ld = wave_sum(ld);
       if (mode == 3) ld = -ld;
     }
-    if (mode == 0) {  // y_i = sum_j M_ij x_j
+    if (mode == 0) {  // y_i = sum_j M_ij x_j: eight rows' sums in one batched reduction (wave64_sum8)
       for (int i0 = 0; i0 < d; i0 += kRows) {
         Row<E> mi[kRows];
         load_rows(i0, mi);
+        float part[kRows], tot[kRows];
 #pragma unroll
         for (int k = 0; k < kRows; ++k) {
-          const float sres = dot_rows<E>(mi[k], v);
+          part[k] = 0.f;
 #pragma unroll
-          for (int e = 0; e < E; ++e) if (lane + 64 * e == i0 + k) out.v[e] = sres;
+          for (int e = 0; e < E; ++e) part[k] += mi[k].v[e] * v.v[e];
         }
+        wave64_sum8(part, tot);
+#pragma unroll
+        for (int k = 0; k < kRows; ++k)
+#pragma unroll
+          for (int e = 0; e < E; ++e) if (lane + 64 * e == i0 + k) out.v[e] = tot[k];
       }
     } else if (mode == 1) {  // y_j = sum_i M_ij x_i: row i scaled by the broadcast x_i
       for (int i0 = 0; i0 < d; i0 += kRows) {
