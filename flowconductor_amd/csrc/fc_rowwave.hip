@@ -415,34 +415,44 @@ __global__ __launch_bounds__(256) void linear_per_sample_kernel(const float* __r
       for (int i0 = 0; i0 < d; i0 += kRows) {
         Row<E> mi[kRows];
         load_rows(i0, mi);
+        // (both sets of eight sums are independent once the chunk's t_i are in place: two batched reductions per chunk
+        //  instead of sixteen sequential ones)
+        float part[kRows], tot[kRows];
 #pragma unroll
         for (int k = 0; k < kRows; ++k) {       // t_i = dg_i x_i + sp sum_{j>i} M_ij x_j
           const int i = i0 + k;
-          float part = 0.f;
+          part[k] = 0.f;
 #pragma unroll
           for (int e = 0; e < E; ++e) {
             const int j = lane + 64 * e;
-            part += (j > i && j < d) ? sp * mi[k].v[e] * v.v[e] : (j == i ? diag.v[e] * v.v[e] : 0.f);
+            part[k] += (j > i && j < d) ? sp * mi[k].v[e] * v.v[e] : (j == i ? diag.v[e] * v.v[e] : 0.f);
           }
-          part = wave_sum(part);
-#pragma unroll
-          for (int e = 0; e < E; ++e) if (lane + 64 * e == i) t.v[e] = part;
         }
+        wave64_sum8(part, tot);
+#pragma unroll
+        for (int k = 0; k < kRows; ++k)
+#pragma unroll
+          for (int e = 0; e < E; ++e) if (lane + 64 * e == i0 + k) t.v[e] = tot[k];
 #pragma unroll
         for (int k = 0; k < kRows; ++k) {       // y_i = t_i + sp sum_{j<i} M_ij t_j
           const int i = i0 + k;
-          float part = 0.f;
+          part[k] = 0.f;
 #pragma unroll
           for (int e = 0; e < E; ++e) {
             const int j = lane + 64 * e;
-            part += j < i ? sp * mi[k].v[e] * t.v[e] : (j == i ? t.v[e] : 0.f);
+            part[k] += j < i ? sp * mi[k].v[e] * t.v[e] : (j == i ? t.v[e] : 0.f);
           }
-          part = wave_sum(part);
-#pragma unroll
-          for (int e = 0; e < E; ++e) if (lane + 64 * e == i) out.v[e] = part;
         }
+        wave64_sum8(part, tot);
+#pragma unroll
+        for (int k = 0; k < kRows; ++k)
+#pragma unroll
+          for (int e = 0; e < E; ++e) if (lane + 64 * e == i0 + k) out.v[e] = tot[k];
       }
     } else {  // forward substitution with unit-lower L, then back substitution with U (no pivoting)
+      // (measured and dropped: per chunk of eight rows one batched reduction over the columns outside the chunk + the 8 x 8
+      //  triangle worked off with v_readlane broadcasts: 3.0 -> 4.4 ms at D = 128 -- the 72 broadcasts per chunk cost more
+      //  than the seven dependent reductions they replace)
       out = v;
       for (int i0 = 0; i0 < d; i0 += kRows) {
         Row<E> mi[kRows];
