@@ -321,9 +321,10 @@ def nsf_k10_h256(device, steps=5, warmup=2, log2n=18, layers=16, hidden=256, bin
            "dtype": "f32 results; conditioner products = 3-term split-f16 MFMA"}
     f_ms, f_n = km["fc_rq_spline_fused_general"]
     if f_ms and hidden == 64:
-        # resident weights: VALU-issue bound like the K = 8 kernel; algorithmic bytes of SURVEY 8d with P = 3K - 1
+        # resident weights: VALU-issue bound like the K = 8 kernel; bytes as in the headline line: what the fused kernel
+        # moves (h + x in, y + logabsdet out = 772 B per sample), not SURVEY 8d's unfused 4 d_t (P + 2) + 8
         out["roofline"] = _hbm_roofline("fc::f4k%d::rq_fused_linear_kernel4 (resident weights, one accumulator set)" % bins,
-                                        "fc_rq_spline_fused_general", f_ms, f_n, (4 * 32 * (p + 2) + 8) * n, bound="valu_issue")
+                                        "fc_rq_spline_fused_general", f_ms, f_n, (4 * 64 + 8 * 64 + 4) * n, bound="valu_issue")
     elif f_ms:
         flops = 2.0 * hidden * 32 * p * n
         tf = flops / (f_ms * 1e-3) / 1e12
