@@ -229,7 +229,7 @@ def test_householder_and_lu_dense_matrix_core_path(d, k, n, device):
         assert maxdiff(lad.cpu().double(), ref_lad) <= 1e-5 * max(1.0, float(ref_lad.abs().max()))
 
 
-@pytest.mark.parametrize("d,m,n", [(12, 5, 300), (128, 32, 512), (70, 3, 65)])
+@pytest.mark.parametrize("d,m,n", [(12, 5, 300), (128, 32, 512), (70, 3, 65), (200, 5, 40), (300, 17, 24)])
 def test_per_sample_sylvester_row_major_upper_triangles(d, m, n, device):
     """The conditional (per-sample) Sylvester form: q [N, M, D], R1 / R2 [N, D, D] row-major as a hyper-network emits
     them, only their upper triangles are read (garbage below the diagonal must not matter); against the formula of
