@@ -59,6 +59,26 @@ __device__ __forceinline__ float rows4_allmax(float v, int lane) {
 // max over all 64 lanes, every lane gets it
 __device__ __forceinline__ float wave64_allmax(float v, int lane) { return rows4_allmax(row16_allmax(v), lane); }
 
+// Merge steps of the batched reductions below.  v_permlane32_swap / v_permlane16_swap with two DIFFERENT registers: after
+// swap(a, b) one register holds a's lower half (even rows) next to b's, the other the upper halves (odd rows), so their sum is
+// a's pair sums in one half of the wave (rows 0, 2) and b's in the other (rows 1, 3).
+// (inline asm: with two different operands hipcc 7.2's __builtin_amdgcn_permlane32_swap hands back its first result twice --
+//  tools/probe/sum8_check.hip; the s_nop 1 is the VALU-write -> cross-lane-read hazard the compiler cannot see inside an asm block)
+__device__ __forceinline__ float lane_merge32(float a, float b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;     // lanes 0-31: a[l] + a[l + 32], lanes 32-63: b[l - 32] + b[l]
+}
+__device__ __forceinline__ float lane_merge16(float a, float b) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;     // rows 0, 2: a's (row r) + (row r + 1), rows 1, 3: b's (row r - 1) + (row r)
+}
+// Four values per lane, each to be summed over the four lanes s, s + 16, s + 32, s + 48: three merge steps instead of four
+// rows4_allsum (eight swaps and as many selects).  Lane (s, row r) gets the sum of value rows4_sum4_index(r).
+__device__ __forceinline__ float rows4_sum4(float v0, float v1, float v2, float v3) {
+  return lane_merge16(lane_merge32(v0, v1), lane_merge32(v2, v3));      // rows: v0, v2, v1, v3
+}
+__device__ __forceinline__ int rows4_sum4_index(int row) { return ((row & 1) << 1) | (row >> 1); }
+
 // Eight wave sums at once.  v_permlane32_swap / v_permlane16_swap with two DIFFERENT registers are a merge step: after
 // swap(a, b) one result holds a's lower half next to b's lower half and the other the two upper halves, so their sum is
 // a's pair sums in one half of the wave and b's in the other -- two vectors become one per swap + add, no selects.  8 -> 4
@@ -70,17 +90,8 @@ __device__ __forceinline__ void wave64_sum8(const float (&s)[8], float (&out)[8]
   for (int k = 0; k < 8; ++k) out[k] = wave64_allsum(s[k], threadIdx.x & 63);
   return;
 #endif
-  // (inline asm: with two different operands that stay live, hipcc 7.2's __builtin_amdgcn_permlane32_swap hands back the
-  //  first result twice -- tools/probe/sum8_check.hip; the s_nop 1 is the VALU-write -> cross-lane-read hazard the compiler
-  //  cannot see inside an asm block)
-  auto merge32 = [](float a, float b) {
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;     // lanes 0-31: a's pair sums, lanes 32-63: b's
-  };
-  auto merge16 = [](float a, float b) {
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return a + b;     // rows 0, 2: a's pair sums, rows 1, 3: b's
-  };
+  auto merge32 = [](float a, float b) { return lane_merge32(a, b); };
+  auto merge16 = [](float a, float b) { return lane_merge16(a, b); };
   const float m01 = merge32(s[0], s[1]), m23 = merge32(s[2], s[3]), m45 = merge32(s[4], s[5]), m67 = merge32(s[6], s[7]);
   // rows of the merged vectors: (s0, s2, s1, s3) and (s4, s6, s5, s7)
   const float lo = row16_allsum(merge16(m01, m23)), hi = row16_allsum(merge16(m45, m67));

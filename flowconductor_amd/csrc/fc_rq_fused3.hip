@@ -301,7 +301,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 
   // One step: evaluate this lane's element of block `cblk` of the tile in buffer `xb` from the accumulators
   // `pa`, and produce into `acc` the accumulators of block `pblk` of the tile in buffer `hb`.
-  auto step = [&](const f32x4 (&pa)[kCt3], int xb, int cblk, f32x4 (&acc)[kCt3], int hb, int pblk) {
+  // (`lad_out`: this lane's logabsdet term; the sums over a sample's four lanes are taken once per tile, after_steps())
+  auto step = [&](const f32x4 (&pa)[kCt3], int xb, int cblk, f32x4 (&acc)[kCt3], int hb, int pblk, float& lad_out) {
     float* xr = xbuf + (xb * R + 16 * cblk + s16) * XS + cs[(4 * wave + g) & (kDt - 1)];
     const float x = *xr;
     const float c_d = hscale[xb * R + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
@@ -359,9 +360,20 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
 #undef FC_WH_SLOT
 #undef FC_HOOK
     if (dim_ok) *xr = y;
-    // logabsdet partial of this wave's 4 dims: lanes s, s+16, s+32, s+48 hold the same sample
-    const float l = rows4_allsum(dim_ok ? lad : 0.f, lane);
-    if (g == 0) lpart[(xb * 8 + wave) * R + 16 * cblk + s16] = l;
+    lad_out = dim_ok ? lad : 0.f;
+  };
+  // logabsdet partials of this wave's 4 dims for the blocks of a tile: lanes s, s+16, s+32, s+48 hold the same sample.  The
+  // four blocks' terms are merged in three swap + add steps (rows4_sum4) and every lane stores one partial, instead of a
+  // two-step all-reduce with selects and a quarter-wave store per block.
+  auto after_steps = [&](int xb, const float (&lb)[NB]) __attribute__((always_inline)) {
+    if constexpr (NB == 4) {
+      const float l = rows4_sum4(lb[0], lb[1], lb[2], lb[3]);
+      lpart[(xb * 8 + wave) * R + 16 * rows4_sum4_index(g) + s16] = l;
+    } else {
+      const float m = lane_merge32(lb[0], lb[1]);       // lanes 0-31: block 0 (rows 0 + 2, 1 + 3), lanes 32-63: block 1
+      const float l = m + lane_xor16(m, lane);
+      if ((g & 1) == 0) lpart[(xb * 8 + wave) * R + 16 * (g >> 1) + s16] = l;
+    }
   };
 
 #if FC_ABL & 16   // ablation: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz, stamped around the loop
@@ -421,11 +433,14 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     if (has_next) fetch(tile + stride);
     // Steps 0 .. NB-2: evaluate block j of `tile`, produce its block j + 1.  (acc0 / acc1 alternate; NB is
     // even, so every tile starts with its block 0 in acc0.)
+    float lb[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) lb[b] = 0.f;
     if (active) {
-      step(acc0, x3, 0, acc1, hb, 1);
+      step(acc0, x3, 0, acc1, hb, 1, lb[0]);
       if constexpr (NB == 4) {
-        step(acc1, x3, 1, acc0, hb, 2);
-        step(acc0, x3, 2, acc1, hb, 3);
+        step(acc1, x3, 1, acc0, hb, 2, lb[1]);
+        step(acc0, x3, 2, acc1, hb, 3, lb[2]);
       }
     }
     FC_PHASE(1);
@@ -437,7 +452,10 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
     FC_PHASE(5);
     // Last step: evaluate block NB-1, produce block 0 of the next tile (unconditional: on the last tile the
     // MFMAs work on stale h rows into accumulators nobody reads -- a branch would split the interleaved block).
-    if (active) step(acc1, x3, NB - 1, acc0, hb ^ 1, 0);
+    if (active) {
+      step(acc1, x3, NB - 1, acc0, hb ^ 1, 0, lb[NB - 1]);
+      after_steps(x3, lb);
+    }
     FC_PHASE(4);
     prev_tile = tile;
     hb ^= 1;

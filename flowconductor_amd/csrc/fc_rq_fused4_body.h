@@ -210,7 +210,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
   // One step: evaluate this lane's element of block `cblk` of the tile in ring slot `xb` from the accumulators, then
   // (from the point where the evaluation has read them all) produce into the SAME accumulators the parameters of block
   // `pblk` of the tile in buffer `hb`.
-  auto step = [&](f32x4 (&acc)[CT], int xb, int cblk, int hb, int pblk) {
+  auto step = [&](f32x4 (&acc)[CT], int xb, int cblk, int hb, int pblk, float& lad_out) {
     float* xr = xbuf + (xb * R + 16 * cblk + s16) * XS + cs[(4 * wave + g) & 31];
     const float x = *xr;
     const float c_d = hscale[xb * R + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
@@ -262,9 +262,14 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
 #undef FC_WH_SLOT
 #undef FC_HOOK
     if (dim_ok) *xr = y;
-    // logabsdet partial of this wave's 4 dims: lanes s, s+16, s+32, s+48 hold the same sample
-    const float l = rows4_allsum(dim_ok ? lad : 0.f, lane);
-    if (g == 0) lpart[(xb * 8 + wave) * R + 16 * cblk + s16] = l;
+    lad_out = dim_ok ? lad : 0.f;
+  };
+  // logabsdet partials of this wave's 4 dims, both blocks of the tile at once: lanes s, s+16, s+32, s+48 hold the same
+  // sample; one merge step puts block 0's pair sums into lanes 0-31 and block 1's into lanes 32-63 (fc_lane.h)
+  auto after_steps = [&](int xb, float l0, float l1) __attribute__((always_inline)) {
+    const float m = lane_merge32(l0, l1);
+    const float l = m + lane_xor16(m, lane);
+    if ((g & 1) == 0) lpart[(xb * 8 + wave) * R + 16 * (g >> 1) + s16] = l;
   };
 
   f32x4 acc[CT];
@@ -311,7 +316,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
     const int x3n = x3 == 2 ? 0 : x3 + 1, x3p = x3 == 0 ? 2 : x3 - 1;
     FC_PHASE(0);
     if (has_next) fetch(tile + stride);
-    if (active) step(acc, x3, 0, hb, 1);
+    float lb0 = 0.f, lb1 = 0.f;
+    if (active) step(acc, x3, 0, hb, 1, lb0);
     FC_PHASE(1);
     if (has_next) park(hb ^ 1, x3n);
     FC_PHASE(2);
@@ -321,7 +327,10 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
     FC_PHASE(4);
     // Last step: evaluate block 1, produce block 0 of the next tile (unconditional: on the last tile the MFMAs work on
     // stale h rows into accumulators nobody reads -- a branch would split the interleaved block).
-    if (active) step(acc, x3, 1, hb ^ 1, 0);
+    if (active) {
+      step(acc, x3, 1, hb ^ 1, 0, lb1);
+      after_steps(x3, lb0, lb1);
+    }
     FC_PHASE(5);
     prev_tile = tile;
     hb ^= 1;
