@@ -210,6 +210,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   dtab[kK * 64] = op.q.tail_const * op.q.beta;
 
   uint32_t err = 0;
+  int mycol = 0;     // this lane's column of x (cs[] is read ONCE, behind the prologue's barrier: per step it was an LDS round trip in front of the x read)
   const int xvec = R * D / 4;     // float4 per x tile: thread tid owns slots tid + 512 k, k < XV
   // (named scalars, not arrays: hipcc keeps register arrays that are written under `if (has_next)` in scratch)
   float4 hv0, hv1, xv0, xv1, xv2, xv3;
@@ -302,8 +303,10 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   // One step: evaluate this lane's element of block `cblk` of the tile in buffer `xb` from the accumulators
   // `pa`, and produce into `acc` the accumulators of block `pblk` of the tile in buffer `hb`.
   // (`lad_out`: this lane's logabsdet term; the sums over a sample's four lanes are taken once per tile, after_steps())
+  // (measured and dropped: the NEXT step's x element and row scale read late in this step's evaluation, so that a step does
+  //  not open with an LDS round trip -- 40 B of spills, 12 400 -> 13 400 cycles per tile)
   auto step = [&](const f32x4 (&pa)[kCt3], int xb, int cblk, f32x4 (&acc)[kCt3], int hb, int pblk, float& lad_out) {
-    float* xr = xbuf + (xb * R + 16 * cblk + s16) * XS + cs[(4 * wave + g) & (kDt - 1)];
+    float* xr = xbuf + (xb * R + 16 * cblk + s16) * XS + mycol;
     const float x = *xr;
     const float c_d = hscale[xb * R + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
     const float c_wh = c_d * wh_mul;        // (c_d is a power of two: the product is exact)
@@ -366,8 +369,8 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   // four blocks' terms are merged in three swap + add steps (rows4_sum4) and every lane stores one partial, instead of a
   // two-step all-reduce with selects and a quarter-wave store per block.
   auto after_steps = [&](int xb, const float (&lb)[NB]) __attribute__((always_inline)) {
-    if constexpr (NB == 4) {
-      const float l = rows4_sum4(lb[0], lb[1], lb[2], lb[3]);
+    if constexpr (NB == 4) {     // lb[0] already holds the merge of blocks 0 and 1
+      const float l = lane_merge16(lb[0], lane_merge32(lb[2], lb[3]));       // rows: blocks 0, 2, 1, 3 (rows4_sum4)
       lpart[(xb * 8 + wave) * R + 16 * rows4_sum4_index(g) + s16] = l;
     } else {
       const float m = lane_merge32(lb[0], lb[1]);       // lanes 0-31: block 0 (rows 0 + 2, 1 + 3), lanes 32-63: block 1
@@ -423,6 +426,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   fetch(tile0);
   park(0, 0);
   __syncthreads();
+  mycol = cs[(4 * wave + g) & (kDt - 1)];
   if (active) produce_only(acc0, 0, 0);   // block 0 of the first tile
   int hb = 0, x3 = 0;          // ring slots of the current tile
   int64_t prev_tile = -1;
@@ -440,6 +444,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
       step(acc0, x3, 0, acc1, hb, 1, lb[0]);
       if constexpr (NB == 4) {
         step(acc1, x3, 1, acc0, hb, 2, lb[1]);
+        lb[0] = lane_merge32(lb[0], lb[1]);      // (merged as soon as both exist: one value less across the next steps)
         step(acc0, x3, 2, acc1, hb, 3, lb[2]);
       }
     }

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
   }
 
   uint32_t err = 0;
+  int mycol = 0;     // this lane's column of x (cs[] is read ONCE, behind the prologue's barrier: per step it was an LDS round trip in front of the x read)
   const int xvec = R * D / 4;     // float4 per x tile: thread tid owns slots tid + 512 k, k < XV
   float4 hv0, xv0, xv1;
   hv0 = xv0 = xv1 = float4{0.f, 0.f, 0.f, 0.f};
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
   // (from the point where the evaluation has read them all) produce into the SAME accumulators the parameters of block
   // `pblk` of the tile in buffer `hb`.
   auto step = [&](f32x4 (&acc)[CT], int xb, int cblk, int hb, int pblk, float& lad_out) {
-    float* xr = xbuf + (xb * R + 16 * cblk + s16) * XS + cs[(4 * wave + g) & 31];
+    float* xr = xbuf + (xb * R + 16 * cblk + s16) * XS + mycol;
     const float x = *xr;
     const float c_d = hscale[xb * R + 16 * cblk + s16] * w_unscale;   // undoes both scalings (a power of two)
     const float c_wh = c_d * wh_mul;        // (c_d is a power of two: the product is exact)
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel4(RQOp<K> op, GenAr
   fetch(tile0);
   park(0, 0);
   __syncthreads();
+  mycol = cs[(4 * wave + g) & 31];
   if (active) produce_only(acc, 0, 0);   // block 0 of the first tile
   int hb = 0, x3 = 0;          // ring slots of the current tile
   int64_t prev_tile = -1;
