@@ -69,7 +69,7 @@ def main():
                                                  wh_divisor=float(hid) ** 0.5, inverse=which.endswith("_inv"),
                                                  streamed_weights=which.endswith("_streamed"))
         name = "fc_rq_spline_fused_general"
-    elif which in ("fused_bwd", "fused_bwd_k10", "fused_bwd_merged"):
+    elif which in ("fused_bwd", "fused_bwd_k10", "fused_bwd_merged", "fused_bwd_wide"):
         kk = 10 if which == "fused_bwd_k10" else 8
         p = 3 * kk - 1
         h = torch.randn(n, 64, device=dev)
@@ -79,7 +79,7 @@ def main():
         packed_t = ops.pack_final_layer_transposed(w, kk, "linear")
         gy, gl = torch.randn(n, d, device=dev), torch.randn(n, device=dev)
         fn = lambda: ops.rq_fused_linear_backward(x, h, gy, gl, packed, packed_t, cols, num_bins=kk, tails="linear",  # noqa: E731
-                                                  tail_bound=3.0, wh_divisor=8.0, merged=which == "fused_bwd_merged")
+                                                  tail_bound=3.0, wh_divisor=8.0, merged="wide" if which == "fused_bwd_wide" else which == "fused_bwd_merged")
         name = "fc_rq_fused_linear_backward"
     elif which == "hidden_bwd":
         from flowconductor_amd.nn import nets
