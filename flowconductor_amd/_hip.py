@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # build of the same ABI call ``use_library(path)`` explicitly before the first kernel call (tools/ only).
 LIB_PATH = os.path.join(_HERE, "csrc", "libflowcon_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ERR_OUTSIDE_DOMAIN = 1
 ERR_DISCRIMINANT = 2

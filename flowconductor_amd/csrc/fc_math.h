@@ -49,6 +49,16 @@ __device__ __forceinline__ float log1p_lean_pos(float t) {
   return d == 0.f ? t : log_lean(u) * div_lean(t, d);
 }
 
+// log1p_lean_pos without control flow: the quotient form is evaluated for every lane (behind an opaque asm, so that the
+// compiler cannot turn the select back into a branch around it) -- for code that must stay one basic block
+__device__ __forceinline__ float log1p_lean_pos_flat(float t) {
+  const float u = 1.f + t;
+  const float d = u - 1.f;
+  float r = log_lean(u) * div_lean(t, d == 0.f ? 1.f : d);
+  asm volatile("" : "+v"(r));
+  return d == 0.f ? t : r;
+}
+
 // sqrt(x) by v_sqrt_f32 plus one Newton correction of the residual; x normal and non-negative.
 __device__ __forceinline__ float sqrt_lean(float x) {
   const float s = __builtin_amdgcn_sqrtf(x);

@@ -138,6 +138,7 @@ __device__ __forceinline__ void householder_rows(Row<E>& x, const float* __restr
         for (int e = 0; e < E; ++e) x.v[e] = x.v[e] - ip * (c * qv[j].v[e]);
       }
   };
+  if (k_count <= 0) return;      // no reflections: the first request below would index row -1 (q may be NULL then)
   Row<E> qa[kB], qb[kB];
   request(0, qa);
   for (int t0 = 0; t0 < k_count; t0 += 2 * kB) {

@@ -1,4 +1,4 @@
-// C entry of the fused final-Linear + RQ-spline backward kernels (fc_rq_fused_backward.h).
+// C entry of the fused final-Linear + RQ-spline backward kernel (fc_rq_fused_backward512.h).
 #include "fc_rq_fused_backward512.h"
 
 extern "C" int fc_rq_fused_linear_backward(int32_t role, const float* x, const float* h, const float* grad_y,
@@ -6,13 +6,12 @@ extern "C" int fc_rq_fused_linear_backward(int32_t role, const float* x, const f
                                            const float* bias_pad, const void* wt_frag, const int32_t* cols,
                                            float* grad_x, float* grad_h, float* grad_bias_pad, float* grad_w_pad,
                                            int64_t n, int32_t d, int32_t d_t, const fc_rq_config* cfg, void* stream) {
-  if (!cfg || n < 0 || d < d_t || d_t < 1 || d_t > 32 || d > 128 || role < 0 || role > 3) return hipErrorInvalidValue;
+  if (!cfg || n < 0 || d < d_t || d_t < 1 || d_t > 32 || d > 128 || role != 3) return hipErrorInvalidValue;
   if (cfg->inverse) return hipErrorInvalidValue;      // gradients of the forward direction
   if (n % fc::kBwdR != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
   if (!x || !h || !grad_y || !w_frag || !w_unscale || !bias_pad || !cols) return hipErrorInvalidValue;
-  if (role != 1 && (!wt_frag || !grad_x || !grad_h || !grad_bias_pad)) return hipErrorInvalidValue;
-  if (role != 0 && !grad_w_pad) return hipErrorInvalidValue;
+  if (!wt_frag || !grad_x || !grad_h || !grad_bias_pad || !grad_w_pad) return hipErrorInvalidValue;
   if ((((uintptr_t)h | (uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)w_frag | (uintptr_t)wt_frag |
         (uintptr_t)grad_x | (uintptr_t)grad_h) & 15u) != 0)
     return hipErrorInvalidValue;
@@ -32,6 +31,5 @@ extern "C" int fc_rq_fused_linear_backward(int32_t role, const float* x, const f
                 static_cast<const fc::f16x8*>(wt_frag), cols, grad_x, grad_h, grad_bias_pad, grad_w_pad,
                 n / fc::kBwdR, d, d_t};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (role == 3) return fc::launch_backward512_any(q.K, q.tails != 0, q, a, s);
-  return q.tails ? fc::launch_backward_tails(q.K, role, q, a, s) : fc::launch_backward_box(q.K, role, q, a, s);
+  return fc::launch_backward512_any(q.K, q.tails != 0, q, a, s);
 }

@@ -34,6 +34,11 @@ namespace fc {
 #ifndef FC_B5_WRES
 #define FC_B5_WRES 1     // 1: the group's forward fragments resident in registers for the whole sweep (8 T registers); 0: streamed per tile
 #endif
+#ifndef FC_B5_PIPE
+#define FC_B5_PIPE 0     // 1: block 1's recompute products inside block 0's (branch-free) spline region with a sched_group_barrier
+                         // pipeline.  Measured SLOWER (1.338 vs 1.296 ms per 2^19 rows): hipcc 7.2 still clumps the 36 products at the
+                         // head of the region, and the branch-free element evaluates both sides of its selects (+600 cycles per block)
+#endif
 #ifndef FC_B5_WPRE
 #define FC_B5_WPRE 0     // streamed forward fragments: the first ring of the NEXT tile is requested at the end of the current one
 #endif
@@ -75,7 +80,8 @@ __global__ __launch_bounds__(kB5Threads) void rq_fused_backward512_kernel(RQPara
   constexpr int PP8 = (PP + 7) / 8 * 8, KK = PP8 / 8;
   constexpr int R = kBwdR, H = kBwdH, KS = 2, SS = kB5SS, HB = kBwdH + 16;
   constexpr int NT = kB5Threads;
-  constexpr bool kWres = FC_B5_WRES != 0 && T <= 6;      // wider parameter rows: the resident fragments no longer fit next to 16 T accumulators
+  constexpr bool kWres = FC_B5_WRES != 0 && T <= 6;
+  constexpr bool kPipe = FC_B5_PIPE != 0 && kWres;      // wider parameter rows: the resident fragments no longer fit next to 16 T accumulators
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   const int D = a.D;
   const bool pad_x = (D & 3) == 0;
@@ -246,13 +252,29 @@ __global__ __launch_bounds__(kB5Threads) void rq_fused_backward512_kernel(RQPara
         ghp1 = reinterpret_cast<const float4*>(a.gh + tile * R * H)[tid + NT];
       }
       if (active) {
-        // ---- recompute the parameters of both blocks against the RESIDENT weight fragments of this wave's group
+        // ---- recompute the parameters of both blocks against the weight fragments of this wave's group
         f32x4 acc[2][T];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
           for (int t = 0; t < T; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
+        // (kPipe) one block against the resident fragments: 6 T products
+        auto recompute_block = [&](int b) __attribute__((always_inline)) {
+          FC_B5_FRESH_LANE();
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const f16x8 bh = hfrag(buf, b, 0, ks, s16, g), bl = hfrag(buf, b, 1, ks, s16, g);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wres[kWres ? ks * T + t : 0][1], bh, acc[b][t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wres[kWres ? ks * T + t : 0][0], bl, acc[b][t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wres[kWres ? ks * T + t : 0][0], bh, acc[b][t], 0, 0, 0);
+          }
+        };
+        if constexpr (kPipe) {
+          recompute_block(0);
+        } else {
           FC_B5_FRESH_LANE();
           const f16x8* wk_ = a.wfrag + (size_t)grp * NF * 2 * 64;
           asm volatile("" : "+s"(wk_));
@@ -314,6 +336,9 @@ __global__ __launch_bounds__(kB5Threads) void rq_fused_backward512_kernel(RQPara
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           __builtin_amdgcn_sched_barrier(0);     // the two blocks' register-hungry spline code must not interleave
+          if constexpr (kPipe) {
+            if (b == 0) recompute_block(1);      // its 6 T products are spread over this block's vector stream below
+          }
           FC_B5_FRESH_LANE();
           const f32x4* bw = reinterpret_cast<const f32x4*>(bias_lds + (grp * 4 + g) * PP);
           const int row = 16 * b + s16;
@@ -336,11 +361,21 @@ __global__ __launch_bounds__(kB5Threads) void rq_fused_backward512_kernel(RQPara
 #pragma unroll
           for (int i = 0; i < 3 * K + 1; ++i) gpe[i] = p[i % PP] * gyv;
 #else
-          rq_backward_element_fast<K, kTails>(q, inv_div, p, xin, gyv, glr, gxv, gpe);
+          if constexpr (kPipe) rq_backward_element_flat<K, kTails>(q, inv_div, p, xin, gyv, glr, gxv, gpe);
+          else rq_backward_element_fast<K, kTails>(q, inv_div, p, xin, gyv, glr, gxv, gpe);
 #endif
 #pragma unroll
           for (int i = 0; i < PP8; ++i) gp[b][i] = i < P ? gpe[i < P ? i : 0] : 0.f;
           if (dim_ok) *gslot = gxv;
+          if constexpr (kPipe) {
+            if (b == 0) {      // one matrix-core instruction per 14 vector instructions of this region
+#pragma unroll
+              for (int i = 0; i < 6 * T; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 14, 0);
+              }
+            }
+          }
           if (b == 0) FC_B5_MARK(3); else FC_B5_MARK(4);      // spline backward, block 0 / 1
         }
         __builtin_amdgcn_sched_barrier(0);

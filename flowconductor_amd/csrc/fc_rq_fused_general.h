@@ -384,7 +384,15 @@ __global__ __launch_bounds__(kGenThreads, gen_waves_per_simd(K, HQ)) void rq_fus
           for (int r = 0; r < 4; ++r) p[4 * t + r] = __builtin_fmaf(acc[b][t][r], c, bt[r]);
         }
         float yv, lad;
-        op.template eval_core<true>(p, xin, yv, lad, err);
+        if constexpr (kPartial) {
+          // rows beyond the batch in the last (partial) tile are phantom copies of the tile's first piece: they must not
+          // raise the domain error (without tails an identity feature among those values may lie outside the box)
+          uint32_t e = 0;
+          op.template eval_core<true>(p, xin, yv, lad, e);
+          err |= row < rows_of(tile) ? e : 0u;
+        } else {
+          op.template eval_core<true>(p, xin, yv, lad, err);
+        }
         if (dim_ok) *xr = yv;
         const float l = rows4_allsum(dim_ok ? lad : 0.f, lane);
         if (g == 0) lpart[(buf * 8 + wave) * R + row] = l;

@@ -231,6 +231,15 @@ def static_memo(module, slot, key, compute):
     return memo[1]
 
 
+def structure_key(net):
+    """The cheap MUTABLE inputs of a conditioner's fast-path predicate, for ``static_memo`` keys: per residual block the
+    identity of its activation, its dropout probability and its own training flag (``block.train()`` / a swapped
+    activation / ``dropout.p = 0.1`` after the first call must re-derive the predicate)."""
+    blocks = getattr(net, "blocks", ())
+    return (net.training, id(getattr(net, "activation", None))) + tuple(
+        (id(getattr(b, "activation", None)), getattr(getattr(b, "dropout", None), "p", 0.0), b.training) for b in blocks)
+
+
 def has_hooks(module):
     """True when ``module`` or a sub-module carries forward (pre-)hooks (old-style weight_norm refreshes ``weight``
     in one): the fast paths read the weights directly and never go through ``__call__``, so they step aside.
@@ -1153,14 +1162,11 @@ def pack_final_layer_transposed(weight, num_bins, tails):
 def rq_fused_linear_backward(inputs, hidden, grad_outputs, grad_logabsdet, packed, packed_t, cols, *, num_bins, tails,
                              tail_bound=1.0, left=0.0, right=1.0, bottom=0.0, top=1.0,
                              min_bin_width=DEFAULT_MIN_BIN_WIDTH, min_bin_height=DEFAULT_MIN_BIN_HEIGHT,
-                             min_derivative=DEFAULT_MIN_DERIVATIVE, wh_divisor=1.0, enable_identity_init=False,
-                             merged=None):
+                             min_derivative=DEFAULT_MIN_DERIVATIVE, wh_divisor=1.0, enable_identity_init=False):
     """Gradients of ``rq_spline_fused_general(inputs, hidden, *packed, cols, ...)`` (forward direction, hidden width
     64, rows a multiple of 32): returns ``(grad_inputs [N, D], grad_hidden [N, 64], grad_weight [d_t * P, 64],
-    grad_bias [d_t * P])`` for the <= 32 dims of ``cols``.  ``merged``: one launch of ``fc_rq_fused_linear_backward``
-    (role 2: both products from one evaluation of the spline backward) instead of two (roles 0 and 1); default: the
-    ``fused_backward_merged`` option ("auto": role 3 -- one launch at one wave per SIMD -- where its shape fits,
-    else roles 0 and 1; "wide": role 3; True: role 2; False: roles 0 and 1)."""
+    grad_bias [d_t * P])`` for the <= 32 dims of ``cols``.  One launch of ``fc_rq_fused_linear_backward`` (one wave per
+    SIMD, ``csrc/fc_rq_fused_backward512.h``): gx / gh deterministic, grad_weight / grad_bias summed with float atomics."""
     lib = _hip.load()
     x = _prep_2d(inputs.detach(), align16=True)
     h = _aligned16(_hip.dev_f32(hidden.detach(), "hidden"))
@@ -1185,27 +1191,10 @@ def rq_fused_linear_backward(inputs, hidden, grad_outputs, grad_logabsdet, packe
     args = (_hip.ptr(x), _hip.ptr(h), _hip.ptr(gy), _hip.ptr(gl), _hip.ptr(w_frag), _hip.ptr(w_un),
             _hip.ptr(bias_pad), _hip.ptr(packed_t), _hip.ptr(cols), _hip.ptr(gx), _hip.ptr(gh), _hip.ptr(gb),
             _hip.ptr(gw), n, d, d_t, cfg, _hip.stream_ptr(x.device))
-    mode = options.get("fused_backward_merged") if merged is None else merged
-    if mode == "auto":
-        mode = "wide" if fused_backward_wide_supported(d, num_bins, tails) else False
-    if mode == "wide":       # role 3: one launch, one wave per SIMD (fc_rq_fused_backward512.h)
-        _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 3, *args)
-    elif mode:
-        _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 2, *args)
-    else:
-        _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 0, *args)
-        _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 1, *args)
+    _call("fc_rq_fused_linear_backward", lib.fc_rq_fused_linear_backward, x.device, 3, *args)      # FC_RQ_BACKWARD_ONE_LAUNCH
     grad_w = gw.reshape(groups * 4, pp, 64)[:d_t, :p].reshape(d_t * p, 64)
     grad_b = gb.reshape(groups * 4, pp)[:d_t, :p].reshape(d_t * p)
     return gx, gh, grad_w, grad_b
-
-
-def fused_backward_wide_supported(d, num_bins, tails):
-    """Shapes of the one-launch backward (role 3 of ``fc_rq_fused_linear_backward``): parameter rows of at most six
-    16-row tiles per dim group (K <= 8 with linear tails, K <= 7 without) and an LDS image that fits 160 KiB."""
-    p = 3 * num_bins - 1 if tails == "linear" else 3 * num_bins + 1
-    lds = 2 * 2 * 32 * 80 * 2 + 2 * 2 * 32 * (d + 4) * 4 + 512 + 128 + 4096 + 4 * 32 * 68 * 4 + 4 * (16 * 40 + 16) * 4
-    return -(-p // 4) <= 8 and lds <= 160 * 1024
 
 
 def fused_backward_supported(n, d, d_t, hidden, num_bins, tails):

@@ -27,10 +27,6 @@ _DEFAULTS = {
     # training: conditioner forward / backward in the HIP kernels (fc_resnet_hidden_backward, fused final-layer
     # backward) instead of PyTorch autograd through library GEMMs
     "fused_training": True,
-    # fc_rq_fused_linear_backward: one launch computing gx, gh, gb and gW from one evaluation of the spline backward
-    # (role 2) instead of two launches (roles 0 and 1) that each recompute it; "wide": role 3 (one launch at one wave per
-    # SIMD, fc_rq_fused_backward512.h); "auto": role 3 where its shape fits, else roles 0 and 1
-    "fused_backward_merged": "auto",
     # Packed-weight caches (kernel-layout copies of parameters) are keyed on the parameters' version counters and storage
     # pointers; a write THROUGH ``.data`` (``p.data.copy_(ema)``) moves neither.  True: every call re-packs (one
     # fc_pack_fragments launch per layer, ~1 % of a cfg-3 log_prob) -- for code that edits ``.data`` of an eval-mode model

@@ -110,21 +110,33 @@ class LoglikAllReduce:
         box = {}
         lib, world, rank, index = self._lib, self.world, self.rank, self.device.index
 
+        lock = threading.Lock()
+
         def bootstrap():
             comm = ctypes.c_void_p()
             try:
                 _hip.check(lib.fc_comm_init_rank_on_device(ctypes.byref(comm), world, ident, rank, index),
                            "fc_comm_init_rank_on_device")
-                box["comm"] = comm
             except Exception as e:  # noqa: BLE001
-                box["error"] = e
+                with lock:
+                    box.setdefault("error", e)
+                return
+            with lock:
+                if box.get("cancelled"):
+                    # the caller gave up on this bootstrap (deadline): nobody will ever use or destroy the communicator, and
+                    # its peers must not take it for live
+                    lib.fc_comm_abort(comm)
+                else:
+                    box["comm"] = comm
 
         helper = threading.Thread(target=bootstrap, daemon=True, name="fc_comm_init_rank")
         helper.start()
         helper.join(timeout=init_timeout_s)
-        stuck = helper.is_alive()
-        if stuck:
-            box["error"] = TimeoutError("fc_comm_init_rank_on_device did not return within %g s" % init_timeout_s)
+        with lock:
+            stuck = "comm" not in box and "error" not in box
+            if stuck:
+                box["cancelled"] = True
+                box["error"] = TimeoutError("fc_comm_init_rank_on_device did not return within %g s" % init_timeout_s)
         # 4. agree on the outcome
         if not agree("comm" in box and "error" not in box):
             if "comm" in box and not stuck:

@@ -178,7 +178,7 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
                     and ops.activation_code(net.activation)[0] == ops.ACT_RELU
                     and ops.affine_tail_fits(inputs.shape[1], len(net.blocks), inputs.shape[1]))
 
-        return (ops.static_memo(self, "_fc_static_ok", (inputs.shape[1], net.training), structure_ok)
+        return (ops.static_memo(self, "_fc_static_ok", (inputs.shape[1],) + ops.structure_key(net), structure_ok)
                 and not ops.has_hooks(net) and not self._needs_grad(inputs))
 
     def _one_kernel(self, inputs, total=None):

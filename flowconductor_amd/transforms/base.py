@@ -67,6 +67,12 @@ class Transform(ops.RuntimeCaches, nn.Module):
         ops.invalidate_hip_caches()
         return super().train(mode)
 
+    def _apply(self, fn, *args, **kwargs):
+        """``.to()`` / ``.float()`` / ``.cuda()`` replace parameter storage: the memoised fast-path predicates and packed
+        images of every module go with them."""
+        ops.invalidate_hip_caches()
+        return super()._apply(fn, *args, **kwargs)
+
 
 class CompositeTransform(Transform):
     """Composes several transforms into one, in the order they are given."""

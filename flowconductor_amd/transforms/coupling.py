@@ -220,7 +220,8 @@ class AffineCouplingTransform(CouplingTransform):
                     and net.hip_hidden_supported(inputs.shape[1], None)
                     and all(ops.activation_code(b.activation)[0] == ops.ACT_RELU for b in net.blocks))
 
-        return (ops.static_memo(self, "_fc_static_ok", (inputs.shape[1], net.training), structure_ok)
+        return (ops.static_memo(self, "_fc_static_ok", (inputs.shape[1], id(self.unconditional_transform)) + ops.structure_key(net),
+                                structure_ok)
                 and not ops.has_hooks(net)
                 and not (torch.is_grad_enabled()
                          and (inputs.requires_grad or any(p.requires_grad for p in net.parameters()))))

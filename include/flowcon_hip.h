@@ -33,8 +33,10 @@ extern "C" {
 #define FC_ERR_DISCRIMINANT 2u   /* assert (discriminant >= 0).all(), rational_quadratic.py:142 */
 #define FC_ERR_NONFINITE 4u
 
-/* ABI version of this header; fc_abi_version() must return it. */
-#define FC_ABI_VERSION 1
+/* ABI version of this header; fc_abi_version() must return it.  Bumped whenever an exported entry, an accepted enum value
+ * or a documented behaviour changes (2: round 4 -- fc_rq_fused_linear_backward is one launch, fc_comm_* entries of round 3,
+ * FC_AFFINE_MAF_SOFTPLUS / FC_RQ_STREAMED_WEIGHTS). */
+#define FC_ABI_VERSION 2
 
 int fc_abi_version(void);
 
@@ -110,11 +112,15 @@ int fc_rq_spline_fused_general(const float* x, float* y, const float* h, const v
  * final Linear + spline (nn/nets/resnet.py:99 + rational_quadratic.py:13-181; the reference trains through them,
  * examples/toy_2d.py:57-68) WITHOUT the [n, d_t P] parameter / parameter-gradient tensors: the parameters are recomputed
  * on the matrix cores from the saved h, the closed-form spline backward runs on them in registers.
- *   role 0: grad_x [n, d] (= grad_y on the other columns), grad_h [n, 64] = W^T G, grad_bias_pad [groups][4][4T] += sum_n G
- *   role 1: grad_w_pad [groups][4][4T][64] += sum_n G (x) h          (both accumulate with atomics: zero them first)
+ * One launch (role must be FC_RQ_BACKWARD_ONE_LAUNCH; ABI 1 ran two launches, roles 0 "dx" and 1 "dw", each recomputing G):
+ *   grad_x [n, d] (= grad_y on the other columns), grad_h [n, 64] = W^T G              (deterministic)
+ *   grad_bias_pad [groups][4][4T] += sum_n G,  grad_w_pad [groups][4][4T][64] += sum_n G (x) h
+ *                                              (both accumulate with float atomics: zero them first)
+ * grad_x / grad_h must not alias grad_y (they serve as scratch between the kernel's sweeps over groups of 16 dims).
  * w_frag / w_unscale / bias_pad as for fc_rq_spline_fused_general with hidden == 64; wt_frag f16
  * [groups][4 hidden tiles][KK][2][64][8], KK = ceil(4T / 8): fragment (hidden tile ht, k-step kk, piece): lane l holds
  * 2^S W[dim 4 group + (l>>4)][param 8 kk + j][hidden 16 ht + (l&15)].  n % 32 == 0; cfg->inverse must be 0; 4T <= 32. */
+#define FC_RQ_BACKWARD_ONE_LAUNCH 3
 int fc_rq_fused_linear_backward(int32_t role, const float* x, const float* h, const float* grad_y,
                                 const float* grad_logabsdet, const void* w_frag, const float* w_unscale,
                                 const float* bias_pad, const void* wt_frag, const int32_t* cols, float* grad_x,

@@ -19,14 +19,11 @@ def _relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("merged", [False, True, "wide"])
 @pytest.mark.parametrize("k,tails,d,d_t,n", [(8, "linear", 64, 32, 256), (10, "linear", 64, 32, 160), (10, None, 16, 8, 96),
                                             (4, "linear", 12, 6, 64), (8, "linear", 63, 31, 96), (5, None, 10, 3, 32)])
-def test_fused_linear_backward_operator_vs_float64_autograd(k, tails, d, d_t, n, merged, device):
+def test_fused_linear_backward_operator_vs_float64_autograd(k, tails, d, d_t, n, device):
     torch.manual_seed(7 * k + d)
     hidden = 64
-    if merged == "wide" and not ops.fused_backward_wide_supported(d, k, tails):
-        pytest.skip("role 3 covers parameter rows of <= 6 tiles per dim group")
     p = 3 * k - 1 if tails == "linear" else 3 * k + 1
     x = torch.rand(n, d) if tails is None else torch.randn(n, d) * 1.5
     if tails == "linear" and n >= 8:
@@ -51,7 +48,7 @@ def test_fused_linear_backward_operator_vs_float64_autograd(k, tails, d, d_t, n,
     packed_t = ops.pack_final_layer_transposed(w.to(device), k, tails)
     gx, gh, gw, gb = ops.rq_fused_linear_backward(x.to(device), h.to(device), gy.to(device), gl.to(device), packed,
                                                   packed_t, cols.to(device), num_bins=k, tails=tails, tail_bound=3.0,
-                                                  merged=merged, **kw)
+                                                  **kw)
     # f32 arithmetic against a float64 reference: relative to the largest entry of each gradient
     assert _relerr(gx, gx_ref) <= 2e-4
     assert _relerr(gh, gh_ref) <= 2e-4
@@ -83,7 +80,7 @@ def _layer(d, hidden, k, tails, seed, blocks=2, mask="alternating"):
                                                      (54, 32, 8, "linear", 512, "alternating")])   # K = 8 with a narrow net
 def test_coupling_layer_trains_through_fused_kernels(d, hidden, k, tails, n, mask, device):
     """Parameter and input gradients of one RQ coupling layer on the fused training path (forward: fc_resnet_hidden +
-    fc_rq_spline_fused_general; backward: fc_rq_fused_linear_backward twice per 32 transformed dims) against float64
+    fc_rq_spline_fused_general; backward: fc_rq_fused_linear_backward once per 32 transformed dims) against float64
     autograd on the oracle.  Batches that are not whole 32-row tiles, D = 128 (two groups of 32 dims), narrow nets; a
     contiguous-half mask (the hidden stack's input gradient then takes the scalar path of fc_resnet_hidden_backward_accum,
     the alternating masks the 16-byte one)."""
@@ -106,9 +103,8 @@ def test_coupling_layer_trains_through_fused_kernels(d, hidden, k, tails, n, mas
         ((y * gy.to(device)).sum() + (lad * gl.to(device)).sum()).backward()
     # forward: the hand-scheduled K = 8 kernel for the north-star shape (it takes the 64-wide nn.Linear weights as they
     # are), the general one otherwise
-    # backward: one launch per 32 dims where role 3 fits (fc_rq_fused_backward512.h), else roles 0 and 1
-    launches = 1 if ops.fused_backward_wide_supported(d, k, tails) else 2
-    assert len(tb.pairs) == launches * groups and len(tf.pairs) + len(tf8.pairs) == groups and not told.pairs
+    # backward: one launch per 32 dims (fc_rq_fused_backward512.h)
+    assert len(tb.pairs) == groups and len(tf.pairs) + len(tf8.pairs) == groups and not told.pairs
     assert bool(tf8.pairs) == (k == 8 and tails == "linear" and hidden == 64)
     assert maxdiff(y.detach(), y_ref.detach()) <= 2e-5 * max(1.0, float(y_ref.detach().abs().max()))
     assert maxdiff(lad.detach(), lad_ref.detach()) <= 3e-4

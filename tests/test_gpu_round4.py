@@ -1,0 +1,102 @@
+"""Round-4 regressions: advisor findings of round 3 (phantom rows of a partial 48-row tile, zero per-sample reflections,
+fast-path predicates that outlive a change of the conditioner) and the one-launch fused backward's extra shapes."""
+import pytest
+import torch
+
+from _util import Lib, maxdiff
+from flowconductor_amd import ops
+from oracle import torch_oracle as O
+
+pytestmark = pytest.mark.gpu
+T, nets, utils = Lib.transforms, Lib.nets, Lib.utils
+
+
+@pytest.mark.parametrize("hidden", [128, 256])
+def test_partial_tile_phantom_rows_do_not_raise_outside_domain(hidden, device):
+    """tails=None, hidden 128 / 256 (48-row tiles), a batch that is not a whole number of 48-row tiles: the rows beyond the
+    batch in the last tile are phantom copies of that tile's first 16-byte piece.  An IDENTITY feature outside the box in it
+    (the reference never range-checks identity features, coupling.py:73-100) must not raise; a transformed one must."""
+    from flowconductor_amd.transforms import InputOutsideDomain
+
+    torch.manual_seed(hidden)
+    k, n, d, d_t = 10, 160, 12, 4          # 160 = 3 x 48 + 16: the last tile holds 16 real rows
+    p = 3 * k + 1
+    x = torch.rand(n, d)
+    h = torch.randn(n, hidden)
+    w = torch.randn(d_t * p, hidden) * (1.0 / hidden ** 0.5)
+    b = torch.randn(d_t * p) * 0.3
+    cols = torch.tensor([4, 6, 9, 11], dtype=torch.int32)          # columns 0..3 (the tile's first piece) are identity features
+    packed = ops.pack_final_layer_general(w.to(device), b.to(device), k, None, hidden)
+    kw = dict(num_bins=k, tails=None, wh_divisor=float(hidden) ** 0.5)
+    x[144, 0:4] = torch.tensor([7.5, -3.0, 1.5, 2.0])              # first row of the last tile, identity columns
+    with torch.no_grad():
+        y, _ = ops.rq_spline_fused_general(x.to(device), h.to(device), *packed, cols.to(device), **kw)
+    assert torch.equal(y[:, :4].cpu(), x[:, :4])
+    bad = x.clone()
+    bad[150, 6] = 1.25
+    with pytest.raises(InputOutsideDomain):
+        with torch.no_grad():
+            ops.rq_spline_fused_general(bad.to(device), h.to(device), *packed, cols.to(device), **kw)
+
+
+def test_per_sample_householder_with_zero_reflections_is_the_identity(device):
+    x = torch.randn(70, 24)
+    q = torch.zeros(70, 0, 24)
+    with torch.no_grad():
+        y = ops.householder(x.to(device), q.to(device))
+        y_rev = ops.householder(x.to(device), q.to(device), reverse=True)
+    assert torch.equal(y.cpu(), x) and torch.equal(y_rev.cpu(), x)
+
+
+def test_one_kernel_predicate_follows_the_conditioner(device):
+    """The memoised structure predicate of the one-kernel affine coupling layer re-derives itself when the conditioner
+    changes under it: dropout switched on in training mode must leave the fused path (the kernel has no dropout)."""
+    torch.manual_seed(3)
+    mask = utils.create_alternating_binary_mask(16, even=True)
+    t = T.AffineCouplingTransform(mask, lambda i, o: nets.ResidualNet(i, o, hidden_features=32, num_blocks=2)).to(device).eval()
+    x = torch.randn(256, 16, device=device)
+    with torch.no_grad():
+        assert t._one_kernel_ok(x, None)
+        y0, _ = t(x)
+        for blk in t.transform_net.blocks:
+            blk.dropout.p = 0.5
+        t.transform_net.train()
+        assert not t._one_kernel_ok(x, None)
+        t.transform_net.eval()
+        for blk in t.transform_net.blocks:
+            blk.dropout.p = 0.0
+        y1, _ = t(x)
+    assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("k,tails,d,d_t,n", [(8, "linear", 64, 20, 96), (9, "linear", 40, 17, 64), (11, "linear", 128, 32, 64),
+                                            (8, None, 24, 9, 128), (6, "linear", 8, 2, 32)])
+def test_one_launch_backward_odd_group_counts(k, tails, d, d_t, n, device):
+    """fc_rq_fused_linear_backward (one launch, sweeps of four dim groups): dim counts that leave waves without a group in
+    the second sweep, a last group of fewer than four dims, D = 128, the widest parameter rows (K = 11: 32 per dim)."""
+    torch.manual_seed(11 * k + d_t)
+    hidden = 64
+    p = 3 * k - 1 if tails == "linear" else 3 * k + 1
+    x = torch.rand(n, d) if tails is None else torch.randn(n, d) * 1.5
+    h = torch.relu(torch.randn(n, hidden)) + torch.randn(n, hidden) * 0.2
+    w = torch.randn(d_t * p, hidden) * (1.0 / hidden ** 0.5)
+    b = torch.randn(d_t * p) * 0.3
+    cols = torch.randperm(d)[:d_t].sort().values.to(torch.int32)
+    gy, gl = torch.randn(n, d), torch.randn(n)
+    kw = dict(wh_divisor=float(hidden) ** 0.5)
+    x64, h64, w64, b64 = (v.double().requires_grad_(True) for v in (x, h, w, b))
+    rows = (h64 @ w64.T + b64).view(n, d_t, p)
+    out, lad_e = O.rq_from_rows(x64[:, cols.long()], rows.clone(), k, tails, 3.0, False, **kw)
+    y64 = x64.clone().index_copy(1, cols.long(), out)
+    loss = (y64 * gy.double()).sum() + (lad_e.sum(dim=1) * gl.double()).sum()
+    refs = torch.autograd.grad(loss, (x64, h64, w64, b64))
+    packed = ops.pack_final_layer_general(w.to(device), b.to(device), k, tails, 64)
+    packed_t = ops.pack_final_layer_transposed(w.to(device), k, tails)
+    got = ops.rq_fused_linear_backward(x.to(device), h.to(device), gy.to(device), gl.to(device), packed, packed_t,
+                                       cols.to(device), num_bins=k, tails=tails, tail_bound=3.0, **kw)
+    for g, r in zip(got, refs):
+        assert float((g.double().cpu() - r).abs().max() / r.abs().max().clamp_min(1e-30)) <= 2e-4
+    # deterministic parts: bit-identical between two launches
+    again = ops.rq_fused_linear_backward(x.to(device), h.to(device), gy.to(device), gl.to(device), packed, packed_t,
+                                         cols.to(device), num_bins=k, tails=tails, tail_bound=3.0, **kw)
+    assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])

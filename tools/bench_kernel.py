@@ -69,8 +69,8 @@ def main():
                                                  wh_divisor=float(hid) ** 0.5, inverse=which.endswith("_inv"),
                                                  streamed_weights=which.endswith("_streamed"))
         name = "fc_rq_spline_fused_general"
-    elif which in ("fused_bwd", "fused_bwd_k10", "fused_bwd_merged", "fused_bwd_wide"):
-        kk = 10 if which == "fused_bwd_k10" else 8
+    elif which in ("fused_bwd", "fused_bwd_k10", "fused_bwd_wide", "fused_bwd_wide_k10"):      # (the _wide names: round-4 probe logs)
+        kk = 10 if which.endswith("_k10") else 8
         p = 3 * kk - 1
         h = torch.randn(n, 64, device=dev)
         w = torch.randn(d_t * p, 64, device=dev) * 0.125
@@ -79,7 +79,7 @@ def main():
         packed_t = ops.pack_final_layer_transposed(w, kk, "linear")
         gy, gl = torch.randn(n, d, device=dev), torch.randn(n, device=dev)
         fn = lambda: ops.rq_fused_linear_backward(x, h, gy, gl, packed, packed_t, cols, num_bins=kk, tails="linear",  # noqa: E731
-                                                  tail_bound=3.0, wh_divisor=8.0, merged="wide" if which == "fused_bwd_wide" else which == "fused_bwd_merged")
+                                                  tail_bound=3.0, wh_divisor=8.0)
         name = "fc_rq_fused_linear_backward"
     elif which == "hidden_bwd":
         from flowconductor_amd.nn import nets
@@ -130,11 +130,6 @@ def main():
         torch.cuda.synchronize()
     ms = sorted(timer.durations_ms())
     med = ms[len(ms) // 2]
-    if which in ("fused_bwd", "fused_bwd_k10"):      # two launches per call: role 0 (dx), role 1 (dw), in that order
-        d_ms = timer.durations_ms()
-        r0, r1 = sorted(d_ms[0::2]), sorted(d_ms[1::2])
-        print("%s N=2^%d: role 0 (gx, gh, gb) median %.4f ms, role 1 (gW) median %.4f ms"
-              % (which, n.bit_length() - 1, r0[len(r0) // 2], r1[len(r1) // 2]))
     print("%s N=2^%d: median %.4f ms  min %.4f  max %.4f  -> %.0f GB/s algorithmic (%.1f%% of 8 TB/s), "
           "actual bytes/alg = %.3f" % (which, n.bit_length() - 1, med, ms[0], ms[-1], alg / med / 1e6,
                                        alg / med / 1e6 / 80.0, (4 * (d_t * p + 2 * d + 1)) / (4 * d_t * (p + 2) + 8)))

@@ -26,7 +26,7 @@ packed_t = ops.pack_final_layer_transposed(w, k, "linear")
 gy, gl = torch.randn(n, d, device=dev), torch.randn(n, device=dev)
 for _ in range(5):
     gx, gh, gw, gb = ops.rq_fused_linear_backward(x, h, gy, gl, packed, packed_t, cols, num_bins=k, tails="linear",
-                                                  tail_bound=3.0, wh_divisor=8.0, merged="wide")
+                                                  tail_bound=3.0, wh_divisor=8.0)
 torch.cuda.synchronize()
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 st = gh[:cus].view(cus, 4, 16).double().cpu()

@@ -12,6 +12,11 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 rm -rf "$W" && mkdir -p "$W/flowconductor_amd" "$R/tools/probe/build"
 cp -r "$R/flowconductor_amd/csrc" "$W/flowconductor_amd/" && cp -r "$R/include" "$W/"
 cd "$W/flowconductor_amd/csrc" && rm -f *.o *.so
+# (round 4: the product library no longer carries the two-launch roles; their instantiation files and C entry come from history)
+git -C "$R" show 6d125f7:flowconductor_amd/csrc/fc_rq_fused_backward_tails.hip > fc_rq_fused_backward_tails.hip
+git -C "$R" show 6d125f7:flowconductor_amd/csrc/fc_rq_fused_backward_box.hip > fc_rq_fused_backward_box.hip
+git -C "$R" show 6d125f7:flowconductor_amd/csrc/fc_rq_fused_backward.hip > fc_rq_fused_backward.hip
+rm -f fc_rq_fused_backward512.hip fc_rq_fused_backward512.h
 git -C "$R" show 44d992e^:flowconductor_amd/csrc/fc_rq_fused_backward.h > fc_rq_fused_backward.h
 python3 "$R/tools/probe/patch_old_bwd.py" fc_rq_fused_backward.h
 build() { name=$1; shift; rm -f fc_rq_fused_backward_tails.o fc_rq_fused_backward_box.o fc_rq_fused_backward.o libflowcon_hip.so
