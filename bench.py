@@ -271,8 +271,12 @@ def main():
     chunk = (1 << args.chunk_log2) if args.chunk_log2 else None
 
     # the path's one collective: {sum log_prob, count}, 16 bytes, through the C ABI (RCCL) when the job runs on RCCL
-    reducer, reducer_note, stuck_helper = None, "none (1 rank)", False
+    # `reducer_kind` / `degraded` are the machine-readable form of the note: "abi" = fc_allreduce_loglik (RCCL through the C ABI),
+    # "torch" = torch.distributed.all_reduce, "none" = one rank without the N > 1 code path; degraded = the ABI reducer was
+    # asked for (the default on RCCL) and the job fell back to torch.distributed
+    reducer, reducer_note, stuck_helper, reducer_kind, degraded = None, "none (1 rank)", False, "none", False
     if collective:
+        reducer_kind = "torch"
         reducer_note = "torch.distributed.all_reduce (%s)" % args.dist_backend
         if args.loglik_allreduce == "abi" and (args.dist_backend == "nccl" or args.share_device0):
             # Collective set-up on THIS thread (it owns the device); only the blocking RCCL bootstrap inside runs under a
@@ -280,9 +284,11 @@ def main():
             try:
                 reducer = parallel.LoglikAllReduce(device, dist.group.WORLD, init_timeout_s=args.comm_timeout)
                 reducer_note = "fc_allreduce_loglik (RCCL ncclAllReduce through the C ABI, %d ranks)" % world
+                reducer_kind = "abi"
             except parallel.CollectiveSetupFailed as e:
                 log("rank %d: fc_allreduce_loglik unavailable (%s)" % (rank, e))
                 stuck_helper = stuck_helper or e.stuck_helper
+                degraded = True
                 reducer_note += " [fc_allreduce_loglik failed to initialise on some rank: %s]" % e
 
     def step():
@@ -378,6 +384,8 @@ def main():
                        "mean_log_prob": mean_lp},
             "rccl_ranks": world if (collective and args.dist_backend == "nccl") else 0,
             "loglik_allreduce": reducer_note,
+            "reducer": reducer_kind,
+            "degraded": degraded,
             "per_rank": per_rank,
             "rank_skew": {"max_ms_per_step": max(r["ms_per_step"] for r in per_rank),
                           "min_ms_per_step": min(r["ms_per_step"] for r in per_rank),
@@ -484,10 +492,11 @@ def main():
     if dist is not None:
         if stuck_helper:
             # a thread of this process is still parked inside ncclCommInitRank: do not run RCCL / interpreter tear-down
-            # around it; the line above is out, leave at once
+            # around it; the line above is out (with "degraded": true), leave at once -- with a NON-ZERO status, so that a
+            # driver that only looks at return codes does not book a fallen-back run as a clean RCCL run
             sys.stdout.flush()
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(3)
         dist.destroy_process_group()
 
 
