@@ -832,6 +832,78 @@ def device_pack_made_affine(made, features):
     return pack, (w_frag, w_un, bias_acc)
 
 
+MADE_AFFINE, MADE_RQ = 0, 1
+
+
+def pack_made_inverse(made, features, per_dim):
+    """Everything ``fc_made_inverse`` needs of a residual-block MADE (hidden <= 64, <= 3 blocks, <= 64 inputs): the hidden
+    stack's image on MASKED weights (rows in the accumulator order of the hidden-layer kernels, one power-of-two scale per
+    layer) and the final layer as per-dim row tiles (``per_dim`` parameter rows of every dim padded to whole 16-row tiles,
+    one scale per dim).  Returns ``(hidden_frag, hidden_unscale [L], hidden_bias [L, 64], final_frag, final_unscale [D],
+    final_bias [D, 16 PT])``."""
+    hw = 64
+    dev = made.initial_layer.weight.device
+    perm = _hb_perm().to(dev)
+    k0s = 1 if features <= 32 else 2
+    layers = [made.initial_layer] + [lin for block in made.blocks for lin in block.linear_layers]
+    wf, uns, biases = [], [], []
+    with torch.no_grad():
+        for i, lin in enumerate(layers):
+            w = _pad_to((lin.weight * lin.mask).detach().float(), (hw, 32 * k0s if i == 0 else hw))
+            sc, un = _pow2_scale(w.abs().amax().reshape(1))
+            uns.append(un)
+            wf.append(_a_fragments((w * sc)[perm]).permute(1, 0, 2, 3, 4).reshape(-1))            # [ks][t][piece][lane][8]
+            biases.append(_pad_to(lin.bias.detach().float(), (hw,))[perm].reshape(4, 4, 4).permute(1, 0, 2).reshape(-1))
+        final = made.final_layer
+        pt = -(-per_dim // 16)
+        w = _pad_to((final.weight * final.mask).detach().float().reshape(features, per_dim, -1), (features, 16 * pt, hw))
+        sc, un = _pow2_scale(w.abs().amax(dim=(1, 2)))
+        frag = _a_fragments((w * sc.reshape(-1, 1, 1)).reshape(features * 16 * pt, hw))           # [D PT, ks, piece, lane, 8]
+        final_frag = frag.reshape(features, pt, 2, 2, 64, 8).permute(0, 2, 1, 3, 4, 5).contiguous()   # [D][ks][t][piece][lane][8]
+        final_bias = _pad_to(final.bias.detach().float().reshape(features, per_dim), (features, 16 * pt)).contiguous()
+    return (torch.cat(wf).contiguous(), torch.cat(uns).float().contiguous(), torch.stack(biases).contiguous(),
+            final_frag, un.float().contiguous(), final_bias)
+
+
+def made_inverse(inputs, packed, num_blocks, per_dim, kind, rq=None, logabsdet_accum=None):
+    """The D passes of an autoregressive inverse in ONE kernel (``fc_made_inverse``): ``inputs`` [N, D <= 64] (rows a
+    multiple of 16), ``packed`` from ``pack_made_inverse``; ``kind`` ``MADE_AFFINE`` or ``MADE_RQ`` (``rq``: keyword
+    arguments of the spline as for ``rq_spline``).  Returns ``(outputs, logabsdet)``."""
+    lib = _hip.load()
+    z = _prep_2d(inputs)
+    _hip.require_no_grad(inputs)
+    n, d = z.shape
+    if n % HIDDEN_ROWS != 0 or d > 64:
+        raise ValueError("fc_made_inverse: rows must be a multiple of %d, D <= 64" % HIDDEN_ROWS)
+    cfg = None
+    if kind == MADE_RQ:
+        rq = dict(rq)
+        cfg = _rq_config(rq.pop("num_bins"), rq.pop("tails"), rq.pop("tail_bound", 1.0),
+                         (rq.pop("left", 0.0), rq.pop("right", 1.0), rq.pop("bottom", 0.0), rq.pop("top", 1.0)),
+                         rq.pop("min_bin_width", DEFAULT_MIN_BIN_WIDTH), rq.pop("min_bin_height", DEFAULT_MIN_BIN_HEIGHT),
+                         rq.pop("min_derivative", DEFAULT_MIN_DERIVATIVE), rq.pop("enable_identity_init", False),
+                         rq.pop("wh_divisor", 1.0), True)
+        if rq:
+            raise TypeError("made_inverse: unknown spline arguments %s" % sorted(rq))
+    y = torch.empty_like(z)
+    if logabsdet_accum is not None:
+        lad = logabsdet_accum
+        if lad.dtype != torch.float32 or lad.shape != (n,) or not lad.is_contiguous() or lad.device != z.device:
+            raise ValueError("logabsdet_accum must be a contiguous float32 [N] tensor on the inputs' device")
+        if cfg is None:
+            cfg = _hip.RQConfig()          # affine form: only the flags are read
+        cfg.flags = 1  # FC_RQ_ACCUMULATE_LOGABSDET
+    else:
+        lad = torch.empty(n, dtype=torch.float32, device=z.device)
+    err = _err_word(z.device, True)
+    hf, hu, hb, ff, fu, fb = packed
+    _call("fc_made_inverse", lib.fc_made_inverse, z.device, _hip.ptr(z), _hip.ptr(y), _hip.ptr(lad), _hip.ptr(hf),
+          _hip.ptr(hu), _hip.ptr(hb), _hip.ptr(ff), _hip.ptr(fu), _hip.ptr(fb), _hip.ptr(err), n, d, num_blocks, per_dim,
+          kind, cfg, _hip.stream_ptr(z.device))
+    _finish(True)
+    return y, lad
+
+
 def affine_tail_fits(in_features, num_blocks, d):
     """LDS budget of ``fc_affine_coupling_resnet``: the weight image (initial layer, 2 per block, the final Linear) + one
     [16, D | 1] float tile per wave next to it, 160 KB per CU; D <= 128, <= 3 blocks."""

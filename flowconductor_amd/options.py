@@ -22,6 +22,8 @@ _DEFAULTS = {
     "sylvester_mm": True,
     # autoregressive inverse: "auto" (column-d-only passes where they pay), "force", "off"
     "ar_incremental": "auto",
+    # autoregressive inverse: all D passes inside one kernel (fc_made_inverse) where the MADE fits it
+    "ar_device_loop": True,
     # fc_rq_spline: pin the LDS-tile kernel instead of the register / wave kernel (FC_RQ_FORCE_TILE)
     "rq_force_tile": False,
     # training: conditioner forward / backward in the HIP kernels (fc_resnet_hidden_backward, fused final-layer

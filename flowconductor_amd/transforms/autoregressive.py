@@ -78,6 +78,8 @@ class AutoregressiveTransform(Transform):
         return self._elementwise_forward(inputs, autoregressive_params)
 
     def inverse(self, inputs, context=None):
+        if self._device_loop_ok(inputs, context):
+            return self._inverse_device_loop(inputs)
         if self._incremental_ok(inputs):
             return self._inverse_incremental(inputs, context)
         num_inputs = int(np.prod(inputs.shape[1:]))
@@ -88,6 +90,46 @@ class AutoregressiveTransform(Transform):
                 autoregressive_params = self._conditioner(outputs, context)
                 outputs, logabsdet = self._elementwise_inverse(inputs, autoregressive_params)
         return outputs, logabsdet
+
+    # ---- the D passes on the device (round 4) -----------------------------------------------------------------------
+    def _device_loop_form(self):
+        """``(kind, parameters per dim, spline keyword arguments)`` of the element-wise inverse ``fc_made_inverse`` knows,
+        or None (the other forms keep the host loop)."""
+        return None
+
+    def _device_loop_ok(self, inputs, context):
+        """One kernel for the whole inverse (``fc_made_inverse``): a residual-block MADE with hidden <= 64, <= 3 ReLU
+        blocks, no context / batch norm / active dropout / hooks, D <= 64, float32 rows on the device, inference only."""
+        net = self.autoregressive_net
+        if not (context is None and inputs.dim() == 2 and inputs.is_cuda and inputs.dtype == torch.float32
+                and 1 < inputs.shape[1] <= 64 and inputs.shape[0] >= 1 and options.get("ar_device_loop")
+                and options.get("fused_hidden") and not self._needs_grad(inputs)):
+            return False
+
+        def structure_ok():
+            form = self._device_loop_form()
+            code = ops.activation_code(net.activation) if isinstance(net, made_module.MADE) else None
+            return (form is not None and isinstance(net, made_module.MADE) and inputs.shape[1] == net.initial_layer.in_features
+                    and not hasattr(net, "context_layer") and len(net.blocks) <= 3 and net.hip_hidden_supported(None)
+                    and code is not None and code[0] == ops.ACT_RELU and form[1] <= 48
+                    and net.final_layer.out_features == form[1] * inputs.shape[1])
+
+        return (ops.static_memo(self, "_fc_device_loop_ok", (inputs.shape[1],) + ops.structure_key(net), structure_ok)
+                and not ops.has_hooks(net))
+
+    def _inverse_device_loop(self, inputs):
+        net = self.autoregressive_net
+        kind, per_dim, rq = self._device_loop_form()
+        features = inputs.shape[1]
+        layers = [net.initial_layer, net.final_layer] + [lin for block in net.blocks for lin in block.linear_layers]
+        key = ops.cache_key(*[t for lin in layers for t in (lin.weight, lin.bias)])
+        cache = self.__dict__.get("_fc_made_inverse_pack")
+        if cache is None or cache[0] != key:
+            cache = self.__dict__["_fc_made_inverse_pack"] = (key, ops.pack_made_inverse(net, features, per_dim))
+        n = inputs.shape[0]
+        rows = inputs if n % ops.HIDDEN_ROWS == 0 else torch.nn.functional.pad(inputs, (0, 0, 0, -n % ops.HIDDEN_ROWS))
+        outputs, logabsdet = ops.made_inverse(rows, cache[1], len(net.blocks), per_dim, kind, rq)
+        return (outputs, logabsdet) if rows is inputs else (outputs[:n], logabsdet[:n])
 
     def _incremental_ok(self, inputs):
         """Column-at-a-time inverse applies to a MADE: its input degrees are 1..D and its output
@@ -227,6 +269,9 @@ class MaskedAffineAutoregressiveTransform(AutoregressiveTransform):
         return ops.affine_coupling(inputs, autoregressive_params, None,
                                    activation=ops.AFFINE_MAF_SOFTPLUS, inverse=True)
 
+    def _device_loop_form(self):
+        return (ops.MADE_AFFINE, 2, None)
+
 
 class MaskedShiftAutoregressiveTransform(AutoregressiveTransform):
     """Shift-only AR layer.  As in the reference (autoregressive.py:164-196) ``forward`` adds
@@ -305,6 +350,17 @@ class MaskedPiecewiseRationalQuadraticAutoregressiveTransform(AutoregressiveTran
 
     def _elementwise_inverse(self, inputs, autoregressive_params):
         return self._elementwise(inputs, autoregressive_params, inverse=True)
+
+    def _device_loop_form(self):
+        if self.tails not in (None, "linear") or not 1 <= self.num_bins <= 16:
+            return None
+        divisor = 1.0
+        if hasattr(self.autoregressive_net, "hidden_features"):
+            divisor = float(np.sqrt(self.autoregressive_net.hidden_features))
+        return (ops.MADE_RQ, self._output_dim_multiplier(),
+                dict(num_bins=self.num_bins, tails=self.tails, tail_bound=self.tail_bound, left=-1.2, right=1.2,
+                     bottom=-1.2, top=1.2, min_bin_width=self.min_bin_width, min_bin_height=self.min_bin_height,
+                     min_derivative=self.min_derivative, enable_identity_init=True, wh_divisor=divisor))
 
     # ---- density direction on the fused kernels ------------------------------------------------------------------
     # One MADE pass yields the parameters of all D dims, so the forward is a coupling layer that transforms every

@@ -127,6 +127,27 @@ int fc_rq_fused_linear_backward(int32_t role, const float* x, const float* h, co
                                 float* grad_h, float* grad_bias_pad, float* grad_w_pad, int64_t n, int32_t d,
                                 int32_t d_t, const fc_rq_config* cfg, void* stream);
 
+/* Autoregressive INVERSE of a MADE-conditioned layer with the D passes on the device (the reference's sampling loop,
+ * flowcon/transforms/autoregressive/autoregressive.py:44-53: D conditioner passes, pass d fixing column d): a wave keeps 16
+ * rows, the pre-masked hidden stack (made.py:205-283: initial layer + residual blocks, mask * weight) in LDS, and per pass
+ * runs the stack, the params_per_dim final-layer rows of dim d and the element-wise inverse of that column.
+ *   z, y [n, d] (d <= 64, n % 16 == 0); logabsdet [n] = sum over the columns (added onto it with FC_RQ_ACCUMULATE_LOGABSDET
+ *   in cfg->flags).
+ *   hidden_frag / hidden_unscale / hidden_bias: the image of fc_resnet_hidden_packed made from the MASKED weights
+ *   (rows 64-padded, in_features = d, 1 k-step for d <= 32 else 2), num_blocks <= 3 ReLU residual blocks.
+ *   final_frag: f16 [d][2 k-steps][PT][2 pieces][64 lanes][8], PT = ceil(params_per_dim / 16): lane l of fragment
+ *   (dim, ks, t, piece) holds 2^S_dim Wmasked[dim * P + 16 t + (l & 15)][32 ks + 8 (l >> 4) + j] (zero rows beyond P);
+ *   final_unscale [d] = 2^-S_dim; final_bias [d][16 PT].
+ *   kind FC_MADE_AFFINE (params_per_dim 2: unconstrained scale, shift -- autoregressive.py:97-129; cfg may be NULL) or
+ *   FC_MADE_RQ (cfg: the spline, any K <= 16 and tail mode, autoregressive.py:529-621; cfg->inverse is ignored).
+ *   err_flag: FC_ERR_* bits of the spline inverse. */
+#define FC_MADE_AFFINE 0
+#define FC_MADE_RQ 1
+int fc_made_inverse(const float* z, float* y, float* logabsdet, const void* hidden_frag, const float* hidden_unscale,
+                    const float* hidden_bias, const void* final_frag, const float* final_unscale, const float* final_bias,
+                    uint32_t* err_flag, int64_t n, int32_t d, int32_t num_blocks, int32_t params_per_dim, int32_t kind,
+                    const fc_rq_config* cfg, void* stream);
+
 /* Backward of fc_affine in the forward direction, per-sample parameters (coupling.py:234-252,
  * autoregressive.py:97-129 under torch.autograd): grad_x[n, cols[j]] = gy s; grad_params in the layout of
  * `params` for the same `activation`.  Other columns of grad_x are NOT written. */

@@ -62,6 +62,7 @@ def test_incremental_inverse_matches_full_passes(kind, features, hidden, n, devi
         ref_y, ref_lad = O.transform_apply(t, x.clone(), inverse=True)
         ref_y64, ref_lad64 = O.transform_apply(copy.deepcopy(t).double(), x.double(), inverse=True)
     t = t.to(device)
+    monkeypatch.setitem(options._values, "ar_device_loop", False)      # (this test: the HOST loops; the device loop below)
     with torch.no_grad():
         # by default only where it pays: >= 8 parameters per dim (not shift / affine) and >= 8192 rows
         assert not t._incremental_ok(x.to(device))
@@ -94,6 +95,7 @@ def test_incremental_inverse_random_masks_round_trip(device, monkeypatch):
     t = t.to(device)
     z = torch.randn(500, 7, device=device)
     monkeypatch.setitem(options._values, "ar_incremental", "force")
+    monkeypatch.setitem(options._values, "ar_device_loop", False)
     with torch.no_grad():
         assert t._incremental_ok(z)
         x, lad_inv = t.inverse(z)
@@ -206,9 +208,77 @@ def test_readme_maf_flow_runs_its_made_on_the_hidden_kernel(device):
             lp = flow.log_prob(x.to(device))
         assert len(timer.pairs) == 2 and not hidden_timer.pairs, "the MAF layers did not run as one kernel each"
         z, _ = flow._transform(x.to(device))
-        with ops.KernelTimer("fc_resnet_hidden") as hidden_timer:
+        with ops.KernelTimer("fc_made_inverse") as loop_timer:
             back, _ = flow._transform.inverse(z)
-        assert len(hidden_timer.pairs) == 4, "the MADE hidden stacks of the inverse passes did not run in fc_resnet_hidden"
+        assert len(loop_timer.pairs) == 2, "the inverse of the two MAF layers did not run as one fc_made_inverse each"
+        with options.override(ar_device_loop=False), ops.KernelTimer("fc_resnet_hidden") as hidden_timer:
+            back_host, _ = flow._transform.inverse(z)
+        assert len(hidden_timer.pairs) == 4, "the MADE hidden stacks of the host-loop passes did not run in fc_resnet_hidden"
+        assert maxdiff(back, back_host) <= 1e-4 * max(1.0, float(x.abs().max()))
     assert maxdiff(lp, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
     assert maxdiff(z, z_ref) <= 2e-5 * max(1.0, float(z_ref.abs().max()))
     assert maxdiff(back, x) <= 1e-4 * max(1.0, float(x.abs().max()))
+
+
+# ---- round 4: the D passes inside one kernel (fc_made_inverse) -------------------------------------------------------
+def _rq(features, hidden, k, tails, blocks=2):
+    from flowconductor_amd import transforms as T
+
+    return T.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(features, hidden, num_bins=k, tails=tails, tail_bound=3.0,
+                                                                     num_blocks=blocks)
+
+
+@pytest.mark.parametrize("kind,features,hidden,n", [
+    ("maf", 6, 64, 1000), ("maf", 2, 4, 4096), ("maf", 40, 50, 333), ("rq_linear_tails", 6, 64, 1000),
+    ("rq_linear_tails", 33, 24, 200), ("rq_box", 5, 24, 77), ("rq_k10_box", 8, 64, 512), ("rq_k16_tails", 7, 32, 160),
+    ("rq_k4_3blocks", 64, 64, 96), ("maf_1block", 9, 16, 50)])
+def test_device_loop_inverse_matches_the_reference_scheme(kind, features, hidden, n, device, monkeypatch):
+    """fc_made_inverse against the oracle's D full passes (autoregressive.py:44-53) in float32 and float64, and against this
+    package's own host loop; affine and RQ forms, D up to 64 (two k-steps of the initial layer), every parameter-tile count
+    (P = 2 .. 47), 1-3 blocks, batches that are not whole 16-row blocks."""
+    from flowconductor_amd import transforms as T
+
+    torch.manual_seed(features + hidden)
+    t = {"maf": lambda: T.MaskedAffineAutoregressiveTransform(features, hidden, num_blocks=2),
+         "maf_1block": lambda: T.MaskedAffineAutoregressiveTransform(features, hidden, num_blocks=1),
+         "rq_linear_tails": lambda: _rq(features, hidden, 8, "linear"), "rq_box": lambda: _rq(features, hidden, 5, None),
+         "rq_k10_box": lambda: _rq(features, hidden, 10, None), "rq_k16_tails": lambda: _rq(features, hidden, 16, "linear"),
+         "rq_k4_3blocks": lambda: _rq(features, hidden, 4, "linear", blocks=3)}[kind]().eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    x = _inputs("rq_box" if "box" in kind else "maf", n, features)
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(t, x.clone(), inverse=True)
+        ref_y64, ref_lad64 = O.transform_apply(copy.deepcopy(t).double(), x.double(), inverse=True)
+    t = t.to(device)
+    from flowconductor_amd import ops
+    with torch.no_grad():
+        assert t._device_loop_ok(x.to(device), None)
+        with ops.KernelTimer("fc_made_inverse") as timer:
+            y, lad = t.inverse(x.to(device))
+        assert len(timer.pairs) == 1
+        monkeypatch.setitem(options._values, "ar_device_loop", False)
+        assert not t._device_loop_ok(x.to(device), None)
+        y_host, lad_host = t.inverse(x.to(device))
+        z, lad_fwd = t.forward(y)
+    tol_y = 1e-4 * max(1.0, float(ref_y.abs().max())) + 4 * maxdiff(ref_y, ref_y64)
+    tol_l = 1e-3 * max(1.0, float(ref_lad.abs().max()) / 10) + 4 * maxdiff(ref_lad, ref_lad64)
+    assert maxdiff(y, ref_y64) <= tol_y and maxdiff(lad, ref_lad64) <= tol_l
+    assert maxdiff(y, y_host) <= tol_y and maxdiff(lad, lad_host) <= tol_l
+    assert maxdiff(z, x) <= 2 * tol_y and maxdiff(lad + lad_fwd, torch.zeros_like(lad)) <= 2 * tol_l
+
+
+def test_device_loop_steps_aside(device):
+    """Forms and conditioners fc_made_inverse does not know keep the host loops: sum-of-sigmoids, a context, autograd."""
+    from flowconductor_amd import transforms as T
+
+    x = torch.randn(64, 6, device=device)
+    assert not _build("sos", 6, 32).to(device)._device_loop_ok(x, None)
+    assert not _build("maf", 6, 32, random_mask=True).to(device)._device_loop_ok(x, None)        # feed-forward blocks
+    t = T.MaskedAffineAutoregressiveTransform(6, 32, context_features=3).to(device)
+    assert not t._device_loop_ok(x, torch.randn(64, 3, device=device))
+    t = _build("maf", 6, 32).to(device)
+    assert not t._device_loop_ok(x, None)                     # parameters require gradients, autograd on
+    with torch.no_grad():
+        assert t._device_loop_ok(x, None)

@@ -1,5 +1,6 @@
-"""Autoregressive inverse (sampling direction): column-at-a-time passes vs the reference's D full passes
-(autoregressive.py:44-53).  python tools/probe/bench_ar_inverse.py [features] [log2 rows]"""
+"""Autoregressive inverse (sampling direction): the D passes inside one kernel (fc_made_inverse, round 4) vs the host loop of
+column-at-a-time passes vs the reference's D full passes (autoregressive.py:44-53).
+python tools/probe/bench_ar_inverse.py [features] [log2 rows]"""
 import os
 import sys
 import time
@@ -36,16 +37,23 @@ def main():
     for name, t in cases.items():
         t = t.to(dev).eval()
         with torch.no_grad():
-            inc = full = float("inf")
+            dev_loop = inc = full = float("inf")
             for _ in range(3):          # alternate: the first measurements of a process run on a cold device
+                options._values["ar_device_loop"] = True
+                dev_loop = min(dev_loop, timed(lambda: t.inverse(z)))
+                y2, l2 = t.inverse(z)
+                options._values["ar_device_loop"] = False
                 options._values["ar_incremental"] = "force"
                 inc = min(inc, timed(lambda: t.inverse(z)))
                 y1, l1 = t.inverse(z)
                 options._values["ar_incremental"] = "off"
                 full = min(full, timed(lambda: t.inverse(z)))
                 y0, l0 = t.inverse(z)
-        print(f"{name}: D={features} N={n}  column-at-a-time {inc:.2f} ms  full passes {full:.2f} ms  x{full / inc:.1f}"
-              f"  max|dy| {float((y1 - y0).abs().max()):.2e}  max|dlad| {float((l1 - l0).abs().max()):.2e}")
+            options._values["ar_device_loop"] = True
+            options._values["ar_incremental"] = "auto"
+        print(f"{name}: D={features} N={n}  device loop {dev_loop:.3f} ms  column-at-a-time {inc:.2f} ms  full passes {full:.2f} ms"
+              f"  x{full / dev_loop:.1f} / x{inc / dev_loop:.1f}  max|dy| {float((y2 - y0).abs().max()):.2e}"
+              f"  max|dlad| {float((l2 - l0).abs().max()):.2e}")
 
 
 if __name__ == "__main__":
