@@ -88,8 +88,21 @@ class LULinear(Linear):
             return outputs, self._per_row(-self.logabsdet(), outputs.shape[0])
         with torch.no_grad():
             lower, upper = self._create_lower_upper()
-            outputs = ops.linear(inputs, upper, lower, self.bias, mode=ops.LINEAR_LU_INVERSE)
-            return outputs, self._per_row(-self.logabsdet(), inputs.shape[0])
+            rows = inputs.shape[0]
+            wide = (inputs.dim() == 2 and inputs.is_cuda and rows >= 1024 and rows % ops.SYLVESTER_MM_ROWS == 0
+                    and ops.sylvester_mm_supported(rows, self.features))
+            if wide:
+                # batch-independent parameters: W^-1 = U^-1 L^-1 formed once by two float64 triangular solves against the
+                # identity (what lu.py:70-91 does per batch, in float32), the batch goes through the matrix cores as in the
+                # forward direction:  W^-1 (x - b) = W^-1 x - W^-1 b.  (The per-row substitution kernel: two dependent sweeps
+                # over D per row, 4.3 ms per 2^20 x 64 against 0.11 ms.)
+                eye = torch.eye(self.features, dtype=torch.float64, device=lower.device)
+                l_inv = torch.linalg.solve_triangular(lower.double(), eye, upper=False, unitriangular=True)
+                w_inv = torch.linalg.solve_triangular(upper.double(), l_inv, upper=True)
+                outputs = ops.dense_mm(inputs, w_inv.float(), -(w_inv @ self.bias.double()).float())
+            else:
+                outputs = ops.linear(inputs, upper, lower, self.bias, mode=ops.LINEAR_LU_INVERSE)
+            return outputs, self._per_row(-self.logabsdet(), rows)
 
     def weight(self):
         lower, upper = self._create_lower_upper()

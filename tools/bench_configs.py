@@ -1,5 +1,6 @@
 """The BASELINE.json configurations other than the headline one, as bench.py's ``configs`` block (and on their own:
-``python tools/bench_configs.py [cfg3_sample cfg1 cfg2 cfg5_shared cfg5_per_sample nsf_k10_h256 nsf_k10_h64]``, one JSON object per line).
+``python tools/bench_configs.py [cfg3_sample cfg1 cfg2 cfg5_shared cfg5_per_sample nsf_k10_h256 nsf_k10_h64 cfg1_sample
+maf_rq_sample kernels]``, one JSON object per line).
 
 Every entry carries what the headline line carries: throughput, the dominant kernel's ``roofline`` (algorithmic bytes or
 flops of SURVEY.md 8d per launch / the average launch duration from HIP events on the launch stream), ``cpu_baseline``
@@ -84,9 +85,34 @@ def _cpu_baseline(fn, units, what):
             "sample": "%s, %d repeats, %.1f s" % (what, reps, dt)}
 
 
+CONFIGS_TRAFFIC_PROFILE = "profiles/r04_configs_hbm_traffic.json"     # tools/profile_configs.py
+_traffic_cache = {}
+
+
+def _measured_traffic(config, row="main"):
+    """HBM bytes per launch of a config's dominant kernel from the committed PMC passes (tools/profile_configs.py), or None:
+    profile absent, row absent, or taken from a DIFFERENT library than the one loaded now (its sha256 is recorded)."""
+    if "rec" not in _traffic_cache:
+        from flowconductor_amd import _hip
+        try:
+            rec = json.load(open(os.path.join(ROOT, CONFIGS_TRAFFIC_PROFILE)))
+            if rec.get("library", {}).get("sha256") != _hip.library_info()["sha256"]:
+                print("[bench_configs] %s was taken from another library build: traffic left null" % CONFIGS_TRAFFIC_PROFILE,
+                      file=sys.stderr)
+                rec = None
+        except (OSError, ValueError):
+            rec = None
+        _traffic_cache["rec"] = rec
+    rec = _traffic_cache["rec"]
+    try:
+        return rec["configs"][config][row]["traffic_bytes_per_launch"]
+    except (TypeError, KeyError):
+        return None
+
+
 def _hbm_roofline(kernel, entry, ms, launches, bytes_per_launch, note=None, bound="hbm"):
     """``bound``: the resource that binds the kernel; achieved / peak / frac are always the algorithmic HBM bytes over
-    the launch time against the HBM peak (``roof``)."""
+    the launch time against the HBM peak (``roof``); ``traffic`` (measured HBM bytes per launch, PMC) is filled by ``run``."""
     gbs = bytes_per_launch / (ms * 1e-3) / 1e9
     r = {"bound": bound, "roof": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
          "traffic": None, "kernel": "%s -> %s" % (entry, kernel), "launches_timed": launches, "avg_launch_ms": ms,
@@ -250,7 +276,8 @@ def cfg5_per_sample(device, steps=5, warmup=2, log2n=18):
     step_s, _ = _time_gpu(lambda: ops.sylvester(x, q, r1, r2, b), steps, warmup)
     km = _kernel_ms(lambda: ops.sylvester(x, q, r1, r2, b), ["fc_sylvester"])
     ms, launches = km["fc_sylvester"]
-    byts = (4 * (2 * d * d + 2 * d + m * d)) * n
+    byts = 4 * (d * (d + 1) + 2 * d + m * d) * n      # upper triangles of R1 / R2 (diagonal included), x in, y out, q
+    byts_survey = 4 * (2 * d * d + 2 * d + m * d) * n
     # float64 formula on 256 rows (planar.py:144-166 with per-sample parameters; the reference's own conditional class
     # only runs for D = 2, SURVEY headline facts: this leg is "parity unpinned" by the reference)
     k = 256
@@ -279,12 +306,16 @@ def cfg5_per_sample(device, steps=5, warmup=2, log2n=18):
            "metric": "transform samples/sec", "unit": "samples/s", "value": n / step_s, "ms_per_step": step_s * 1e3,
            "dtype": "f32",
            "roofline": _hbm_roofline("fc::sylvester_kernel (per-sample parameters)", "fc_sylvester", ms, launches, byts,
-                                     "SURVEY 8d accounting: 4*(2 D^2 + 2 D + M D) = 148 480 B per sample; the kernel reads "
-                                     "only the upper triangle of every R row, ~82 KB per sample actually moved"),
+                                     "bytes the algorithm needs: the upper triangles of R1 / R2, 4*(D(D+1) + 2 D + M D) = 83 456 B per "
+                                     "sample (the hyper-network emits full row-major [D, D] matrices; their lower triangles are zero "
+                                     "and never read).  SURVEY 8d's figure prices the full matrices: 148 480 B per sample -> "
+                                     "`survey_accounting`"),
            "parity": {"max_abs_doutputs_vs_f64_formula": _maxdiff(y, y64),
                       "max_abs_dlogabsdet_vs_f64_formula": _maxdiff(lad, lad64), "rows": k,
                       "note": "parity unpinned by the reference (its conditional Sylvester class runs for D = 2 only)"},
            "cpu_baseline": _cpu_baseline(f64_formula, k, "the float64 torch formula on 256 samples per call")}
+    out["roofline"]["survey_accounting"] = {"bytes_per_launch": byts_survey, "achieved": byts_survey / (ms * 1e-3) / 1e9,
+                                            "frac": byts_survey / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     out["cpu_baseline"]["kind"] = "port (float64 formula: the reference class cannot run at D = 128)"
     out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     del q, r1, r2
@@ -429,8 +460,201 @@ def cfg3_sample(device, steps=8, warmup=5, log2n=20):      # (warm-up: the cachi
     return out
 
 
+
+
+# ---- sampling through autoregressive layers (fc_made_inverse: the D passes inside one kernel) --------------------------
+
+def _ar_sample(device, build, d, n, workload, steps=20, warmup=5, cpu_rows=4096):
+    import copy
+    from oracle import torch_oracle as O
+
+    torch.manual_seed(0)
+    flow_cpu = build().eval()
+    flow = copy.deepcopy(flow_cpu).to(device)
+    step_s, _ = _time_gpu(lambda: flow.sample(n), steps, warmup)
+    km = _kernel_ms(lambda: flow.sample(n), ["fc_made_inverse"])
+    ms, launches = km["fc_made_inverse"]
+    z = torch.randn(1024, d, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        ref, ref_lad = O.transform_apply(flow_cpu._transform, z.clone(), inverse=True)
+        ref64, _ = O.transform_apply(copy.deepcopy(flow_cpu._transform).double(), z.double(), inverse=True)
+        got, got_lad = flow._transform.inverse(z.to(device))
+    zc = torch.randn(cpu_rows, d, generator=torch.Generator().manual_seed(8))
+    out = {"workload": workload, "metric": "sample samples/sec", "unit": "samples/s", "value": n / step_s,
+           "ms_per_step": step_s * 1e3, "dtype": "f32",
+           "roofline": _hbm_roofline("fc::made_inverse_kernel", "fc_made_inverse", ms, launches, (8 * d + 4) * n,
+                                     "z row in, x row out, logabsdet: 8 D + 4 B per sample and layer; the D sequential conditioner "
+                                     "passes (autoregressive.py:44-53) run inside the kernel on LDS-resident pre-masked weights: "
+                                     "bound by the serial chain of D x 5 layers, not by HBM", bound="valu_issue"),
+           "parity": {"max_abs_dsamples": _maxdiff(got, ref), "max_abs_dlogabsdet": _maxdiff(got_lad, ref_lad),
+                      "max_abs_dsamples_vs_float64": _maxdiff(got, ref64), "f32_oracle_vs_float64": _maxdiff(ref, ref64),
+                      "rows": 1024},
+           "cpu_baseline": _cpu_baseline(lambda: O.transform_apply(flow_cpu._transform, zc.clone(), inverse=True), cpu_rows,
+                                         "inverse of the stack on %d noise rows per call (the oracle's D full passes)" % cpu_rows)}
+    out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def cfg1_sample(device):
+    """BASELINE.json configs[0] in the sampling direction: Flow.sample(4096) of the README flow."""
+    def build():
+        layers = []
+        for _ in range(2):
+            layers.append(transforms.MaskedAffineAutoregressiveTransform(features=2, hidden_features=4))
+            layers.append(transforms.RandomPermutation(features=2))
+        return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([2]))
+    return _ar_sample(device, build, 2, 4096, "BASELINE.json configs[0], sampling: README flow, Flow.sample(4096)", steps=50, warmup=10)
+
+
+def maf_rq_sample(device, d=8, log2n=20):
+    """Sampling through RQ-spline autoregressive layers (autoregressive.py:529-621): 5 x [MaskedPiecewiseRationalQuadratic
+    AutoregressiveTransform(D = 8, hidden 64, K = 8, linear tails), ReversePermutation], Flow.sample(2^20)."""
+    def build():
+        layers = []
+        for _ in range(5):
+            layers.append(transforms.MaskedPiecewiseRationalQuadraticAutoregressiveTransform(
+                d, 64, num_bins=8, tails="linear", tail_bound=3.0, num_blocks=2))
+            layers.append(transforms.ReversePermutation(features=d))
+        return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([d]))
+    return _ar_sample(device, build, d, 1 << log2n,
+                      "5 x [RQ-spline MAF(D=%d, hidden 64, K=8, linear tails), ReversePermutation], Flow.sample(2^%d)" % (d, log2n),
+                      steps=5, warmup=2, cpu_rows=2048)
+
+
+# ---- one roofline row per remaining kernel family -----------------------------------------------------------------------
+
+def kernels(device):
+    """Stand-alone bijector kernels that the headline flow does not launch: each with its algorithmic bytes per unit
+    (B = 4 d_t (P + 2) + 8 for a coupling bijector; rows in + out for the others), the average launch duration
+    (HIP events), the fraction of the HBM peak, and parity of 1 024 rows against the CPU oracle."""
+    import copy
+    import types
+    from oracle import torch_oracle as O
+
+    rows = {}
+    gen = torch.Generator(device=device).manual_seed(1234)
+
+    def add(name, entry, kernel, fn, bytes_per_launch, parity, note=None, bound="hbm", reps=5):
+        with torch.no_grad():
+            for _ in range(2):
+                fn()
+        ms_list = []
+        for _ in range(reps):
+            ms, launches = _kernel_ms(fn, [entry])[entry]
+            ms_list.append(ms)
+        ms_list.sort()
+        r = _hbm_roofline(kernel, entry, ms_list[len(ms_list) // 2], launches, bytes_per_launch, note, bound)
+        r["parity"] = parity
+        rows[name] = r
+
+    def module_parity(t_gpu, x, inverse=False):
+        t_cpu = copy.deepcopy(t_gpu).cpu()
+        xs = x[:1024]
+        with torch.no_grad():
+            ref, ref_lad = O.transform_apply(t_cpu, xs.cpu().clone(), inverse=inverse)
+            got, got_lad = (t_gpu.inverse if inverse else t_gpu)(xs)
+        return {"max_abs_doutputs": _maxdiff(got, ref), "max_abs_dlogabsdet": _maxdiff(got_lad, ref_lad), "rows": 1024}
+
+    def conditioner(i, o):
+        return nets.ResidualNet(i, o, hidden_features=64, num_blocks=2)
+
+    n18, n20, d = 1 << 18, 1 << 20, 64
+    x18 = torch.randn(n18, d, device=device, generator=gen)
+    mask = utils.create_alternating_binary_mask(d, even=True)
+    # sibling splines as coupling bijectors (K = 8): P = K / 2K - 1 / 2K + 2 parameters per transformed dim
+    torch.manual_seed(0)
+    for name, cls, p in (("linear_spline_coupling", transforms.PiecewiseLinearCouplingTransform, 8),
+                         ("quadratic_spline_coupling", transforms.PiecewiseQuadraticCouplingTransform, 15),
+                         ("cubic_spline_coupling", transforms.PiecewiseCubicCouplingTransform, 18)):
+        kw = dict(num_bins=8, tails="linear", tail_bound=3.0)
+        t = cls(mask, conditioner, **kw).to(device).eval()
+        add(name, "fc_piecewise_spline", "fc::spline tile kernel (%s)" % name.split("_")[0], lambda t=t: t(x18),
+            (4 * 32 * (p + 2) + 8) * n18, module_parity(t, x18))
+        del t
+    # sum of sigmoids, S = 30, D = 8 all transformed, per-sample parameters: forward and numerical inverse
+    ns, dsos = 30, 8
+    xs = torch.randn(n18, dsos, device=device, generator=gen) * 2.0
+    prm = torch.randn(n18, dsos * (3 * ns + 1), device=device, generator=gen)
+    fake = types.SimpleNamespace(n_sigmoids=ns, features=dsos)
+    with torch.no_grad():
+        y_f, l_f = ops.sum_of_sigmoids(xs[:1024], prm[:1024], ns, offset=0.5)
+        r_f, rl_f = O._ew_sos_ar(fake, xs[:1024].cpu() , prm[:1024].cpu(), False)
+        y_i, l_i = ops.sum_of_sigmoids(y_f, prm[:1024], ns, inverse=True, offset=0.5)
+    sos_bytes = (4 * dsos * (3 * ns + 3) + 8) * n18
+    add("sum_of_sigmoids_forward", "fc_sum_of_sigmoids", "fc::sos tile kernel", lambda: ops.sum_of_sigmoids(xs, prm, ns, offset=0.5),
+        sos_bytes, {"max_abs_doutputs": _maxdiff(y_f, r_f), "max_abs_dlogabsdet": _maxdiff(l_f, rl_f.sum(-1) if rl_f.dim() > 1 else rl_f), "rows": 1024})
+    add("sum_of_sigmoids_inverse", "fc_sum_of_sigmoids", "fc::sos tile kernel (bracket + safeguarded Newton)",
+        lambda: ops.sum_of_sigmoids(xs, prm, ns, inverse=True, offset=0.5), sos_bytes,
+        {"round_trip_max_abs": _maxdiff(y_i, xs[:1024]), "max_abs_logabsdet_sum": float((l_f + l_i).abs().max()), "rows": 1024},
+        "~10 evaluations of the S = 30 sigmoids per element: bound by vector issue, not by HBM", bound="valu_issue")
+    del xs, prm
+    # LU linear, D = 64: forward (folded into one dense matrix on the matrix cores for wide batches) and inverse
+    torch.manual_seed(1)
+    x20 = torch.randn(n20, d, device=device, generator=gen)
+    lu = transforms.LULinear(d).to(device).eval()
+    with torch.no_grad():
+        lu.lower_entries.normal_(0, 0.1)
+        lu.upper_entries.normal_(0, 0.1)
+        lu.bias.normal_(0, 0.1)
+    add("lu_linear_forward", "fc_dense_mm", "fc::sylvester_mm_kernel<2> (fc_dense_mm: L U folded, split-f16 MFMA)", lambda: lu(x20), (8 * d + 4) * n20,
+        module_parity(lu, x20), "8 D B per sample; 2 D^2 flop per sample run on the matrix cores")
+    add("lu_linear_inverse", "fc_dense_mm", "fc::sylvester_mm_kernel<2> (fc_dense_mm: U^-1 L^-1 folded in float64, split-f16 MFMA)", lambda: lu.inverse(x20),
+        (8 * d + 4) * n20, module_parity(lu, x20, inverse=True))
+    # shared Householder sequence D = 128, K = 32 (folded into one orthogonal matrix on the matrix cores)
+    x128 = torch.randn(n18, 128, device=device, generator=gen)
+    hh = transforms.HouseholderSequence(features=128, num_transforms=32).to(device).eval()
+    with torch.no_grad():
+        hh.q_vectors.normal_()
+    add("householder_shared", "fc_dense_mm", "fc::sylvester_mm_kernel<4> (fc_dense_mm: 32 reflections folded)", lambda: hh(x128), (8 * 128) * n18,
+        module_parity(hh, x128))
+    del x128
+    # planar, D = 64
+    pl = transforms.PlanarTransform(features=d).to(device).eval()
+    add("planar", "fc_planar", "fc::planar row-wave kernel", lambda: pl(x20), (8 * d + 4) * n20, module_parity(pl, x20))
+    # permutation, D = 64 (bit-exact)
+    perm = transforms.RandomPermutation(features=d).to(device)
+    pp = module_parity(perm, x20)
+    pp["bit_exact"] = pp["max_abs_doutputs"] == 0.0
+    add("permutation", "fc_permute", "fc::permute kernel", lambda: perm(x20), (8 * d) * n20, pp)
+    # element-wise family: tanh (forward), D = 64
+    th = transforms.Tanh().to(device)
+    add("elementwise_tanh", "fc_elementwise", "fc::elementwise kernel", lambda: th(x20), (8 * d + 4) * n20, module_parity(th, x20))
+    # standard normal log-prob, D = 64
+    sn = distributions.StandardNormal([d]).to(device)
+    with torch.no_grad():
+        got = sn.log_prob(x20[:1024])
+        ref = O.standard_normal_log_prob(x20[:1024].cpu())
+    add("standard_normal_log_prob", "fc_standard_normal_log_prob", "fc::std_normal kernel", lambda: sn.log_prob(x20), (4 * d + 4) * n20,
+        {"max_abs_dlog_prob": _maxdiff(got, ref), "rows": 1024})
+    del x20
+    # RQ spline backward (stand-alone bijector, parameters from HBM): cfg-3 layer shape
+    k, d_t = 8, 32
+    p = 3 * k - 1
+    nb = 1 << 19
+    xb = torch.randn(nb, d, device=device, generator=gen) * 1.5
+    prm = torch.randn(nb, d_t * p, device=device, generator=gen)
+    cols = torch.arange(0, d, 2, dtype=torch.int32, device=device)
+    gy, gl = torch.randn(nb, d, device=device, generator=gen), torch.randn(nb, device=device, generator=gen)
+    kw = dict(num_bins=k, tails="linear", tail_bound=3.0, wh_divisor=8.0)
+    rows_p = 256
+    x64 = xb[:rows_p].double().cpu().requires_grad_(True)
+    p64 = prm[:rows_p].double().cpu().requires_grad_(True)
+    out64, lad64 = O.rq_from_rows(x64[:, cols.long().cpu()], p64.view(rows_p, d_t, p).clone(), k, "linear", 3.0, False, wh_divisor=8.0)
+    y64 = x64.clone().index_copy(1, cols.long().cpu(), out64)
+    loss = (y64 * gy[:rows_p].double().cpu()).sum() + (lad64.sum(dim=1) * gl[:rows_p].double().cpu()).sum()
+    gx_ref, gp_ref = torch.autograd.grad(loss, (x64, p64))
+    gx, gp = ops.rq_spline_backward(xb[:rows_p], prm[:rows_p], cols, gy[:rows_p], gl[:rows_p], **kw)
+    add("rq_spline_backward", "fc_rq_spline_backward", "fc::rq_backward wave kernel",
+        lambda: ops.rq_spline_backward(xb, prm, cols, gy, gl, **kw), (2 * 4 * d_t * p + 12 * d_t + 4) * nb,
+        {"max_rel_dgrad_inputs_vs_f64_autograd": _maxdiff(gx, gx_ref) / max(1e-30, float(gx_ref.abs().max())),
+         "max_rel_dgrad_params_vs_f64_autograd": _maxdiff(gp, gp_ref) / max(1e-30, float(gp_ref.abs().max())), "rows": rows_p})
+    return {"workload": "stand-alone bijector kernels (SURVEY 8a rows S4, G1-G3, U1, H1, P1, M1, E1, F2, and the spline backward)",
+            "kernels": rows}
+
+
 ALL = {"cfg3_sample": cfg3_sample, "cfg1": cfg1, "cfg2": cfg2, "cfg5_shared": cfg5_shared, "cfg5_per_sample": cfg5_per_sample,
-       "nsf_k10_h256": nsf_k10_h256, "nsf_k10_h64": nsf_k10_h64}
+       "nsf_k10_h256": nsf_k10_h256, "nsf_k10_h64": nsf_k10_h64, "cfg1_sample": cfg1_sample, "maf_rq_sample": maf_rq_sample,
+       "kernels": kernels}
 
 
 def run(device, which=None, log=None):
@@ -439,6 +663,16 @@ def run(device, which=None, log=None):
         t0 = time.perf_counter()
         try:
             res[name] = ALL[name](device)
+            # measured HBM traffic of the dominant kernel(s), from the committed PMC passes of this same command
+            rl = res[name].get("roofline")
+            if isinstance(rl, dict) and rl.get("traffic") is None:
+                rl["traffic"] = _measured_traffic(name)
+                if rl["traffic"] is not None:
+                    rl["traffic_profile"] = CONFIGS_TRAFFIC_PROFILE
+            for row, r in (res[name].get("kernels") or {}).items():
+                r["traffic"] = _measured_traffic(name, row)
+                if r["traffic"] is not None:
+                    r["traffic_profile"] = CONFIGS_TRAFFIC_PROFILE
         except Exception as e:      # a secondary block must never take the headline line down with it
             res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         if log:
