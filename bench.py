@@ -50,7 +50,34 @@ def build_flow():
     return flows.Flow(transforms.CompositeTransform(layers), distributions.StandardNormal([FEATURES])).eval()
 
 
-TRAFFIC_PROFILE = "profiles/r03_hbm_traffic.json"
+TRAFFIC_PROFILE = "profiles/r04_hbm_traffic.json"
+FUSED_COUNTERS = "profiles/r04_fused_sq_counters.txt"
+HIDDEN_COUNTERS = "profiles/r04_hidden_sq_counters.txt"
+# Set by main(): True = a profile taken from ANOTHER build of the library ends the run (tools/profile_bench.sh verifies its own
+# output this way); False (default) = its numbers are left out of the line (traffic / issue_bound null) and the mismatch is
+# reported in `profile_mismatch` -- the driver's end-of-round run must not die of a stale profile.
+STRICT_PROFILES = False
+PROFILE_MISMATCH = []
+
+
+def _profile_sha_ok(name, recorded):
+    """True when the profile file `name` was taken from the library loaded now (or predates the sha256 bookkeeping)."""
+    from flowconductor_amd import _hip
+    if not recorded:
+        PROFILE_MISMATCH.append({"profile": name, "reason": "no library.sha256 recorded"})
+        if STRICT_PROFILES:
+            raise SystemExit("bench.py: %s carries no library.sha256 -- re-run tools/profile_bench.sh" % name)
+        return False
+    loaded = _hip.library_info()["sha256"]
+    if recorded != loaded:
+        PROFILE_MISMATCH.append({"profile": name, "recorded_sha256": recorded, "loaded_sha256": loaded})
+        if STRICT_PROFILES:
+            raise SystemExit("bench.py: %s was taken from library %s, the loaded library is %s -- re-run tools/profile_bench.sh"
+                             % (name, recorded[:16], loaded[:16]))
+        print("[bench] %s was taken from another library build (%s..., loaded %s...): its numbers are left out"
+              % (name, recorded[:12], loaded[:12]), file=sys.stderr)
+        return False
+    return True
 # kernel symbol (substring) each C-ABI entry launches in this flow: the committed PMC profile must have counted THAT
 # kernel, or its number does not belong in this line
 EXPECTED_KERNELS = {"fc_rq_spline_fused_linear": "rq_fused_linear_kernel3", "fc_resnet_hidden": "resnet_hidden_kernel",
@@ -69,6 +96,8 @@ def measured_traffic_per_launch(entry, rows_per_launch):
         return None
     if entry not in rec or rows_per_launch != (1 << 20):
         return None
+    if not _profile_sha_ok(TRAFFIC_PROFILE, rec.get("library", {}).get("sha256")):
+        return None
     if rec[entry].get("kernel") != EXPECTED_KERNELS[entry]:
         raise SystemExit("bench.py: %s counted kernel %r for %s, this flow launches %r -- re-run tools/profile_bench.sh"
                          % (TRAFFIC_PROFILE, rec[entry].get("kernel"), entry, EXPECTED_KERNELS[entry]))
@@ -85,11 +114,15 @@ def issue_bound(counters_file, launch_ms, rows_per_launch, valu_cycles):
     try:
         if rows_per_launch != (1 << 20):
             return None
-        vals = {}
+        vals, sha = {}, None
         for line in open(os.path.join(ROOT, counters_file)):
             parts = line.split()
+            if len(parts) >= 2 and parts[0] == "library.sha256":
+                sha = parts[1]
             if len(parts) >= 3 and parts[0] in ("SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_VALU_TRANS_F32"):
                 vals[parts[0]] = float(parts[2])
+        if not _profile_sha_ok(counters_file, sha):
+            return None
         cycles = valu_cycles * (vals["SQ_INSTS_VALU"] + vals.get("SQ_INSTS_VALU_TRANS_F32", 0.0)) + 8.0 * vals["SQ_INSTS_MFMA"]
         avail = 256 * 4 * 2.4e9 * launch_ms * 1e-3
         return {"valu_wave_instructions": vals["SQ_INSTS_VALU"], "mfma_wave_instructions": vals["SQ_INSTS_MFMA"],
@@ -218,6 +251,9 @@ def main():
     ap.add_argument("--chunk-log2", type=int, default=0, help="log2 rows per pass through the stack (0 = whole shard)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the secondary `configs` block (cfg 1, 2, 5, K=10)")
+    ap.add_argument("--strict-profiles", action="store_true",
+                    help="end the run (SystemExit) when a committed profile (HBM traffic, SQ counters) was taken from another "
+                         "build of the library than the one loaded; default: leave its numbers out and say so")
     ap.add_argument("--cpu-sample-log2", type=int, default=16, help="rows per CPU-baseline chunk (BASELINE.md: 2^16)")
     ap.add_argument("--loglik-allreduce", default="abi", choices=["abi", "torch"],
                     help="abi: fc_allreduce_loglik (RCCL through the C ABI); torch: torch.distributed.all_reduce")
@@ -231,6 +267,8 @@ def main():
     ap.add_argument("--share-device0", action="store_true",
                     help="rehearsal only: every rank on the single GPU of the box (with --dist-backend gloo)")
     args = ap.parse_args()
+    global STRICT_PROFILES
+    STRICT_PROFILES = args.strict_profiles
 
     stray = [k for k in LEGACY_ENV_SWITCHES if k in os.environ]
     if stray:
@@ -425,10 +463,10 @@ def main():
                                "algorithmic_bytes_per_launch": f_bytes,
                                "share_of_step": sum(fused_ms) / (1e3 * elapsed / args.steps),
                                "binding_resource": "valu_issue",
-                               "limiter": "VALU issue (spline arithmetic); SQ counters in profiles/r03_fused_sq_counters.txt; "
+                               "limiter": "VALU issue (spline arithmetic); SQ counters in " + FUSED_COUNTERS + "; "
                                           "`frac` is the distance to the HBM roof the contract asks for, "
                                           "`issue_bound.frac` the share of the SIMDs' issue cycles in use",
-                               "issue_bound": issue_bound("profiles/r03_fused_sq_counters.txt", f_avg, rows_per_launch, 3.6),
+                               "issue_bound": issue_bound(FUSED_COUNTERS, f_avg, rows_per_launch, 3.6),
                                # BASELINE.md section 4 prices a coupling bijector at B = 4 d_t (P + 2) + 8 bytes per
                                # sample and layer (parameters read from HBM).  The fused kernel never moves them; in
                                # that accounting it delivers:
@@ -456,7 +494,7 @@ def main():
                                           "algorithmic_bytes_per_launch": h_bytes,
                                           "share_of_step": sum(hidden_ms) / (1e3 * elapsed / args.steps),
                                           "binding_resource": "mfma_issue / dependent-latency (a wave walks the layers serially)",
-                                          "issue_bound": issue_bound("profiles/r03_hidden_sq_counters.txt", h_avg,
+                                          "issue_bound": issue_bound(HIDDEN_COUNTERS, h_avg,
                                                                      rows_per_launch, 2.6),
                                           "matrix_pipe": {"algorithmic_tflops": hflops / (h_avg * 1e-3) / 1e12,
                                                           "executed_tflops": 3.0 * hflops / (h_avg * 1e-3) / 1e12,
@@ -486,6 +524,8 @@ def main():
                 import bench_configs
 
                 out["configs"] = bench_configs.run(device, log=log)
+        if PROFILE_MISMATCH:
+            out["profile_mismatch"] = PROFILE_MISMATCH
         print(json.dumps(out))
     if reducer is not None:
         reducer.close()

@@ -213,18 +213,26 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   int mycol = 0;     // this lane's column of x (cs[] is read ONCE, behind the prologue's barrier: per step it was an LDS round trip in front of the x read)
   const int xvec = R * D / 4;     // float4 per x tile: thread tid owns slots tid + 512 k, k < XV
   // (named scalars, not arrays: hipcc keeps register arrays that are written under `if (has_next)` in scratch)
+  // kCarry: x pieces beyond the first ride in registers across the tile.  Only the headline shape (d_t = 32, D <= 64) has room
+  // for them (246-251 registers, no scratch); the other instantiations spilled 12-144 B per lane and read those pieces when
+  // they park the tile instead (one exposed L2 / HBM latency per tile for layers the kernel was not tuned for).
+  constexpr bool kCarry = kFull && XV <= 2;
   float4 hv0, hv1, xv0, xv1, xv2, xv3;
   hv0 = hv1 = xv0 = xv1 = xv2 = xv3 = float4{0.f, 0.f, 0.f, 0.f};
+  int64_t fetched = tile0;
   auto fetch = [&](int64_t t) __attribute__((always_inline)) {
+    fetched = t;
     if (FC_ABL & 8) t = tile0;   // ablation: every tile's loads hit in L2
     const float4* hg = reinterpret_cast<const float4*>(a.h + t * R * kH);
     hv0 = hg[tid];
-    if constexpr (HV > 1) hv1 = hg[tid + 512];
+    if constexpr (HV > 1 && kFull) hv1 = hg[tid + 512];
     const float4* xg = reinterpret_cast<const float4*>(a.x + t * R * D);
     xv0 = xg[tid < xvec ? tid : 0];
-    if constexpr (XV > 1) xv1 = xg[tid + 512 < xvec ? tid + 512 : 0];
-    if constexpr (XV > 2) xv2 = xg[tid + 1024 < xvec ? tid + 1024 : 0];
-    if constexpr (XV > 3) xv3 = xg[tid + 1536 < xvec ? tid + 1536 : 0];
+    if constexpr (kCarry) {
+      if constexpr (XV > 1) xv1 = xg[tid + 512 < xvec ? tid + 512 : 0];
+      if constexpr (XV > 2) xv2 = xg[tid + 1024 < xvec ? tid + 1024 : 0];
+      if constexpr (XV > 3) xv3 = xg[tid + 1536 < xvec ? tid + 1536 : 0];
+    }
   };
   auto xslot = [&](int buf, int i) __attribute__((always_inline)) {   // float4 index i of a [R, D] tile -> its LDS position
     if constexpr (!kPadX) return reinterpret_cast<float4*>(xbuf + buf * R * XS + 4 * i);
@@ -262,8 +270,16 @@ __global__ __launch_bounds__(512) void rq_fused_linear_kernel3(RQOp<kK> op, Fuse
   // h tile -> hbuf[hb2] (ring of 2), its row scales and the x tile -> ring slot x3 (ring of 3)
   auto park = [&](int hb2, int x3) __attribute__((always_inline)) {
     park_h(hb2, x3, 0, hv0);
+    if constexpr (HV > 1 && !kFull)      // (the generic variants carry one piece of h and one of x across the tile)
+      hv1 = reinterpret_cast<const float4*>(a.h + ((FC_ABL & 8) ? tile0 : fetched) * R * kH)[tid + 512];
     if constexpr (HV > 1) park_h(hb2, x3, 1, hv1);
     if (tid < xvec) *xslot(x3, tid) = xv0;
+    if constexpr (!kCarry && XV > 1) {
+      const float4* xg = reinterpret_cast<const float4*>(a.x + ((FC_ABL & 8) ? tile0 : fetched) * R * D);
+      xv1 = xg[tid + 512 < xvec ? tid + 512 : 0];
+      if constexpr (XV > 2) xv2 = xg[tid + 1024 < xvec ? tid + 1024 : 0];
+      if constexpr (XV > 3) xv3 = xg[tid + 1536 < xvec ? tid + 1536 : 0];
+    }
     if constexpr (XV > 1) if (tid + 512 < xvec) *xslot(x3, tid + 512) = xv1;
     if constexpr (XV > 2) if (tid + 1024 < xvec) *xslot(x3, tid + 1024) = xv2;
     if constexpr (XV > 3) if (tid + 1536 < xvec) *xslot(x3, tid + 1536) = xv3;

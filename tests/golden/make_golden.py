@@ -108,6 +108,22 @@ def make_knot_fixture(path):
     print("wrote", path, sorted(out))
 
 
+def make_softplus_4d_fixture(L, path):
+    """The reference's ``Softplus`` on a 4-D batch (nonlinearities.py:172-189): it sums the log-Jacobian over the LAST dim
+    only (``.sum(-1)``, :182 / :188), so its logabsdet has shape [N, C, H] there, not [N].  The fixture pins what this package
+    does with that quirk (tests/test_gpu_round4.py): outputs identical, logabsdet = the reference's summed over the remaining
+    non-batch dims."""
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(5, 3, 4, 6, generator=gen) * 2.0
+    t = L.transforms.Softplus().eval()
+    with torch.no_grad():
+        y, lad = t(x.clone())
+        xi, ladi = t.inverse(y.clone())
+    out = {"x": x.numpy(), "y": y.numpy(), "lad": lad.numpy(), "xinv": xi.numpy(), "ladinv": ladi.numpy()}
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: v.shape for k, v in out.items()})
+
+
 def main():
     sys.path.insert(0, HERE)
     import cases
@@ -115,6 +131,7 @@ def main():
     L = import_reference()
     torch.set_num_threads(4)
     make_knot_fixture(os.path.join(HERE, "fn_rq_interior_knots.npz"))
+    make_softplus_4d_fixture(L, os.path.join(HERE, "fn_softplus_4d.npz"))
     if "--knots-only" in sys.argv:
         return
     only = sys.argv[sys.argv.index("--only") + 1:] if "--only" in sys.argv else None      # --only name [name ...]

@@ -457,12 +457,19 @@ def test_made_hidden_stack_on_hip_kernel(kind, inverse, device, monkeypatch):
     fn = t.inverse if inverse else t.forward
     with torch.no_grad():
         assert t.autoregressive_net.hip_hidden_supported()
-        with ops.KernelTimer("fc_resnet_hidden") as timer, ops.KernelTimer("fc_affine_coupling_resnet") as one:
+        with ops.KernelTimer("fc_resnet_hidden") as timer, ops.KernelTimer("fc_affine_coupling_resnet") as one, \
+                ops.KernelTimer("fc_made_inverse") as loop:
             y, lad = fn(x.to(device))
         if kind == "maf" and not inverse:      # round 3: the affine form's density direction is ONE kernel (hidden stack inside)
             assert len(one.pairs) == 1 and not timer.pairs, "the one-kernel MAF path did not run"
+        elif inverse:                          # round 4: the D passes of the inverse run inside ONE kernel
+            assert len(loop.pairs) == 1 and not timer.pairs, "the device-loop inverse did not run"
+            with options.override(ar_device_loop=False), ops.KernelTimer("fc_resnet_hidden") as host_timer:
+                y_host, lad_host = fn(x.to(device))
+            assert len(host_timer.pairs) == 6, "the hidden-layer kernel did not run in the host loop"
+            assert maxdiff(y, y_host) <= 3e-4 * max(1.0, float(ref_y.abs().max()))
         else:
-            assert len(timer.pairs) == (6 if inverse else 1), "the hidden-layer kernel did not run"
+            assert len(timer.pairs) == 1, "the hidden-layer kernel did not run"
         monkeypatch.setitem(options._values, "fused_hidden", False)
         y2, lad2 = fn(x.to(device))
     scale = max(1.0, float(ref_y.abs().max()))

@@ -100,3 +100,25 @@ def test_one_launch_backward_odd_group_counts(k, tails, d, d_t, n, device):
     again = ops.rq_fused_linear_backward(x.to(device), h.to(device), gy.to(device), gl.to(device), packed, packed_t,
                                          cols.to(device), num_bins=k, tails=tails, tail_bound=3.0, **kw)
     assert torch.equal(got[0], again[0]) and torch.equal(got[1], again[1])
+
+
+def test_softplus_on_a_4d_batch_against_the_reference_fixture(device):
+    """The reference's ``Softplus`` sums its log-Jacobian over the LAST dim only (nonlinearities.py:182,188): on a 4-D batch
+    its logabsdet has shape [N, C, H].  This package returns [N] (the sum over all non-batch dims, what every other
+    transform of the reference does and what CompositeTransform adds up): outputs identical to the reference fixture
+    (tests/golden/fn_softplus_4d.npz, generated by importing the reference), logabsdet = the fixture's summed over C, H."""
+    import os
+
+    import numpy as np
+
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "fn_softplus_4d.npz"))
+    t = T.Softplus().to(device)
+    x = torch.from_numpy(fx["x"]).to(device)
+    with torch.no_grad():
+        y, lad = t(x)
+        xi, ladi = t.inverse(torch.from_numpy(fx["y"]).to(device))
+    assert lad.shape == (5,) and ladi.shape == (5,)
+    assert maxdiff(y, torch.from_numpy(fx["y"])) <= 2e-6
+    assert maxdiff(lad, torch.from_numpy(fx["lad"]).sum(dim=(1, 2))) <= 2e-5
+    assert maxdiff(xi, torch.from_numpy(fx["xinv"])) <= 2e-5
+    assert maxdiff(ladi, torch.from_numpy(fx["ladinv"]).sum(dim=(1, 2))) <= 2e-4

@@ -29,7 +29,10 @@ for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if "$MATCH" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+import hashlib
+sha = hashlib.sha256(open("$R/flowconductor_amd/csrc/libflowcon_hip.so", "rb").read()).hexdigest()
 with open("$OUT/summary.txt", "w") as o:
+    o.write("library.sha256 %s  (flowconductor_amd/csrc/libflowcon_hip.so; bench.py compares it with the loaded library)\n" % sha)
     for k in sorted(acc):
         v = acc[k]
         line = "%-32s mean/launch %.4g  (launches %d)" % (k, sum(v) / len(v), len(v))

@@ -23,9 +23,16 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- pyth
 echo "train trace exit $?"
 cd $R
 python3 tools/summarize_profile.py $OUT $TAG
+# SQ counters of the two hot kernels of the SAME library (the summaries carry its sha256)
+bash tools/probe/pmc_kernel.sh $TAG fused rq_fused_linear_kernel3 > $OUT/pmc_fused.log 2>&1 && cp gpurun_out/pmc_fused_$TAG/summary.txt profiles/${TAG}_fused_sq_counters.txt
+bash tools/probe/pmc_kernel.sh $TAG hidden resnet_hidden_kernel > $OUT/pmc_hidden.log 2>&1 && cp gpurun_out/pmc_hidden_$TAG/summary.txt profiles/${TAG}_hidden_sq_counters.txt
 for what in configs train; do
   f=$(ls $OUT/trace_$what/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp $f profiles/${TAG}_${what}_kernel_stats.csv
 done
 cp $OUT/configs.jsonl profiles/${TAG}_configs_under_rocprof.jsonl 2>/dev/null
 cp $OUT/train.json profiles/${TAG}_train_under_rocprof.json 2>/dev/null
+# the line of the profiled library, un-profiled, refusing any profile of another build: every profiles/${TAG}_* file must carry
+# the sha256 that this line reports as `library.sha256`
+python3 bench.py --steps 20 --warmup 5 --strict-profiles > profiles/${TAG}_bench_n1.json 2> $OUT/bench_final.err
+echo "final strict bench exit $?"

@@ -8,8 +8,12 @@ import os
 import shutil
 import sys
 
+import hashlib
+
 out, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBRARY = {"path": "flowconductor_amd/csrc/libflowcon_hip.so",
+           "sha256": hashlib.sha256(open(os.path.join(root, "flowconductor_amd", "csrc", "libflowcon_hip.so"), "rb").read()).hexdigest()}
 prof = os.path.join(root, "profiles")
 stats = glob.glob(os.path.join(out, "trace", "*", "*kernel_stats.csv"))
 if stats:
@@ -46,7 +50,7 @@ def per_launch(counter, key):
     return sum(sel) / len(sel), len(sel)
 
 
-summary = {"tag": tag,
+summary = {"tag": tag, "library": LIBRARY,
            "source": "tools/profile_bench.sh %s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of "
                      "bench.py --steps 3 --warmup 3, per-launch means over the full-batch (2^20-row) launches; "
                      "FETCH_SIZE x2 (gfx950 wide-stream correction), KiB -> bytes" % tag}
@@ -69,7 +73,7 @@ print(json.dumps(summary))
 traces = glob.glob(os.path.join(out, "trace", "*", "*kernel_trace.csv"))
 if traces:
     rows = list(csv.DictReader(open(traces[0])))
-    per_step = {"source": "rocprofv3 --kernel-trace of the profiled bench.py run (%s_bench_n1_under_rocprof.json); "
+    per_step = {"library": LIBRARY, "source": "rocprofv3 --kernel-trace of the profiled bench.py run (%s_bench_n1_under_rocprof.json); "
                           "microseconds; passes in launch order: warm-up steps, timed steps (the last one carries "
                           "bench.py's HIP-event pairs), then the untimed FC_FUSED=0 pass (hidden kernel only)" % tag}
     for entry in ("fc_rq_spline_fused_linear", "fc_resnet_hidden"):
