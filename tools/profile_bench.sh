@@ -1,6 +1,10 @@
 #!/bin/bash
 # Profile `bench.py` on the GPU box: kernel-trace stats + separate PMC passes for HBM traffic.
-# Usage (from the repo root, on the GPU box):  bash tools/profile_bench.sh <tag>
+# Usage (from the repo root, on the GPU box):  [STAGES="a b"] bash tools/profile_bench.sh <tag>
+#   stage a: kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py, traces of the configs and of the training step, summaries
+#   stage b: SQ counters of the two hot kernels, then the un-profiled line with --strict-profiles (every profiles/<tag>_* file
+#            must carry the sha256 of the library that line reports)
+#   (tools/profile_configs.py <tag>: the PMC traffic of every `configs` entry -- a third call, its own ~8 minutes)
 # Writes raw output under gpurun_out/prof_<tag>/ and the judged summaries under profiles/.
 set -u
 TAG=${1:-r01}
@@ -8,7 +12,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT $R/profiles
+STAGES=${STAGES:-"a b"}
 ARGS="--steps 3 --warmup 3 --no-cpu-baseline --no-configs"   # 3 warm-up steps: the first two run 5-10 % slower under the profiler
+if [[ " $STAGES " == *" a "* ]]; then
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err
 echo "trace exit $?"
@@ -23,16 +29,22 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_train -- pyth
 echo "train trace exit $?"
 cd $R
 python3 tools/summarize_profile.py $OUT $TAG
-# SQ counters of the two hot kernels of the SAME library (the summaries carry its sha256)
-bash tools/probe/pmc_kernel.sh $TAG fused rq_fused_linear_kernel3 > $OUT/pmc_fused.log 2>&1 && cp gpurun_out/pmc_fused_$TAG/summary.txt profiles/${TAG}_fused_sq_counters.txt
-bash tools/probe/pmc_kernel.sh $TAG hidden resnet_hidden_kernel > $OUT/pmc_hidden.log 2>&1 && cp gpurun_out/pmc_hidden_$TAG/summary.txt profiles/${TAG}_hidden_sq_counters.txt
 for what in configs train; do
   f=$(ls $OUT/trace_$what/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp $f profiles/${TAG}_${what}_kernel_stats.csv
 done
 cp $OUT/configs.jsonl profiles/${TAG}_configs_under_rocprof.jsonl 2>/dev/null
 cp $OUT/train.json profiles/${TAG}_train_under_rocprof.json 2>/dev/null
+fi
+if [[ " $STAGES " == *" b "* ]]; then
+cd $R
+# SQ counters of the two hot kernels of the SAME library (the summaries carry its sha256)
+bash tools/probe/pmc_kernel.sh $TAG fused rq_fused_linear_kernel3 > $OUT/pmc_fused.log 2>&1 && cp gpurun_out/pmc_fused_$TAG/summary.txt profiles/${TAG}_fused_sq_counters.txt
+bash tools/probe/pmc_kernel.sh $TAG hidden resnet_hidden_kernel > $OUT/pmc_hidden.log 2>&1 && cp gpurun_out/pmc_hidden_$TAG/summary.txt profiles/${TAG}_hidden_sq_counters.txt
 # the line of the profiled library, un-profiled, refusing any profile of another build: every profiles/${TAG}_* file must carry
 # the sha256 that this line reports as `library.sha256`
 python3 bench.py --steps 20 --warmup 5 --strict-profiles > profiles/${TAG}_bench_n1.json 2> $OUT/bench_final.err
 echo "final strict bench exit $?"
+fi
+# gpurun only carries gpurun_out/ back: the judged files travel there too (copy them into profiles/ after the call)
+mkdir -p $R/gpurun_out/profiles_$TAG && cp $R/profiles/${TAG}_* $R/gpurun_out/profiles_$TAG/ 2>/dev/null

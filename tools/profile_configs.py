@@ -100,6 +100,9 @@ def main():
             old["configs"].update(res["configs"])
             res = old
     json.dump(res, open(dst, "w"), indent=1)
+    carry = os.path.join(ROOT, "gpurun_out", "profiles_%s" % tag)      # gpurun only carries gpurun_out/ back
+    os.makedirs(carry, exist_ok=True)
+    json.dump(res, open(os.path.join(carry, os.path.basename(dst)), "w"), indent=1)
     print(json.dumps(res["configs"]))
 
 
