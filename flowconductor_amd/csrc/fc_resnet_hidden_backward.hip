@@ -71,7 +71,8 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
 
   // (the wave index as a scalar: tile and strip addresses derived from it stay SGPR bases)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int s16 = lane & 15, g = lane >> 4;
+  const int s16_ = lane & 15, g_ = lane >> 4;
+  const int s16 = s16_, g = g_;
   const int D = a.D, k0 = a.k0;
   if ((int64_t)blockIdx.x >= a.rounds) return;
   for (int i = tid; i < kFragsF * 64; i += kHbThreads) wfl[i] = a.wf[i];
@@ -143,6 +144,11 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
   // (g, a) of this wave's 16 samples -> the shared [feature][sample] images; barrier; this wave's tiles of gW_l
   auto weight_grad = [&](auto Lc, const f32x4 (&gv)[4], const f32x4 (&av)[4], int wt_off, int wt_frags) __attribute__((always_inline)) {
     constexpr int l = decltype(Lc)::value;
+    // fresh copies of the lane coordinates behind an opaque asm: the staging / tile addresses of the five weight_grad phases are
+    // then formed per phase instead of being hoisted out of the round loop as loop-invariant registers (round 4: the headline
+    // instantiation <2, 1> 132 -> 0 B of scratch, <1, 2> 196 -> 68 B, <2, 2> 864 -> 656 B)
+    int s16 = s16_, g = g_;
+    asm volatile("" : "+v"(s16), "+v"(g));
     __syncthreads();        // the previous layer's tiles have been read, the previous W^T product is done
     if constexpr (kWtLds) {
       // fragments wt_off .. wt_off + wt_frags of the transposed image -> wts; wave w moves fragments w, w + 8
@@ -165,8 +171,11 @@ __global__ __launch_bounds__(kHbThreads) void resnet_hidden_backward_kernel(HidB
     const int tile0 = kInTiles == 2 ? wave : 2 * wave;                 // 8 or 16 tiles over 8 waves
     const int ot = tile0 / kInTiles, it0 = tile0 % kInTiles;
     const float* ga = gT + (16 * ot + s16) * kHbLd + 32 * g;
+#ifndef FC_HB_ABL
+#define FC_HB_ABL 0      // probe builds: 1 = no weight-gradient products (staging and barriers stay)
+#endif
 #pragma unroll
-    for (int c4 = 0; c4 < 8; ++c4) {
+    for (int c4 = 0; c4 < ((FC_HB_ABL & 1) ? 0 : 8); ++c4) {
       const float4 av4 = *reinterpret_cast<const float4*>(ga + 4 * c4);
       const float avs[4] = {av4.x, av4.y, av4.z, av4.w};
 #pragma unroll
