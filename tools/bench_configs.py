@@ -110,6 +110,28 @@ def _measured_traffic(config, row="main"):
         return None
 
 
+KERNELS_SQ_PROFILE = "profiles/r04_kernels_sq_counters.json"          # tools/profile_configs.py --sq
+
+
+def _sq_counters(row):
+    if "sq" not in _traffic_cache:
+        from flowconductor_amd import _hip
+        try:
+            rec = json.load(open(os.path.join(ROOT, KERNELS_SQ_PROFILE)))
+            if rec.get("library", {}).get("sha256") != _hip.library_info()["sha256"]:
+                rec = None
+        except (OSError, ValueError):
+            rec = None
+        _traffic_cache["sq"] = rec
+    rec = _traffic_cache["sq"]
+    try:
+        v = rec["kernels"][row]
+        return {"valu_active": v["valu_active_frac_of_wave_cycles"], "wait_memory": v["wait_memory_frac_of_wave_cycles"],
+                "wait_issue": v["wait_issue_frac_of_wave_cycles"], "profile": KERNELS_SQ_PROFILE}
+    except (TypeError, KeyError):
+        return None
+
+
 def _hbm_roofline(kernel, entry, ms, launches, bytes_per_launch, note=None, bound="hbm"):
     """``bound``: the resource that binds the kernel; achieved / peak / frac are always the algorithmic HBM bytes over
     the launch time against the HBM peak (``roof``); ``traffic`` (measured HBM bytes per launch, PMC) is filled by ``run``."""
@@ -185,7 +207,12 @@ def cfg2(device, steps=20, warmup=5):
     flow = copy.deepcopy(flow_cpu).to(device)
     n = 1 << 18
     x = torch.randn(n, 32, device=device, generator=torch.Generator(device=device).manual_seed(1234))
-    step_s, _ = _time_gpu(lambda: flow.log_prob(x), steps, warmup)
+    from flowconductor_amd.utils.graphs import GraphedCall
+
+    eager_s, lp_e = _time_gpu(lambda: flow.log_prob(x), steps, warmup)
+    graphed = GraphedCall(flow.log_prob, x, clone=False)       # the 8 dependent launches + the base distribution as ONE HIP graph
+    graph_s, lp_g = _time_gpu(lambda: graphed(x), steps, warmup)
+    step_s = min(eager_s, graph_s)
     km = _kernel_ms(lambda: flow.log_prob(x), ["fc_affine_coupling_resnet"])
     a_ms, a_n = km["fc_affine_coupling_resnet"]
     xs = x[:2048].cpu()
@@ -196,6 +223,9 @@ def cfg2(device, steps=20, warmup=5):
     xc = torch.randn(sample, 32, generator=torch.Generator().manual_seed(99))
     out = {"workload": "BASELINE.json configs[1]: 8-layer affine-coupling flow, D=32, ResidualNet(64, 2 blocks), N=2^18",
            "metric": "log_prob samples/sec", "unit": "samples/s", "value": n / step_s, "ms_per_step": step_s * 1e3,
+           "eager": {"value": n / eager_s, "ms_per_step": eager_s * 1e3},
+           "hip_graph": {"value": n / graph_s, "ms_per_step": graph_s * 1e3, "launches_per_replay": 1,
+                         "max_abs_dlog_prob_vs_eager": _maxdiff(lp_g, lp_e)},
            "dtype": "f32",
            "roofline": _hbm_roofline("resnet_hidden_kernel (coupling tail)", "fc_affine_coupling_resnet", a_ms, a_n, 264 * n,
                                      "one kernel per coupling layer (hidden stack + final Linear + affine bijector); "
@@ -673,6 +703,9 @@ def run(device, which=None, log=None):
                 r["traffic"] = _measured_traffic(name, row)
                 if r["traffic"] is not None:
                     r["traffic_profile"] = CONFIGS_TRAFFIC_PROFILE
+                c = _sq_counters(row)
+                if c is not None:      # what a row below the HBM roof is busy with (fractions of its wave cycles)
+                    r["sq_counters"] = c
         except Exception as e:      # a secondary block must never take the headline line down with it
             res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         if log:

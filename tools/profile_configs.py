@@ -59,8 +59,50 @@ def per_launch(dirname, counter, key, grid=None):
     return {"mean": sum(v) / len(v), "launches": len(v), "grid": g, "symbols": sorted(names)[:3]}
 
 
+SQ_SETS = ["SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY",
+           "SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_LDS SQ_INSTS_LDS"]
+
+
+def sq_counters(tag):
+    """`--sq`: wave-level SQ counters of every row of `configs.kernels` (what a kernel below the HBM roof is busy with):
+    profiles/<tag>_kernels_sq_counters.json."""
+    out = os.path.join(ROOT, "gpurun_out", "prof_%s_configs" % tag)
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(ROOT, "flowconductor_amd", "csrc", "libflowcon_hip.so")
+    env = dict(os.environ, TMPDIR="/tmp")
+    acc = {}
+    for i, cset in enumerate(SQ_SETS):
+        d = os.path.join(out, "kernels_sq%d" % i)
+        cmd = ["rocprofv3", "--pmc"] + cset.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                                                          sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "kernels"]
+        with open(os.path.join(out, "kernels_sq%d.log" % i), "w") as log:
+            rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT).returncode
+        print("[profile_configs] kernels sq set %d rc=%d" % (i, rc), flush=True)
+        for row, key in KERNELS["kernels"].items():
+            for counter in cset.split():
+                r = per_launch(d, counter, key)
+                if r:
+                    acc.setdefault(row, {"kernel": key})[counter] = r["mean"]
+    for row, v in acc.items():
+        wc = v.get("SQ_WAVE_CYCLES")
+        if wc:
+            v["valu_active_frac_of_wave_cycles"] = v.get("SQ_ACTIVE_INST_VALU", 0.0) / wc
+            v["wait_memory_frac_of_wave_cycles"] = v.get("SQ_WAIT_ANY", 0.0) / wc
+            v["wait_issue_frac_of_wave_cycles"] = v.get("SQ_WAIT_INST_ANY", 0.0) / wc
+    res = {"tag": tag, "library": {"path": "flowconductor_amd/csrc/libflowcon_hip.so", "sha256": sha256(lib)},
+           "source": "tools/profile_configs.py --sq: rocprofv3 --pmc passes of tools/bench_configs.py kernels; per-launch means over the "
+                     "launches of the largest grid of each kernel symbol (rows that share a symbol and a grid share their numbers); "
+                     "SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles", "kernels": acc}
+    for dst in (os.path.join(ROOT, "profiles"), os.path.join(ROOT, "gpurun_out", "profiles_%s" % tag)):
+        os.makedirs(dst, exist_ok=True)
+        json.dump(res, open(os.path.join(dst, "%s_kernels_sq_counters.json" % tag), "w"), indent=1)
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk.endswith("wave_cycles")} for k, v in acc.items()}))
+
+
 def main():
     tag = sys.argv[1]
+    if "--sq" in sys.argv:
+        return sq_counters(tag)
     which = sys.argv[2:] or list(KERNELS)
     out = os.path.join(ROOT, "gpurun_out", "prof_%s_configs" % tag)
     os.makedirs(out, exist_ok=True)
