@@ -19,6 +19,7 @@
 // hidden <= 64 (zero-padded), <= 3 residual blocks, ReLU, D <= 64, no context, P <= 48 parameters per dim.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "fc_device.h"
 #include "fc_lane.h"
 #include "fc_math.h"
@@ -46,15 +47,18 @@ struct MadeInvArgs {
   const float* fun;         // [D] 2^-S of each dim's rows
   const float* fbias;       // [D][16 PT]
   uint32_t* err;
+  const int32_t* need;      // [D] hidden units pass d reads (a prefix of the packed unit order), or null: all 64
   int64_t blocks16;
   int D, P, accumulate;
 };
 
-// kind: 0 = affine (P = 2: unconstrained scale, shift), 1 = rational-quadratic spline
+// kind: 0 = affine (P = 2: unconstrained scale, shift), 1 = rational-quadratic spline with a run-time bin count (parameters read
+// from the strip as they are needed), 8 / 10 = the same with K = 8 / 10 bins fixed at compile time: the lane copies its 3K -/+ 1
+// parameters from its strip and runs the unrolled evaluation of the stand-alone kernels (RQOp<K>::eval_core, two-sided knot walk)
 // BPW: 16-row blocks a wave carries together -- every pass is a serial chain (five layers, each row maximum -> split ->
 // products -> bias), so a second, independent block fills its waits, and each weight fragment read from LDS serves both
 template <int NB, int K0S, int PT, int kKind, int BPW>
-__global__ __launch_bounds__(kMiThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void made_inverse_kernel(MadeInvArgs a, RQOp<0> op) {
+__global__ __launch_bounds__(kMiThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void made_inverse_kernel(MadeInvArgs a, RQOp<(kKind > 1 ? kKind : 0)> op) {
   constexpr int kLayers = 1 + 2 * NB, kMiPS = mi_strip_row(PT);
   constexpr int kFrag0 = K0S * 4 * 2, kFragL = 2 * 4 * 2, kFrags = kFrag0 + 2 * NB * kFragL;
   extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
@@ -75,76 +79,78 @@ __global__ __launch_bounds__(kMiThreads) __attribute__((amdgpu_waves_per_eu(2, 2
   __syncthreads();
   float* strip = strips + (size_t)wave * BPW * 16 * kMiPS;
 
-  // B operand of one layer from this lane's 16 activations v[t][r] (k = 32 (t >> 1) + 8 g + 4 (t & 1) + r): row maximum
-  // over the sample's four lanes, power-of-two scale, two f16 pieces
-  auto make_operand = [&](const f32x4 (&v)[4], f16x8 (&bh)[2], f16x8 (&bl)[2]) {
+  // B operand of one layer from this lane's activations v[t][r], t < NT (k = 32 (t >> 1) + 8 g + 4 (t & 1) + r; the
+  // tiles beyond NT count as zero): row maximum over the sample's four lanes, power-of-two scale, two f16 pieces
+  auto make_operand = [&](auto nt_c, const f32x4 (&v)[4], f16x8 (&bh)[2], f16x8 (&bl)[2]) {
+    constexpr int NT = decltype(nt_c)::value;
     float m = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) m = fmaxf(m, fabsf(v[t][r]));
     m = rows4_allmax(m, lane);
     float sc, un;
     pow2_scale(m, sc, un);
-    u32x4 hh[2], ll[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int ks = 0; ks < (NT + 1) / 2; ++ks) {
+      u32x4 hh, ll;
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        uint32_t ph, pl;
-        split2_pair(v[t][2 * p], v[t][2 * p + 1], sc, ph, pl);
-        hh[t >> 1][2 * (t & 1) + p] = ph;
-        ll[t >> 1][2 * (t & 1) + p] = pl;
+      for (int q = 0; q < 4; ++q) {
+        uint32_t ph = 0, pl = 0;
+        if (2 * ks + (q >> 1) < NT) split2_pair(v[2 * ks + (q >> 1)][2 * (q & 1)], v[2 * ks + (q >> 1)][2 * (q & 1) + 1], sc, ph, pl);
+        hh[q] = ph;
+        ll[q] = pl;
       }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bh[ks] = __builtin_bit_cast(f16x8, hh[ks]);
-      bl[ks] = __builtin_bit_cast(f16x8, ll[ks]);
+      bh[ks] = __builtin_bit_cast(f16x8, hh);
+      bl[ks] = __builtin_bit_cast(f16x8, ll);
     }
     return un;
   };
-  auto layer = [&](int base, int nks, const f16x8 (&bh)[BPW][2], const f16x8 (&bl)[BPW][2], f32x4 (&acc)[BPW][4]) {
+  // a layer's products: NKS k-steps of the operand, the first NTS 16-unit tiles of the outputs
+  auto layer = [&](auto nts_c, auto nks_c, int base, const f16x8 (&bh)[BPW][2], const f16x8 (&bl)[BPW][2], f32x4 (&acc)[BPW][4]) {
+    constexpr int NTS = decltype(nts_c)::value, NKS = decltype(nks_c)::value;
 #pragma unroll
     for (int b = 0; b < BPW; ++b)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NTS; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f16x8* wf = wfrag + base * 64 + lane;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      if (ks < nks) {
-        f16x8 wl[4], wh[4];
+    for (int ks = 0; ks < NKS; ++ks) {
+      f16x8 wl[NTS], wh[NTS];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          wl[t] = wf[((ks * 4 + t) * 2 + 1) * 64];
-          wh[t] = wf[((ks * 4 + t) * 2 + 0) * 64];
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int b = 0; b < BPW; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh[b][ks], acc[b][t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int b = 0; b < BPW; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl[b][ks], acc[b][t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int b = 0; b < BPW; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh[b][ks], acc[b][t], 0, 0, 0);
+      for (int t = 0; t < NTS; ++t) {
+        wl[t] = wf[((ks * 4 + t) * 2 + 1) * 64];
+        wh[t] = wf[((ks * 4 + t) * 2 + 0) * 64];
       }
+#pragma unroll
+      for (int t = 0; t < NTS; ++t)
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh[b][ks], acc[b][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NTS; ++t)
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl[b][ks], acc[b][t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NTS; ++t)
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh[b][ks], acc[b][t], 0, 0, 0);
+    }
   };
-  auto finish = [&](int l, float un_act, const f32x4 (&acc)[4], f32x4 (&out)[4]) {
+  auto finish = [&](auto nts_c, int l, float un_act, const f32x4 (&acc)[4], f32x4 (&out)[4]) {
+    constexpr int NTS = decltype(nts_c)::value;
     const float c = un_act * wun[l];
     const f32x4* bsrc = reinterpret_cast<const f32x4*>(bias + l * 64 + g * 16);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NTS; ++t) {
       const f32x4 b = bsrc[t];
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[t][r] = __builtin_fmaf(acc[t][r], c, b[r]);
     }
   };
-  auto relu16 = [&](const f32x4 (&in)[4], f32x4 (&out)[4]) {
+  auto relu_tiles = [&](auto nts_c, const f32x4 (&in)[4], f32x4 (&out)[4]) {
+    constexpr int NTS = decltype(nts_c)::value;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NTS; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[t][r] = fmaxf(in[t][r], 0.f);
   };
@@ -190,54 +196,68 @@ __global__ __launch_bounds__(kMiThreads) __attribute__((amdgpu_waves_per_eu(2, 2
           }
       }
       const float f_un = a.fun[d];
-      // ---- hidden stack (fc_resnet_hidden.hip's dataflow)
-      f16x8 bh[BPW][2], bl[BPW][2];
-      f32x4 acc[BPW][4], h[BPW][4], tmid[BPW][4];
-      float un[BPW];
-      FC_EACH_BLOCK un[b] = make_operand(xin[b], bh[b], bl[b]);
-      layer(0, K0S, bh, bl, acc);
-      FC_EACH_BLOCK finish(0, un[b], acc[b], h[b]);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        FC_EACH_BLOCK {
-          f32x4 act[4];
-          relu16(h[b], act);
-          un[b] = make_operand(act, bh[b], bl[b]);
-        }
-        layer(kFrag0 + (2 * nb) * kFragL, 2, bh, bl, acc);
-        FC_EACH_BLOCK {
-          f32x4 act[4];
-          finish(1 + 2 * nb, un[b], acc[b], tmid[b]);
-          relu16(tmid[b], act);
-          un[b] = make_operand(act, bh[b], bl[b]);
-        }
-        layer(kFrag0 + (2 * nb + 1) * kFragL, 2, bh, bl, acc);
-        FC_EACH_BLOCK {
-          finish(2 + 2 * nb, un[b], acc[b], tmid[b]);
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[b][t][r] += tmid[b][t][r];
-        }
-      }
-      // ---- the P final-layer rows of dim d (no activation in front: made.py:281)
-      FC_EACH_BLOCK un[b] = make_operand(h[b], bh[b], bl[b]);
+      // pass d reads `units` hidden units (the packed order puts them first) and the d columns found so far
+      const int units = a.need ? __builtin_amdgcn_readfirstlane(a.need[d]) : 64;
+      // ---- hidden stack (fc_resnet_hidden.hip's dataflow) on the first NTS 16-unit tiles, then the P final-layer rows of
+      // dim d (no activation in front: made.py:281); one copy of the code per tile count, the pass picks its own
       f32x4 pacc[BPW][PT];
+      float un[BPW];
       FC_EACH_BLOCK {
+        un[b] = 0.f;
 #pragma unroll
         for (int t = 0; t < PT; ++t) pacc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+      auto stack = [&](auto nts_c) {
+        constexpr int NTS = decltype(nts_c)::value, NKS = (NTS + 1) / 2;
+        const std::integral_constant<int, NKS> nks_c;
+        f16x8 bh[BPW][2], bl[BPW][2];
+        f32x4 acc[BPW][4], h[BPW][4], tmid[BPW][4];
+        FC_EACH_BLOCK un[b] = make_operand(std::integral_constant<int, 2 * K0S>{}, xin[b], bh[b], bl[b]);
+        layer(nts_c, std::integral_constant<int, K0S>{}, 0, bh, bl, acc);
+        FC_EACH_BLOCK finish(nts_c, 0, un[b], acc[b], h[b]);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+        for (int nb = 0; nb < NB; ++nb) {
+          FC_EACH_BLOCK {
+            f32x4 act[4];
+            relu_tiles(nts_c, h[b], act);
+            un[b] = make_operand(nts_c, act, bh[b], bl[b]);
+          }
+          layer(nts_c, nks_c, kFrag0 + (2 * nb) * kFragL, bh, bl, acc);
+          FC_EACH_BLOCK {
+            f32x4 act[4];
+            finish(nts_c, 1 + 2 * nb, un[b], acc[b], tmid[b]);
+            relu_tiles(nts_c, tmid[b], act);
+            un[b] = make_operand(nts_c, act, bh[b], bl[b]);
+          }
+          layer(nts_c, nks_c, kFrag0 + (2 * nb + 1) * kFragL, bh, bl, acc);
+          FC_EACH_BLOCK {
+            finish(nts_c, 2 + 2 * nb, un[b], acc[b], tmid[b]);
 #pragma unroll
-        for (int t = 0; t < PT; ++t)
-          FC_EACH_BLOCK pacc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks][t], bh[b][ks], pacc[b][t], 0, 0, 0);
+            for (int t = 0; t < NTS; ++t)
 #pragma unroll
-        for (int t = 0; t < PT; ++t)
-          FC_EACH_BLOCK pacc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks][t], bl[b][ks], pacc[b][t], 0, 0, 0);
+              for (int r = 0; r < 4; ++r) h[b][t][r] += tmid[b][t][r];
+          }
+        }
+        FC_EACH_BLOCK un[b] = make_operand(nts_c, h[b], bh[b], bl[b]);
 #pragma unroll
-        for (int t = 0; t < PT; ++t)
-          FC_EACH_BLOCK pacc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks][t], bh[b][ks], pacc[b][t], 0, 0, 0);
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+          for (int t = 0; t < PT; ++t)
+            FC_EACH_BLOCK pacc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks][t], bh[b][ks], pacc[b][t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < PT; ++t)
+            FC_EACH_BLOCK pacc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks][t], bl[b][ks], pacc[b][t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < PT; ++t)
+            FC_EACH_BLOCK pacc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks][t], bh[b][ks], pacc[b][t], 0, 0, 0);
+        }
+      };
+      switch ((units + 15) >> 4) {
+        case 0: break;                 // no unit feeds this dim (dim 0): its parameters are the final layer's biases
+        case 1: stack(std::integral_constant<int, 1>{}); break;
+        case 2: stack(std::integral_constant<int, 2>{}); break;
+        case 3: stack(std::integral_constant<int, 3>{}); break;
+        default: stack(std::integral_constant<int, 4>{}); break;
       }
       // lane (s, g) holds parameters 16 t + 4 g + r of sample s: into the strip, one lane per sample reads them back
       {
@@ -269,7 +289,8 @@ __global__ __launch_bounds__(kMiThreads) __attribute__((amdgpu_waves_per_eu(2, 2
           yv = div_lean(zmine - p[1], sc);
           ladv = -log_lean(sc);
         } else {
-          op.template eval_core<false>(p, zmine, yv, ladv, err);
+          static_assert(kKind == 1 || PT == 2, "3K -/+ 1 parameters in two 16-row tiles");
+          op.template eval_core<false>(p, zmine, yv, ladv, err);     // K static (8 / 10): the unrolled two-sided walk on the strip
         }
 #pragma unroll
         for (int b = 0; b < BPW; ++b) lad_sum[b] += g == b ? ladv : 0.f;
@@ -319,7 +340,11 @@ hipError_t launch_made_inverse_bpw(const MadeInvArgs& a, const RQOp<0>& op, hipS
   int64_t grid = device_cu_count();
   const int64_t need = ((a.blocks16 + BPW - 1) / BPW + 7) / 8;
   if (grid > need) grid = need;
-  hipLaunchKernelGGL((made_inverse_kernel<NB, K0S, PT, kKind, BPW>), dim3((unsigned)grid), dim3(kMiThreads), lds, s, a, op);
+  RQOp<(kKind > 1 ? kKind : 0)> opk;       // same fields; the static-K form is the type the unrolled evaluation is written on
+  opk.q = op.q;
+  opk.inv_beta = op.inv_beta;
+  opk.inv_div = op.inv_div;
+  hipLaunchKernelGGL((made_inverse_kernel<NB, K0S, PT, kKind, BPW>), dim3((unsigned)grid), dim3(kMiThreads), lds, s, a, opk);
   return hipGetLastError();
 }
 
@@ -336,6 +361,8 @@ template <int NB, int K0S>
 hipError_t dispatch_made_inverse_pt(const MadeInvArgs& a, const RQOp<0>& op, int kind, hipStream_t s) {
   const int pt = (a.P + 15) / 16;
   if (kind == 0) return launch_made_inverse<NB, K0S, 1, 0>(a, op, s);
+  if (op.q.K == 8) return launch_made_inverse<NB, K0S, 2, 8>(a, op, s);        // 23 / 25 parameters per dim
+  if (op.q.K == 10) return launch_made_inverse<NB, K0S, 2, 10>(a, op, s);      // 29 / 31 (the reference's default bin count)
   switch (pt) {
     case 1: return launch_made_inverse<NB, K0S, 1, 1>(a, op, s);
     case 2: return launch_made_inverse<NB, K0S, 2, 1>(a, op, s);
@@ -348,7 +375,8 @@ hipError_t dispatch_made_inverse_pt(const MadeInvArgs& a, const RQOp<0>& op, int
 
 extern "C" int fc_made_inverse(const float* z, float* y, float* logabsdet, const void* hidden_frag,
                                const float* hidden_unscale, const float* hidden_bias, const void* final_frag,
-                               const float* final_unscale, const float* final_bias, uint32_t* err_flag, int64_t n,
+                               const float* final_unscale, const float* final_bias, const int32_t* units_needed,
+                               uint32_t* err_flag, int64_t n,
                                int32_t d, int32_t num_blocks, int32_t params_per_dim, int32_t kind,
                                const fc_rq_config* cfg, void* stream) {
   if (n < 0 || d < 1 || d > 64 || num_blocks < 0 || num_blocks > 3 || kind < 0 || kind > 1) return hipErrorInvalidValue;
@@ -375,7 +403,7 @@ extern "C" int fc_made_inverse(const float* z, float* y, float* logabsdet, const
     op.inv_beta = 1.f / q.beta;
   }
   fc::MadeInvArgs a{z, y, logabsdet, static_cast<const fc::f16x8*>(hidden_frag), hidden_unscale, hidden_bias,
-                    static_cast<const fc::f16x8*>(final_frag), final_unscale, final_bias, err_flag, n / 16, d, params_per_dim,
+                    static_cast<const fc::f16x8*>(final_frag), final_unscale, final_bias, err_flag, units_needed, n / 16, d, params_per_dim,
                     (cfg && (cfg->flags & FC_RQ_ACCUMULATE_LOGABSDET)) ? 1 : 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool wide = d > 32;

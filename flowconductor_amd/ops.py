@@ -835,12 +835,36 @@ def device_pack_made_affine(made, features):
 MADE_AFFINE, MADE_RQ = 0, 1
 
 
+def _made_pass_prefix(made, features, per_dim, hw):
+    """Which hidden units pass d of the inverse reads, from the masks alone: the units the rows of dim d reach backwards
+    through the hidden layers (and the residual identities).  Returns ``(order, need)``: ``order[rank]`` = hidden unit, sorted
+    by the first pass that reads it (zero-padded units last), and ``need[d]`` = how many leading units of that order pass d
+    reads -- for the reference's degrees (made.py:13-24: unit j has degree j % (D - 1) + 1) the units of degree <= d."""
+    hidden = [lin for block in made.blocks for lin in block.linear_layers]
+    step = torch.eye(hw, dtype=torch.bool)
+    for lin in hidden:
+        step |= _pad_to((lin.mask != 0).cpu(), (hw, hw))                     # [unit, the units it reads]
+    reach = _pad_to((made.final_layer.mask != 0).cpu().reshape(features, per_dim, -1).any(dim=1), (features, hw))
+    while True:
+        wider = reach | ((reach.float() @ step.float()) > 0)
+        if bool((wider == reach).all()):
+            break
+        reach = wider
+    dims = torch.arange(features).reshape(-1, 1).expand(features, hw)
+    first = torch.where(reach, dims, torch.full_like(dims, features)).amin(dim=0)      # [hw]; `features` = never read
+    order = torch.argsort(first, stable=True)
+    need = (first.reshape(1, -1) <= torch.arange(features).reshape(-1, 1)).sum(dim=1).to(torch.int32)
+    return order, need
+
+
 def pack_made_inverse(made, features, per_dim):
     """Everything ``fc_made_inverse`` needs of a residual-block MADE (hidden <= 64, <= 3 blocks, <= 64 inputs): the hidden
     stack's image on MASKED weights (rows in the accumulator order of the hidden-layer kernels, one power-of-two scale per
     layer) and the final layer as per-dim row tiles (``per_dim`` parameter rows of every dim padded to whole 16-row tiles,
-    one scale per dim).  Returns ``(hidden_frag, hidden_unscale [L], hidden_bias [L, 64], final_frag, final_unscale [D],
-    final_bias [D, 16 PT])``."""
+    one scale per dim).  The hidden units are renumbered in the order the passes first read them (``_made_pass_prefix``:
+    the same renumbering in every layer, so the residual sums stay unit-for-unit), which lets pass d compute only the
+    leading 16-unit tiles / 32-unit k-steps that hold its ``units_needed[d]`` units.  Returns ``(hidden_frag,
+    hidden_unscale [L], hidden_bias [L, 64], final_frag, final_unscale [D], final_bias [D, 16 PT], units_needed [D])``."""
     hw = 64
     dev = made.initial_layer.weight.device
     perm = _hb_perm().to(dev)
@@ -848,21 +872,36 @@ def pack_made_inverse(made, features, per_dim):
     layers = [made.initial_layer] + [lin for block in made.blocks for lin in block.linear_layers]
     wf, uns, biases = [], [], []
     with torch.no_grad():
+        order, need = _made_pass_prefix(made, features, per_dim, hw)
+        order = order.to(dev)
+        # rank r sits where the accumulator layout keeps feature perm[r]: ranks 0..15 fill product tile 0, 16..31 tile 1
+        # (both in k-step 0), 32..47 tile 2, 48..63 tile 3 (k-step 1)
+        slot = perm
         for i, lin in enumerate(layers):
             w = _pad_to((lin.weight * lin.mask).detach().float(), (hw, 32 * k0s if i == 0 else hw))
-            sc, un = _pow2_scale(w.abs().amax().reshape(1))
+            moved = torch.zeros_like(w)
+            if i == 0:
+                moved[slot] = w[order]
+            else:
+                moved[slot.reshape(-1, 1), slot.reshape(1, -1)] = w[order.reshape(-1, 1), order.reshape(1, -1)]
+            sc, un = _pow2_scale(moved.abs().amax().reshape(1))
             uns.append(un)
-            wf.append(_a_fragments((w * sc)[perm]).permute(1, 0, 2, 3, 4).reshape(-1))            # [ks][t][piece][lane][8]
-            biases.append(_pad_to(lin.bias.detach().float(), (hw,))[perm].reshape(4, 4, 4).permute(1, 0, 2).reshape(-1))
+            wf.append(_a_fragments((moved * sc)[perm]).permute(1, 0, 2, 3, 4).reshape(-1))        # [ks][t][piece][lane][8]
+            b = torch.zeros(hw, device=dev)
+            b[slot] = _pad_to(lin.bias.detach().float(), (hw,))[order]
+            biases.append(b[perm].reshape(4, 4, 4).permute(1, 0, 2).reshape(-1))
         final = made.final_layer
         pt = -(-per_dim // 16)
         w = _pad_to((final.weight * final.mask).detach().float().reshape(features, per_dim, -1), (features, 16 * pt, hw))
+        moved = torch.zeros_like(w)
+        moved[:, :, slot] = w[:, :, order]
+        w = moved
         sc, un = _pow2_scale(w.abs().amax(dim=(1, 2)))
         frag = _a_fragments((w * sc.reshape(-1, 1, 1)).reshape(features * 16 * pt, hw))           # [D PT, ks, piece, lane, 8]
         final_frag = frag.reshape(features, pt, 2, 2, 64, 8).permute(0, 2, 1, 3, 4, 5).contiguous()   # [D][ks][t][piece][lane][8]
         final_bias = _pad_to(final.bias.detach().float().reshape(features, per_dim), (features, 16 * pt)).contiguous()
     return (torch.cat(wf).contiguous(), torch.cat(uns).float().contiguous(), torch.stack(biases).contiguous(),
-            final_frag, un.float().contiguous(), final_bias)
+            final_frag, un.float().contiguous(), final_bias, need.to(dev).contiguous())
 
 
 def made_inverse(inputs, packed, num_blocks, per_dim, kind, rq=None, logabsdet_accum=None):
@@ -896,9 +935,11 @@ def made_inverse(inputs, packed, num_blocks, per_dim, kind, rq=None, logabsdet_a
     else:
         lad = torch.empty(n, dtype=torch.float32, device=z.device)
     err = _err_word(z.device, True)
-    hf, hu, hb, ff, fu, fb = packed
+    hf, hu, hb, ff, fu, fb, need = packed
+    if need.dtype != torch.int32 or need.numel() != d:
+        raise ValueError("made_inverse: units_needed must hold one int32 per dim")
     _call("fc_made_inverse", lib.fc_made_inverse, z.device, _hip.ptr(z), _hip.ptr(y), _hip.ptr(lad), _hip.ptr(hf),
-          _hip.ptr(hu), _hip.ptr(hb), _hip.ptr(ff), _hip.ptr(fu), _hip.ptr(fb), _hip.ptr(err), n, d, num_blocks, per_dim,
+          _hip.ptr(hu), _hip.ptr(hb), _hip.ptr(ff), _hip.ptr(fu), _hip.ptr(fb), _hip.ptr(need), _hip.ptr(err), n, d, num_blocks, per_dim,
           kind, cfg, _hip.stream_ptr(z.device))
     _finish(True)
     return y, lad

@@ -140,12 +140,16 @@ int fc_rq_fused_linear_backward(int32_t role, const float* x, const float* h, co
  *   final_unscale [d] = 2^-S_dim; final_bias [d][16 PT].
  *   kind FC_MADE_AFFINE (params_per_dim 2: unconstrained scale, shift -- autoregressive.py:97-129; cfg may be NULL) or
  *   FC_MADE_RQ (cfg: the spline, any K <= 16 and tail mode, autoregressive.py:529-621; cfg->inverse is ignored).
+ *   units_needed [d] or NULL: pass c reads only the first units_needed[c] hidden units (in feature order 0..63 of EVERY
+ *   hidden layer: the caller renumbers the units so that each pass's units form a prefix -- for the reference's degrees,
+ *   made.py:13-24, the units of degree <= c) and the kernel computes just the 16-unit product tiles and 32-unit k-steps
+ *   that hold them; the other units may then hold any finite value (they meet zeroed weights only).  NULL: all 64.
  *   err_flag: FC_ERR_* bits of the spline inverse. */
 #define FC_MADE_AFFINE 0
 #define FC_MADE_RQ 1
 int fc_made_inverse(const float* z, float* y, float* logabsdet, const void* hidden_frag, const float* hidden_unscale,
                     const float* hidden_bias, const void* final_frag, const float* final_unscale, const float* final_bias,
-                    uint32_t* err_flag, int64_t n, int32_t d, int32_t num_blocks, int32_t params_per_dim, int32_t kind,
+                    const int32_t* units_needed, uint32_t* err_flag, int64_t n, int32_t d, int32_t num_blocks, int32_t params_per_dim, int32_t kind,
                     const fc_rq_config* cfg, void* stream);
 
 /* Backward of fc_affine in the forward direction, per-sample parameters (coupling.py:234-252,
