@@ -2,7 +2,7 @@
 //
 // v_mfma_f32_*_f32 (f32 in, f32 out) runs at the f32 VALU rate and does not overlap with VALU work; the
 // 16-bit matrix pipe is 16x faster.  A value x, scaled by a power of two so that the maximum of its row
-// sits in [2^10, 2^11), is split as x = xh + xl + e, xh = f16(x), xl = f16(x - xh), |e| <= 2^-22 max|x|;
+// sits in [2^14, 2^15), is split as x = xh + xl + e, xh = f16(x), xl = f16(x - xh), |e| <= 2^-22 max|x|;
 // a product sum a.b is taken as  al.bh + ah.bl + ah.bh  (the al.bl term, <= 2^-22 |a||b|, is dropped),
 // three f16 MFMAs accumulating in f32.  Against float64 the error of a 64-term product is max 1.7e-7 /
 // rms 2.2e-8 of sum|a||b|; an f32 GEMM's own rounding is 4.1e-7 / 3.4e-8 (tools/probe/split_accuracy.py).
@@ -18,13 +18,20 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// Power-of-two scale that lifts m = max|x| into [2^10, 2^11), and its inverse.  Tiny or zero maxima are left
-// alone (their pieces underflow to an absolute error far below f32 resolution of any O(1) result).
+// Power-of-two scale that lifts m = max|x| into [2^14, 2^15) (f16 tops out at 65504), and its inverse.  Tiny or zero
+// maxima are left alone (their pieces underflow to an absolute error far below f32 resolution of any O(1) result).
+// Why the top of the range: the two pieces carry 22 bits of a value as long as its low piece stays above f16's subnormal
+// quantum 2^-24, i.e. down to values 2^16 times smaller than the row maximum (one bit less per further factor of two).
+// Dense products do not care (the large entry dominates the sum anyway), MASKED ones do: a MADE unit that only reads the
+// small columns of a row must see them at full precision beside a large column it does not read (rounds 1-3 lifted the
+// maximum to [2^10, 2^11): full precision only down to 2^12 below it -- tools/probe/fuzz_ar_inverse.py found rows of an
+// affine autoregressive inverse, |y| up to 8e3 beside O(1) columns, 4e-3 off).
+constexpr uint32_t kSplitTopExp = 14;
 __device__ __forceinline__ void pow2_scale(float m, float& scale, float& unscale) {
   const uint32_t e = (__float_as_uint(m) >> 23) & 255u;      // biased exponent, floor(log2 m) = e - 127
-  const bool ok = e >= 11u && e < 255u;
-  scale = ok ? __uint_as_float((264u - e) << 23) : 1.f;       // 2^(10 - (e - 127))
-  unscale = ok ? __uint_as_float((e - 10u) << 23) : 1.f;
+  const bool ok = e > kSplitTopExp && e < 255u;
+  scale = ok ? __uint_as_float((254u + kSplitTopExp - e) << 23) : 1.f;       // 2^(14 - (e - 127))
+  unscale = ok ? __uint_as_float((e - kSplitTopExp) << 23) : 1.f;
 }
 
 // x = h + l (+ residual <= 2^-22 |x|) with f16 pieces, round-to-nearest-even; the difference is exact in f32

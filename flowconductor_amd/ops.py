@@ -536,10 +536,10 @@ def _exact_pow2(shift):
 
 
 def _pow2_scale(m):
-    """fc_split.h pow2_scale on a tensor of maxima: (scale, unscale), exact powers of two lifting each into [2^10, 2^11)."""
+    """fc_split.h pow2_scale on a tensor of maxima: (scale, unscale), exact powers of two lifting each into [2^14, 2^15)."""
     _, exp = torch.frexp(m)                                   # m = mant * 2^exp, mant in [0.5, 1)
-    ok = (m > 0) & torch.isfinite(m) & (exp >= -115)
-    shift = torch.where(ok, 11 - exp, torch.zeros_like(exp))
+    ok = (m > 0) & torch.isfinite(m) & (exp >= -111)
+    shift = torch.where(ok, 15 - exp, torch.zeros_like(exp))
     return _exact_pow2(shift), _exact_pow2(-shift)
 
 

@@ -85,10 +85,18 @@ class AutoregressiveTransform(Transform):
         num_inputs = int(np.prod(inputs.shape[1:]))
         outputs = torch.zeros_like(inputs)
         logabsdet = None
+        # Pass p fixes column p (autoregressive.py:44-53); what it leaves in the later columns is the inverse under parameters
+        # made from unfinished inputs -- harmless for the reference, whose masked GEMMs multiply it by exact zeros, but the
+        # hidden-layer kernel scales every ROW by its maximum before the f16 split, and with an affine form those values can
+        # grow by 1 / scale per pass and drown the finished columns.  They are never read again by a dim that is kept, so
+        # they go back to zero (2-D inputs: the column order is the feature order).
+        clear_rest = inputs.dim() == 2 and not self._needs_grad(inputs)
         with ops.deferred_errors():
-            for _ in range(num_inputs):
+            for p in range(num_inputs):
                 autoregressive_params = self._conditioner(outputs, context)
                 outputs, logabsdet = self._elementwise_inverse(inputs, autoregressive_params)
+                if clear_rest and p + 1 < num_inputs:
+                    outputs[:, p + 1:] = 0
         return outputs, logabsdet
 
     # ---- the D passes on the device (round 4) -----------------------------------------------------------------------

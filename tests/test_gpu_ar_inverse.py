@@ -282,3 +282,27 @@ def test_device_loop_steps_aside(device):
     assert not t._device_loop_ok(x, None)                     # parameters require gradients, autograd on
     with torch.no_grad():
         assert t._device_loop_ok(x, None)
+
+
+@pytest.mark.parametrize("features,hidden,blocks", [(8, 64, 2), (64, 64, 2), (33, 40, 3), (5, 24, 1)])
+def test_device_loop_prefix_passes_equal_whole_passes(features, hidden, blocks, device):
+    """units_needed (each pass computes the leading hidden units it reads) against the same kernel computing all 64 units
+    in every pass: the skipped units only meet zeroed weights, so the rows agree to the rounding of the row scales."""
+    from flowconductor_amd import ops
+
+    torch.manual_seed(features)
+    t = _rq(features, hidden, 8, "linear", blocks=blocks).to(device).eval()
+    kind, per_dim, rq = t._device_loop_form()
+    assert kind == ops.MADE_RQ and per_dim == 23
+    z = torch.randn(4096 + 16, features, device=device)
+    with torch.no_grad():
+        packed = ops.pack_made_inverse(t.autoregressive_net, features, per_dim)
+        need = packed[-1]
+        assert int(need[0]) == 0 and int(need.max()) <= hidden and bool((need[1:] >= need[:-1]).all())
+        y, lad = ops.made_inverse(z, packed, blocks, per_dim, kind, rq)
+        whole = packed[:-1] + (torch.full_like(need, 64),)
+        y_all, lad_all = ops.made_inverse(z, whole, blocks, per_dim, kind, rq)
+        y_t, lad_t = t.inverse(z)
+    assert maxdiff(y, y_all) <= 2e-6 * max(1.0, float(y_all.abs().max()))
+    assert maxdiff(lad, lad_all) <= 2e-5 * max(1.0, float(lad_all.abs().max()) / 10)
+    assert maxdiff(y, y_t) <= 1e-6 and maxdiff(lad, lad_t) <= 1e-5      # (the transform's own call: same kernel, same pack)

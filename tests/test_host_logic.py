@@ -488,3 +488,28 @@ def test_param_list_memo_sees_replaced_parameter_objects():
     net.load_state_dict(sd, assign=True)
     assert net._storage_key() != key
     assert all(a is b for a, b in zip(net._param_list(), net.parameters()))
+
+
+@pytest.mark.parametrize("features,hidden,blocks,per_dim", [(8, 64, 2, 23), (64, 64, 2, 2), (5, 24, 1, 16), (33, 50, 3, 2)])
+def test_made_pass_prefix_follows_the_masks(features, hidden, blocks, per_dim):
+    """fc_made_inverse's units_needed: the renumbering is a permutation, the counts grow with the pass, they are the units
+    of degree <= d for the reference's degrees (made.py:13-24), and no unit inside a pass's prefix reads one outside it."""
+    from flowconductor_amd.transforms.made import MADE
+
+    made = MADE(features, hidden, num_blocks=blocks, output_multiplier=per_dim)
+    order, need = ops._made_pass_prefix(made, features, per_dim, 64)
+    assert sorted(order.tolist()) == list(range(64))
+    need = need.tolist()
+    assert need == sorted(need) and need[0] == 0 and need[-1] <= hidden
+    degrees = torch.arange(hidden) % max(1, features - 1) + min(1, features - 1)
+    assert need == [int((degrees <= d).sum()) for d in range(features)]
+    rank = torch.empty(64, dtype=torch.long)
+    rank[order] = torch.arange(64)
+    for lin in [l for b in made.blocks for l in b.linear_layers]:
+        reads = (lin.mask != 0).nonzero()
+        for d in range(features):
+            inside = rank[reads[:, 0]] < need[d]
+            assert bool((rank[reads[inside, 1]] < need[d]).all())
+    final = (made.final_layer.mask != 0).reshape(features, per_dim, -1).any(dim=1)
+    for d in range(features):
+        assert bool((rank[final[d].nonzero().reshape(-1)] < need[d]).all())
