@@ -34,6 +34,9 @@ namespace fc {
 #ifndef FC_B5_WRES
 #define FC_B5_WRES 1     // 1: the group's forward fragments resident in registers for the whole sweep (8 T registers); 0: streamed per tile
 #endif
+#ifndef FC_B5_MIX_BLOCKS
+#define FC_B5_MIX_BLOCKS 0   // probe: 1 lets the scheduler interleave the two blocks' spline backward, 2 also makes each one basic block
+#endif
 #ifndef FC_B5_PIPE
 #define FC_B5_PIPE 0     // 1: block 1's recompute products inside block 0's (branch-free) spline region with a sched_group_barrier
                          // pipeline.  Measured SLOWER (1.338 vs 1.296 ms per 2^19 rows): hipcc 7.2 still clumps the 36 products at the
@@ -335,7 +338,9 @@ __global__ __launch_bounds__(kB5Threads) void rq_fused_backward512_kernel(RQPara
         float gp[2][PP8];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
+#if !FC_B5_MIX_BLOCKS
           __builtin_amdgcn_sched_barrier(0);     // the two blocks' register-hungry spline code must not interleave
+#endif
           if constexpr (kPipe) {
             if (b == 0) recompute_block(1);      // its 6 T products are spread over this block's vector stream below
           }
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(kB5Threads) void rq_fused_backward512_kernel(RQPara
 #pragma unroll
           for (int i = 0; i < 3 * K + 1; ++i) gpe[i] = p[i % PP] * gyv;
 #else
-          if constexpr (kPipe) rq_backward_element_flat<K, kTails>(q, inv_div, p, xin, gyv, glr, gxv, gpe);
+          if constexpr (kPipe || FC_B5_MIX_BLOCKS == 2) rq_backward_element_flat<K, kTails>(q, inv_div, p, xin, gyv, glr, gxv, gpe);
           else rq_backward_element_fast<K, kTails>(q, inv_div, p, xin, gyv, glr, gxv, gpe);
 #endif
 #pragma unroll
