@@ -716,4 +716,4 @@ def run(device, which=None, log=None):
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     for k, v in run(dev, sys.argv[1:] or None, log=lambda m: print("[bench_configs] " + m, file=sys.stderr)).items():
-        print(json.dumps({k: v}))
+        print(json.dumps({k: v, "library": _hip.library_info()}))

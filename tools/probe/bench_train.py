@@ -13,7 +13,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from flowconductor_amd import distributions, flows, ops, options, transforms, utils  # noqa: E402
+from flowconductor_amd import _hip, distributions, flows, ops, options, transforms, utils  # noqa: E402
 from flowconductor_amd.nn import nets  # noqa: E402
 
 KERNELS = ("fc_rq_spline", "fc_rq_spline_backward", "fc_rq_spline_fused_general", "fc_rq_fused_linear_backward",
@@ -67,10 +67,12 @@ def main():
             res[mode] = rec
     res["rows"] = n
     if "unfused" not in res:
+        res["library"] = _hip.library_info()
         print(json.dumps(res))
         return
     res["speedup"] = res["unfused"]["ms_per_step"] / res["fused"]["ms_per_step"]
     if "--json" in sys.argv:
+        res["library"] = _hip.library_info()
         print(json.dumps(res))
         return
     for mode in ("fused", "unfused"):

@@ -12,6 +12,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT $R/profiles
+touch $OUT/.start          # (the manifest lists what this call writes after this moment)
 STAGES=${STAGES:-"a b"}
 ARGS="--steps 3 --warmup 3 --no-cpu-baseline --no-configs"   # 3 warm-up steps: the first two run 5-10 % slower under the profiler
 if [[ " $STAGES " == *" a "* ]]; then
@@ -46,5 +47,25 @@ bash tools/probe/pmc_kernel.sh $TAG hidden resnet_hidden_kernel > $OUT/pmc_hidde
 python3 bench.py --steps 20 --warmup 5 --strict-profiles > profiles/${TAG}_bench_n1.json 2> $OUT/bench_final.err
 echo "final strict bench exit $?"
 fi
+# the raw rocprofv3 tables cannot carry a field of their own: one manifest names every file of this tag with the library it
+# was taken from (the JSON / text summaries also record it themselves)
+cd $R
+python3 - "$TAG" "$STAGES" "$OUT/.start" <<'PYEOF'
+import glob, hashlib, json, os, sys, time
+tag, stages = sys.argv[1], sys.argv[2]
+lib = "flowconductor_amd/csrc/libflowcon_hip.so"
+sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()
+path = "profiles/%s_manifest.json" % tag
+man = json.load(open(path)) if os.path.exists(path) else {"files": {}}
+if man.get("library", {}).get("sha256") != sha:
+    man = {"files": {}}            # another build: earlier entries no longer describe files of this library
+man["library"] = {"path": lib, "sha256": sha}
+fresh = os.path.getmtime(sys.argv[3])
+for f in sorted(glob.glob("profiles/%s_*" % tag)):
+    if f != path and os.path.getmtime(f) >= fresh:
+        man["files"][os.path.basename(f)] = {"stage": stages, "bytes": os.path.getsize(f)}
+json.dump(man, open(path, "w"), indent=1, sort_keys=True)
+PYEOF
 # gpurun only carries gpurun_out/ back: the judged files travel there too (copy them into profiles/ after the call)
-mkdir -p $R/gpurun_out/profiles_$TAG && cp $R/profiles/${TAG}_* $R/gpurun_out/profiles_$TAG/ 2>/dev/null
+# -- only what this call wrote (older files of the tag travelled here with the snapshot and may belong to another build)
+mkdir -p $R/gpurun_out/profiles_$TAG && find $R/profiles -name "${TAG}_*" -newer $OUT/.start -exec cp {} $R/gpurun_out/profiles_$TAG/ \;
