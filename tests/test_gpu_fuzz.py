@@ -1,4 +1,4 @@
-"""The five random-shape fuzzers of tools/probe/ as tests: each runs in this process (runpy, no child per case) on
+"""The six random-shape fuzzers of tools/probe/ as tests: each runs in this process (runpy, no child per case) on
 fixed seeds with a case count sized so that the whole file stays inside about a minute on the GPU box.  The fuzzers
 compare every kernel family and the fast-path dispatch with the CPU oracle (float64 oracle as the noise floor); in
 round 2 they found both real defects of the round while sitting outside the suite.  Plus the frozen case of
@@ -22,7 +22,8 @@ FUZZERS = [("fuzz_kernels.py", (3, 5, 11), 30),
            ("fuzz_tile_kernels.py", (3, 4, 12), 40),
            ("fuzz_other_kernels.py", (4, 6, 13), 40),
            ("fuzz_flows.py", (3, 5, 21), 16),
-           ("fuzz_backward.py", (1, 12, 17), 20)]
+           ("fuzz_backward.py", (1, 12, 17), 20),
+           ("fuzz_ar_inverse.py", (1, 3), 12)]       # round 4: fc_made_inverse against the float64 oracle and the host loops
 
 
 @pytest.mark.parametrize("script,seed,cases", [(s, seed, c) for s, seeds, c in FUZZERS for seed in seeds])

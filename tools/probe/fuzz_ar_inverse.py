@@ -104,4 +104,6 @@ for c in range(cases):
             r, y[r, :6].tolist(), y_host[r, :6].tolist(), ref_y64[r, :6].tolist(), ref_y[r, :6].tolist()))
 print("fuzz_ar_inverse seed %d: %d cases on the device loop, %d failed, worst err/tol %.2f (%d rows with |y| > 1e3 left out of "
       "the host-loop / forward comparisons)" % (seed, ran, failed, worst, left_out))
-sys.exit(1 if failed else 0)
+if failed:
+    sys.exit(1)
+print("fuzz ok: seed %d, %d device-loop layers" % (seed, ran))
