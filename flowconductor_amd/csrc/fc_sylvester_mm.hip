@@ -17,6 +17,7 @@
 #include "fc_split.h"
 #include "fc_device.h"
 #include "fc_lane.h"
+#include "fc_math.h"
 #include "../../include/flowcon_hip.h"
 
 namespace fc {
@@ -54,11 +55,31 @@ __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
   const int s16 = lane & 15, g = lane >> 4;
 
   // ---- once per workgroup: scale, split and lay out both matrices ------------------------------------
+  // fragment entry e = (ks * NT + t) * 64 + lane': W[feat(t, lane' & 15)][32 ks + 8 (lane' >> 4) + j], j < 8 -- the entries
+  // cover the matrix exactly once, so ONE pass serves both the maximum and the split: a thread keeps its kPer entries (two
+  // 16-byte loads each) in registers across the reduction (round 4; before: one pass for the maximum, a second one with
+  // eight scalar loads per entry -- ~10 us of a 100 us launch)
+  constexpr int kPer = (KS * NT * 64 + kSylThreads - 1) / kSylThreads;
 #pragma unroll
   for (int l = 0; l < (kDense ? 1 : 2); ++l) {
     const float* w = l == 0 ? a.w1 : a.w2;
+    float4 keep[kPer][2];
     float m = 0.f;
-    for (int i = tid; i < F * F; i += kSylThreads) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = tid + i * kSylThreads;
+      keep[i][0] = keep[i][1] = float4{0.f, 0.f, 0.f, 0.f};
+      if (e < KS * NT * 64) {
+        const int ln = e & 63, t = (e >> 6) % NT, ks = (e >> 6) / NT;
+        const int rho = ln & 15, f = syl_feat(t, rho >> 2, rho & 3);
+        const float4* src = reinterpret_cast<const float4*>(w + (size_t)f * F + 32 * ks + 8 * (ln >> 4));
+        keep[i][0] = src[0];
+        keep[i][1] = src[1];
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(keep[i][h].x), fabsf(keep[i][h].y))), fmaxf(fabsf(keep[i][h].z), fabsf(keep[i][h].w)));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     __syncthreads();
@@ -70,21 +91,23 @@ __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
     float sc, un;
     pow2_scale(m, sc, un);
     if (tid == 0) wun[l] = un;
-    // fragment entry e = (ks * NT + t) * 64 + lane': W[feat(t, lane' & 15)][32 ks + 8 (lane' >> 4) + j]
-    for (int e = tid; e < KS * NT * 64; e += kSylThreads) {
-      const int ln = e & 63, t = (e >> 6) % NT, ks = (e >> 6) / NT;
-      const int rho = ln & 15, f = syl_feat(t, rho >> 2, rho & 3);
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+      const int e = tid + i * kSylThreads;
+      if (e >= KS * NT * 64) continue;
+      const float v[8] = {keep[i][0].x, keep[i][0].y, keep[i][0].z, keep[i][0].w,
+                          keep[i][1].x, keep[i][1].y, keep[i][1].z, keep[i][1].w};
       f16x8 hi, lo;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int k = 32 * ks + 8 * (ln >> 4) + j;
         _Float16 ph, pl;
-        split2(w[(size_t)f * F + k] * sc, ph, pl);
+        split2(v[j] * sc, ph, pl);
         hi[j] = ph;
         lo[j] = pl;
       }
-      wfrag[(l * kFragL + (ks * NT + t) * 2 + 0) * 64 + ln] = hi;
-      wfrag[(l * kFragL + (ks * NT + t) * 2 + 1) * 64 + ln] = lo;
+      // (entry e of the [ks][t] grid -> fragment ((ks * NT + t) * 2 + piece), lane e & 63)
+      wfrag[(l * kFragL + (e >> 6) * 2 + 0) * 64 + (e & 63)] = hi;
+      wfrag[(l * kFragL + (e >> 6) * 2 + 1) * 64 + (e & 63)] = lo;
     }
   }
   for (int i = tid; i < 4 * NT * 4; i += kSylThreads) {   // accumulator order: [g][t * 4 + r]
@@ -141,16 +164,26 @@ __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
   };
 
   const int64_t nwaves = (int64_t)gridDim.x * (kSylThreads / 64);
-  for (int64_t blk = (int64_t)blockIdx.x * (kSylThreads / 64) + wave; blk < a.blocks16; blk += nwaves) {
-    asm volatile("" ::: "memory");   // keeps the loop-invariant LDS fragment loads inside the loop
-    // lane (s, g) holds features 32 ks + 8 g + j of sample s: tile 2 ks + (j >> 2), register j & 3
+  // lane (s, g) holds features 32 ks + 8 g + j of sample s: tile 2 ks + (j >> 2), register j & 3
+  auto load_rows = [&](int64_t blk, f32x4 (&dst)[NT]) {
     const float4* xrow = reinterpret_cast<const float4*>(a.x + (blk * 16 + s16) * F);
-    f32x4 z[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const float4 v = xrow[8 * (t >> 1) + 2 * g + (t & 1)];
-      z[t] = f32x4{v.x, v.y, v.z, v.w};
+      dst[t] = f32x4{v.x, v.y, v.z, v.w};
     }
+  };
+  const int64_t blk0 = (int64_t)blockIdx.x * (kSylThreads / 64) + wave;
+  f32x4 znext[NT];
+  if (blk0 < a.blocks16) load_rows(blk0, znext);
+  for (int64_t blk = blk0; blk < a.blocks16; blk += nwaves) {
+    asm volatile("" ::: "memory");   // keeps the loop-invariant LDS fragment loads inside the loop
+    f32x4 z[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) z[t] = znext[t];
+    // the next block's rows are requested now and land behind this block's products (round 4: the wave used to wait for
+    // every block's HBM latency with nothing else in flight)
+    if (blk + nwaves < a.blocks16) load_rows(blk + nwaves, znext);
     f16x8 bh[KS], bl[KS];
     f32x4 acc[NT];
     float un = make_operand(z, bh, bl);
@@ -175,9 +208,12 @@ __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
       const f32x4 b = bsrc[t], rd = rsrc[t];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float act = tanhf(__builtin_fmaf(acc[t][r], c, b[r]));     // tanh(R1 Q^T z + b)
+        // (tanh / log on the lean primitives, one exponential / one v_log each: libm's were ~10 000 vector operations per
+        //  row of 128 features, more than half of the kernel)
+        const float act = tanh_lean(__builtin_fmaf(acc[t][r], c, b[r]));     // tanh(R1 Q^T z + b)
         acc[t][r] = act;
-        lsum += logf(1.f + (1.f - act * act) * rd[r]);                    // planar.py:160-163
+        const float arg = 1.f + (1.f - act * act) * rd[r];
+        lsum += (arg > 0.f && arg < INFINITY) ? log_lean(arg) : logf(arg);   // planar.py:160-163
       }
     }
     un = make_operand(acc, bh, bl);
@@ -215,7 +251,7 @@ extern "C" int fc_sylvester_mm(const float* x, float* y, float* logabsdet, const
   if (n < 0 || d <= 0 || d % 32 != 0 || d > 128 || n % 16 != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
   if (!x || !y || !logabsdet || !w1 || !w2 || !bias || !r_diag_prod) return hipErrorInvalidValue;
-  if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return hipErrorInvalidValue;
+  if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w1 | (uintptr_t)w2) & 15u) != 0) return hipErrorInvalidValue;
   fc::SylArgs a{x, y, logabsdet, w1, w2, bias, r_diag_prod, n / 16};
   const int cus = fc::device_cu_count();
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -232,7 +268,7 @@ extern "C" int fc_dense_mm(const float* x, float* y, const float* w, const float
   if (n < 0 || d <= 0 || d % 32 != 0 || d > 128 || n % 16 != 0) return hipErrorInvalidValue;
   if (n == 0) return hipSuccess;
   if (!x || !y || !w) return hipErrorInvalidValue;
-  if ((((uintptr_t)x | (uintptr_t)y) & 15u) != 0) return hipErrorInvalidValue;
+  if ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w) & 15u) != 0) return hipErrorInvalidValue;
   fc::SylArgs a{x, y, nullptr, w, nullptr, bias, nullptr, n / 16};
   const int cus = fc::device_cu_count();
   hipStream_t s = static_cast<hipStream_t>(stream);

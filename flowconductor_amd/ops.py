@@ -1967,7 +1967,7 @@ def dense_mm(inputs, weight, bias=None):
     n, d = x.shape
     if n % SYLVESTER_MM_ROWS != 0 or not sylvester_mm_supported(n, d):
         raise ValueError("fc_dense_mm: unsupported shape %s" % (tuple(x.shape),))
-    w = _param(weight, x.device, "weight")
+    w = _aligned16(_param(weight, x.device, "weight"))
     if w.shape != (d, d):
         raise ValueError("weight must be [%d, %d]" % (d, d))
     bv = _param(bias, x.device, "bias").reshape(-1) if bias is not None else None
@@ -1986,6 +1986,7 @@ def sylvester_mm(inputs, w1, w2, bias, rdiag):
     if n % SYLVESTER_MM_ROWS != 0 or not sylvester_mm_supported(n, d):
         raise ValueError("fc_sylvester_mm: unsupported shape %s" % (tuple(x.shape),))
     bv = _param(bias, x.device, "bias")
+    w1, w2 = _aligned16(_hip.dev_f32(w1, "w1")), _aligned16(_hip.dev_f32(w2, "w2"))
     y = torch.empty_like(x)
     lad = torch.empty(n, dtype=torch.float32, device=x.device)
     _call("fc_sylvester_mm", lib.fc_sylvester_mm, x.device, _hip.ptr(x), _hip.ptr(y), _hip.ptr(lad), _hip.ptr(w1),

@@ -466,13 +466,13 @@ int fc_sylvester(const float* x, float* y, float* logabsdet, const float* q, con
 /* Shared-weight Sylvester flow as two dense products on the matrix cores (planar.py:144-166 with the batch-
  * independent chains folded into W1 = R1 Q^T and W2 = Q R2, both [d, d] row-major):
  *   y = x + W2 tanh(W1 x + bias),  logabsdet[n] = sum_i log(1 + (1 - tanh^2(.)_i) r_diag_prod_i).
- * d % 32 == 0, d <= 128, n % 16 == 0, x / y 16-byte aligned.  Products: three-term scaled f16 splits. */
+ * d % 32 == 0, d <= 128, n % 16 == 0, x / y / w1 / w2 16-byte aligned.  Products: three-term scaled f16 splits. */
 int fc_sylvester_mm(const float* x, float* y, float* logabsdet, const float* w1, const float* w2,
                     const float* bias, const float* r_diag_prod, int64_t n, int32_t d, void* stream);
 
 /* y = W x + bias for a batch-independent dense [d, d] matrix on the matrix cores (same split-f16 products):
  * LULinear / Linear forward with W = L U (lu.py:56-68, linear.py:45-60), a HouseholderSequence folded into its
- * orthogonal matrix (orthogonal.py:63-85).  bias may be NULL.  d % 32 == 0, d <= 128, n % 16 == 0. */
+ * orthogonal matrix (orthogonal.py:63-85).  bias may be NULL.  d % 32 == 0, d <= 128, n % 16 == 0; x / y / w 16-byte aligned. */
 int fc_dense_mm(const float* x, float* y, const float* w, const float* bias, int64_t n, int32_t d, void* stream);
 
 /* ---- weight packing on the device ------------------------------------------------------------------------- */

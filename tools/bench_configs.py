@@ -18,7 +18,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import flowconductor_amd  # noqa: E402,F401
-from flowconductor_amd import distributions, flows, ops, transforms, utils  # noqa: E402
+from flowconductor_amd import _hip, distributions, flows, ops, transforms, utils  # noqa: E402
 from flowconductor_amd.nn import nets  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
