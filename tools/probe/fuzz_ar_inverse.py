@@ -89,9 +89,11 @@ for c in range(cases):
         tl = 1e-3 * max(1.0, float(ref_lad[tc].abs().max()) / 10) + 4 * md(ref_lad[tc], ref_lad64[tc])
     else:
         ty, tl = tol_y, tol_l
-    e = (md(y, ref_y64) / tol_y, md(lad, ref_lad64) / tol_l, md(y[tame], y_host[tame]) / ty,
-         md(lad[tame], lad_host[tame]) / tl, md(z[tame], xd[tame]) / (2 * ty),
-         md((lad + lad_fwd)[tame], torch.zeros_like(lad[tame])) / (2 * tl))
+    # (two float32 paths against each other, and a round trip through the forward map whose slope reaches 1 / 1e-3: four
+    #  times the allowance of one path against float64)
+    e = (md(y, ref_y64) / tol_y, md(lad, ref_lad64) / tol_l, md(y[tame], y_host[tame]) / (4 * ty),
+         md(lad[tame], lad_host[tame]) / (4 * tl), md(z[tame], xd[tame]) / (4 * ty),
+         md((lad + lad_fwd)[tame], torch.zeros_like(lad[tame])) / (4 * tl))
     worst = max(worst, max(e))
     ran += 1
     flag = "" if max(e) <= 1.0 else "   <-- FAIL"
