@@ -40,7 +40,8 @@ __host__ __device__ constexpr int syl_feat(int t, int g, int r) { return 32 * (t
 // F = 32 KS features: NT = 2 KS accumulator tiles per lane group, KS k-steps
 // kDense: only the first product, y = W1 z + b (a dense linear layer with batch-independent weights: LU / Linear
 // forward, a Householder sequence folded into its orthogonal matrix)
-template <int KS, bool kDense>
+// BPW: 16-row blocks a wave carries together (each weight fragment read from LDS serves all of them)
+template <int KS, bool kDense, int BPW>
 __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
   constexpr int F = 32 * KS, NT = 2 * KS;
   constexpr int kFragL = KS * NT * 2;   // fragments of one product: [ks][t][piece]
@@ -128,38 +129,55 @@ __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
     float sc, un;
     pow2_scale(m, sc, un);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 hh, ll;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        _Float16 ph, pl;
-        split2(v[t][r] * sc, ph, pl);
-        bh[t >> 1][4 * (t & 1) + r] = ph;
-        bl[t >> 1][4 * (t & 1) + r] = pl;
+      for (int q = 0; q < 4; ++q) {
+        uint32_t ph, pl;
+        split2_pair(v[2 * ks + (q >> 1)][2 * (q & 1)], v[2 * ks + (q >> 1)][2 * (q & 1) + 1], sc, ph, pl);
+        hh[q] = ph;
+        ll[q] = pl;
       }
+      bh[ks] = __builtin_bit_cast(f16x8, hh);
+      bl[ks] = __builtin_bit_cast(f16x8, ll);
+    }
     return un;
   };
-  // acc = (scaled W_l) (scaled v)^T: three split terms, small ones first; consecutive MFMAs on different tiles
-  auto product = [&](int l, const f16x8 (&bh)[KS], const f16x8 (&bl)[KS], f32x4 (&acc)[NT]) {
+  // acc = (scaled W_l) (scaled v)^T: three split terms, small ones first; consecutive MFMAs on different tiles / blocks
+  constexpr int kChunk = NT % 4 == 0 ? 4 : 2;      // tiles whose high pieces are held at a time (NT = 2 KS)
+  auto product = [&](int l, const f16x8 (&bh)[BPW][KS], const f16x8 (&bl)[BPW][KS], f32x4 (&acc)[BPW][NT]) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < BPW; ++b)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f16x8* wf = wfrag + (size_t)l * kFragL * 64 + lane;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const f16x8 wl = wf[((ks * NT + t) * 2 + 1) * 64];
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[ks], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh[b][ks], acc[b][t], 0, 0, 0);
       }
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      f16x8 wh[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wh[t] = wf[((ks * NT + t) * 2 + 0) * 64];
+      for (int t0 = 0; t0 < NT; t0 += kChunk) {
+        f16x8 wh[kChunk];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl[ks], acc[t], 0, 0, 0);
+        for (int t = 0; t < kChunk; ++t) wh[t] = wf[((ks * NT + t0 + t) * 2 + 0) * 64];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh[ks], acc[t], 0, 0, 0);
+        for (int t = 0; t < kChunk; ++t)
+#pragma unroll
+          for (int b = 0; b < BPW; ++b)
+            acc[b][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl[b][ks], acc[b][t0 + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < kChunk; ++t)
+#pragma unroll
+          for (int b = 0; b < BPW; ++b)
+            acc[b][t0 + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh[b][ks], acc[b][t0 + t], 0, 0, 0);
+      }
     }
   };
 
@@ -173,75 +191,122 @@ __global__ __launch_bounds__(kSylThreads) void sylvester_mm_kernel(SylArgs a) {
       dst[t] = f32x4{v.x, v.y, v.z, v.w};
     }
   };
-  const int64_t blk0 = (int64_t)blockIdx.x * (kSylThreads / 64) + wave;
-  f32x4 znext[NT];
-  if (blk0 < a.blocks16) load_rows(blk0, znext);
-  for (int64_t blk = blk0; blk < a.blocks16; blk += nwaves) {
+  // group grp = blocks BPW grp .. BPW grp + BPW - 1; the last group of an odd count repeats its first block (computed twice,
+  // stored once).  One block per wave: the next block's rows are requested before this block's products and land behind them
+  // (round 4: the wave used to wait for every block's HBM latency with nothing else in flight); two blocks per wave keep two
+  // requests in flight by themselves and have no registers left for a third.
+  constexpr bool kPrefetch = BPW == 1;
+  const int64_t groups = (a.blocks16 + BPW - 1) / BPW;
+  auto blk_of = [&](int64_t grp, int b) {
+    const int64_t blk = grp * BPW + b;
+    return blk < a.blocks16 ? blk : a.blocks16 - 1;
+  };
+  const int64_t grp0 = (int64_t)blockIdx.x * (kSylThreads / 64) + wave;
+  f32x4 znext[kPrefetch ? NT : 1];
+  if constexpr (kPrefetch) {
+    if (grp0 < groups) load_rows(grp0, znext);
+  }
+  for (int64_t grp = grp0; grp < groups; grp += nwaves) {
     asm volatile("" ::: "memory");   // keeps the loop-invariant LDS fragment loads inside the loop
-    f32x4 z[NT];
+    f32x4 z[BPW][NT];
+    if constexpr (kPrefetch) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) z[t] = znext[t];
-    // the next block's rows are requested now and land behind this block's products (round 4: the wave used to wait for
-    // every block's HBM latency with nothing else in flight)
-    if (blk + nwaves < a.blocks16) load_rows(blk + nwaves, znext);
-    f16x8 bh[KS], bl[KS];
-    f32x4 acc[NT];
-    float un = make_operand(z, bh, bl);
+      for (int t = 0; t < NT; ++t) z[0][t] = znext[t];
+      if (grp + nwaves < groups) load_rows(grp + nwaves, znext);
+    } else {
+#pragma unroll
+      for (int b = 0; b < BPW; ++b) load_rows(blk_of(grp, b), z[b]);
+    }
+    f16x8 bh[BPW][KS], bl[BPW][KS];
+    f32x4 acc[BPW][NT];
+    float un[BPW];
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) un[b] = make_operand(z[b], bh[b], bl[b]);
     product(0, bh, bl, acc);
     const f32x4* bsrc = reinterpret_cast<const f32x4*>(bias + g * NT * 4);
     const f32x4* rsrc = reinterpret_cast<const f32x4*>(rdg + g * NT * 4);
-    float c = un * wun[0];
     if constexpr (kDense) {
-      float4* yrow = reinterpret_cast<float4*>(a.y + (blk * 16 + s16) * F);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const f32x4 b = bsrc[t];
-        yrow[8 * (t >> 1) + 2 * g + (t & 1)] =
-            float4{__builtin_fmaf(acc[t][0], c, b[0]), __builtin_fmaf(acc[t][1], c, b[1]),
-                   __builtin_fmaf(acc[t][2], c, b[2]), __builtin_fmaf(acc[t][3], c, b[3])};
+      for (int b = 0; b < BPW; ++b) {
+        if (grp * BPW + b >= a.blocks16) continue;
+        const float c = un[b] * wun[0];
+        float4* yrow = reinterpret_cast<float4*>(a.y + ((grp * BPW + b) * 16 + s16) * F);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const f32x4 bb = bsrc[t];
+          yrow[8 * (t >> 1) + 2 * g + (t & 1)] =
+              float4{__builtin_fmaf(acc[b][t][0], c, bb[0]), __builtin_fmaf(acc[b][t][1], c, bb[1]),
+                     __builtin_fmaf(acc[b][t][2], c, bb[2]), __builtin_fmaf(acc[b][t][3], c, bb[3])};
+        }
       }
       continue;
     }
-    float lsum = 0.f;
+    float lsum[BPW];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const f32x4 b = bsrc[t], rd = rsrc[t];
+    for (int b = 0; b < BPW; ++b) {
+      const float c = un[b] * wun[0];
+      lsum[b] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // (tanh / log on the lean primitives, one exponential / one v_log each: libm's were ~10 000 vector operations per
-        //  row of 128 features, more than half of the kernel)
-        const float act = tanh_lean(__builtin_fmaf(acc[t][r], c, b[r]));     // tanh(R1 Q^T z + b)
-        acc[t][r] = act;
-        const float arg = 1.f + (1.f - act * act) * rd[r];
-        lsum += (arg > 0.f && arg < INFINITY) ? log_lean(arg) : logf(arg);   // planar.py:160-163
+      for (int t = 0; t < NT; ++t) {
+        const f32x4 bb = bsrc[t], rd = rsrc[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // (tanh / log on the lean primitives, one exponential / one v_log each: libm's were ~10 000 vector operations per
+          //  row of 128 features, more than half of the kernel)
+          const float act = tanh_lean(__builtin_fmaf(acc[b][t][r], c, bb[r]));     // tanh(R1 Q^T z + b)
+          acc[b][t][r] = act;
+          const float arg = 1.f + (1.f - act * act) * rd[r];
+          lsum[b] += (arg > 0.f && arg < INFINITY) ? log_lean(arg) : logf(arg);   // planar.py:160-163
+        }
       }
+      un[b] = make_operand(acc[b], bh[b], bl[b]);
     }
-    un = make_operand(acc, bh, bl);
     product(1, bh, bl, acc);
-    c = un * wun[1];
-    float4* yrow = reinterpret_cast<float4*>(a.y + (blk * 16 + s16) * F);
+    if constexpr (BPW > 1) {      // (the rows are read again for the residual instead of living through both products: L2)
+      asm volatile("" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-      yrow[8 * (t >> 1) + 2 * g + (t & 1)] = float4{z[t][0] + acc[t][0] * c, z[t][1] + acc[t][1] * c,
-                                                    z[t][2] + acc[t][2] * c, z[t][3] + acc[t][3] * c};
-    lsum = rows4_allsum(lsum, lane);
-    if (g == 0) a.lad[blk * 16 + s16] = lsum;
+      for (int b = 0; b < BPW; ++b) load_rows(blk_of(grp, b), z[b]);
+    }
+#pragma unroll
+    for (int b = 0; b < BPW; ++b) {
+      if (grp * BPW + b >= a.blocks16) continue;
+      const float c = un[b] * wun[1];
+      float4* yrow = reinterpret_cast<float4*>(a.y + ((grp * BPW + b) * 16 + s16) * F);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        yrow[8 * (t >> 1) + 2 * g + (t & 1)] = float4{z[b][t][0] + acc[b][t][0] * c, z[b][t][1] + acc[b][t][1] * c,
+                                                      z[b][t][2] + acc[b][t][2] * c, z[b][t][3] + acc[b][t][3] * c};
+      const float l = rows4_allsum(lsum[b], lane);
+      if (g == 0) a.lad[(grp * BPW + b) * 16 + s16] = l;
+    }
   }
 }
 
-template <int KS, bool kDense>
-static hipError_t launch_syl(const SylArgs& a, int cus, hipStream_t s) {
+template <int KS, bool kDense, int BPW>
+static hipError_t launch_syl_bpw(const SylArgs& a, int cus, hipStream_t s) {
   constexpr int NT = 2 * KS;
   const size_t lds = (size_t)2 * KS * NT * 2 * 64 * 16 + (2 * 4 * NT * 4 + 16) * 4;
   static PerDeviceOnce attr;
-  const hipError_t ea = ensure_max_dynamic_lds(attr, reinterpret_cast<const void*>(&sylvester_mm_kernel<KS, kDense>),
+  const hipError_t ea = ensure_max_dynamic_lds(attr, reinterpret_cast<const void*>(&sylvester_mm_kernel<KS, kDense, BPW>),
                                                160 * 1024);
   if (ea != hipSuccess) return ea;
   int64_t grid = cus;
-  const int64_t need = (a.blocks16 + 7) / 8;
+  const int64_t need = ((a.blocks16 + BPW - 1) / BPW + 7) / 8;
   if (grid > need) grid = need;
-  hipLaunchKernelGGL((sylvester_mm_kernel<KS, kDense>), dim3((unsigned)grid), dim3(kSylThreads), lds, s, a);
+  hipLaunchKernelGGL((sylvester_mm_kernel<KS, kDense, BPW>), dim3((unsigned)grid), dim3(kSylThreads), lds, s, a);
   return hipGetLastError();
+}
+
+#ifndef FC_SYL_BPW
+#define FC_SYL_BPW 1
+#endif
+template <int KS, bool kDense>
+static hipError_t launch_syl(const SylArgs& a, int cus, hipStream_t s) {
+  // two blocks per wave once every wave of the launch has a pair to carry
+  if constexpr (FC_SYL_BPW == 2 && KS == 4 && !kDense) {
+    if (a.blocks16 >= 2 * 8 * (int64_t)cus) return launch_syl_bpw<KS, kDense, 2>(a, cus, s);
+  }
+  return launch_syl_bpw<KS, kDense, 1>(a, cus, s);
 }
 
 }  // namespace fc

@@ -1,12 +1,15 @@
 """Launch time of fc_sylvester_mm (shared-parameter Sylvester, D = 128) against the batch: the intercept is the per-workgroup
-prologue (scaling, splitting and laying out both matrices).  python tools/probe/bench_sylvester_mm.py"""
+prologue (scaling, splitting and laying out both matrices).  python tools/probe/bench_sylvester_mm.py [--lib probe.so]"""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from flowconductor_amd import ops  # noqa: E402
+from flowconductor_amd import _hip, ops  # noqa: E402
+
+if "--lib" in sys.argv:          # a probe build (e.g. -DFC_SYL_BPW=2)
+    _hip.use_library(sys.argv[sys.argv.index("--lib") + 1])
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -27,5 +30,7 @@ for log2n in (4, 12, 15, 18, 20):
             ops.sylvester_mm(x, w1, w2, bias, rdiag)
         torch.cuda.synchronize()
         best = min(best, min(t.durations_ms()))
+    y_chk, lad_chk = ops.sylvester_mm(x, w1, w2, bias, rdiag)
+    chk = (float(y_chk.double().sum()), float(lad_chk.double().sum()))
     alg = n * (2 * d + 1) * 4
-    print("N=2^%d: %.4f ms  (%.0f GB/s algorithmic)" % (log2n, best, alg / best / 1e6))
+    print("N=2^%d: %.4f ms  (%.0f GB/s algorithmic)  checksums %.6f %.6f" % (log2n, best, alg / best / 1e6, chk[0], chk[1]))
