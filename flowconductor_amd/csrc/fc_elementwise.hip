@@ -34,8 +34,20 @@ __device__ __forceinline__ void ew_eval(const EwArgs& a, int64_t row, int64_t j,
       else { if (x <= 0.f) err |= 1u; y = logf(x); lad = -y; }
       break;
     case FC_EW_TANH:
-      if (!a.inverse) { y = tanhf(x); lad = logf(1.f - y * y); }
-      else {
+      if (!a.inverse) {
+        // nonlinearities.py:40-43 from ONE exponential e = exp(-2|x|) (round 4: libm's tanhf + logf made this a vector-bound
+        // kernel at 0.23 of the HBM peak):  tanh = (1 - e) / (1 + e),  log(1 - tanh^2) = log(4 e / (1 + e)^2)
+        // = 2 (ln 2 - |x| - log1p(e)) -- no cancellation near saturation, where log(1 - y^2) on a rounded y is off by
+        // 1e-4 at |x| = 4 and by 0.3 at |x| = 8 in ANY float32 evaluation, the reference's included (tools/probe/
+        // tanh_accuracy.py: reference 3.0e-1, this 2.2e-5 against float64 over 4096 x 64 inputs ~ 2 N(0, 1)).  Where a float32
+        // tanh rounds to +-1 the reference's log(0) = -inf is kept.
+        const float ax = fabsf(x);
+        const float e = exp_lean(-2.f * ax);
+        const float t = div_lean(1.f - e, 1.f + e);
+        y = x >= 0.f ? t : -t;
+        // (9.0109: where 1 - tanh(x) drops below half an ulp of 1, i.e. where a correctly rounded float32 tanh returns 1)
+        lad = ax < 9.010913f ? 2.f * ((0.6931471805599453f - ax) - log1p_lean_pos(e)) : -INFINITY;
+      } else {
         if (x <= -1.f || x >= 1.f) err |= 1u;
         y = 0.5f * logf((1.f + x) / (1.f - x));
         lad = -logf(1.f - x * x);
@@ -142,6 +154,38 @@ __global__ __launch_bounds__(256) void elementwise_kernel(EwArgs a) {
   if (err && a.err) atomicOr(a.err, err);
 }
 
+// Rows whose length is a multiple of 4 (16-byte aligned buffers): a lane moves float4 pieces -- four times the bytes in
+// flight per lane and a quarter of the butterfly steps of the one-element-per-lane form above.
+template <int T>
+__global__ __launch_bounds__(256) void elementwise_kernel_v4(EwArgs a) {
+  const int rows_per_block = 256 / T;
+  const int lane = threadIdx.x % T;
+  const int64_t row = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / T;
+  float acc = 0.f;
+  uint32_t err = 0;
+  if (row < a.n) {
+    const float4* xr = reinterpret_cast<const float4*>(a.x + row * a.m);
+    float4* yr = reinterpret_cast<float4*>(a.y + row * a.m);
+    float4* lr = a.lad_elem ? reinterpret_cast<float4*>(a.lad_elem + row * a.m) : nullptr;
+    const int64_t m4 = a.m >> 2;
+    for (int64_t j4 = lane; j4 < m4; j4 += T) {
+      const float4 xv = xr[j4];
+      float4 yv, lv;
+      ew_eval(a, row, 4 * j4 + 0, xv.x, yv.x, lv.x, err);
+      ew_eval(a, row, 4 * j4 + 1, xv.y, yv.y, lv.y, err);
+      ew_eval(a, row, 4 * j4 + 2, xv.z, yv.z, lv.z, err);
+      ew_eval(a, row, 4 * j4 + 3, xv.w, yv.w, lv.w, err);
+      yr[j4] = yv;
+      if (lr) lr[j4] = lv;
+      acc += (lv.x + lv.y) + (lv.z + lv.w);
+    }
+  }
+#pragma unroll
+  for (int o = T >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, T);
+  if (row < a.n && lane == 0 && a.lad_row) a.lad_row[row] = acc;
+  if (err && a.err) atomicOr(a.err, err);
+}
+
 }  // namespace fc
 
 extern "C" int fc_elementwise(const float* x, float* y, float* logabsdet_row, float* logabsdet_elem,
@@ -154,12 +198,30 @@ extern "C" int fc_elementwise(const float* x, float* y, float* logabsdet_row, fl
                          kind == FC_EW_EXTENDED_SOFTPLUS || kind == FC_EW_GLU;
   if (needs_aux && !aux) return hipErrorInvalidValue;
   fc::EwArgs a{x, y, logabsdet_row, logabsdet_elem, aux, err_flag, n, m, kind, inverse, p0, p1, p2, p3};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (m % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)logabsdet_elem) & 15u) == 0) {
+    int t4 = 1;
+    while (t4 < m / 4 && t4 < 64) t4 <<= 1;
+    const int rows_per_block4 = 256 / t4;
+    const int64_t grid4 = (n + rows_per_block4 - 1) / rows_per_block4;
+    if (grid4 > 0x7fffffffLL) return hipErrorInvalidConfiguration;
+    dim3 g4((unsigned)grid4), b4(256);
+    switch (t4) {
+      case 1: hipLaunchKernelGGL(fc::elementwise_kernel_v4<1>, g4, b4, 0, s, a); break;
+      case 2: hipLaunchKernelGGL(fc::elementwise_kernel_v4<2>, g4, b4, 0, s, a); break;
+      case 4: hipLaunchKernelGGL(fc::elementwise_kernel_v4<4>, g4, b4, 0, s, a); break;
+      case 8: hipLaunchKernelGGL(fc::elementwise_kernel_v4<8>, g4, b4, 0, s, a); break;
+      case 16: hipLaunchKernelGGL(fc::elementwise_kernel_v4<16>, g4, b4, 0, s, a); break;
+      case 32: hipLaunchKernelGGL(fc::elementwise_kernel_v4<32>, g4, b4, 0, s, a); break;
+      default: hipLaunchKernelGGL(fc::elementwise_kernel_v4<64>, g4, b4, 0, s, a); break;
+    }
+    return hipGetLastError();
+  }
   int t = 1;
   while (t < m && t < 64) t <<= 1;
   const int rows_per_block = 256 / t;
   const int64_t grid = (n + rows_per_block - 1) / rows_per_block;
   if (grid > 0x7fffffffLL) return hipErrorInvalidConfiguration;
-  hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 g((unsigned)grid), b(256);
   switch (t) {
     case 1: hipLaunchKernelGGL(fc::elementwise_kernel<1>, g, b, 0, s, a); break;
