@@ -234,6 +234,56 @@ __global__ __launch_bounds__(256) void planar_kernel(const float* __restrict__ x
   }
 }
 
+// The same map for rows of 4 L' <= 4 L floats (16-byte aligned): L lanes carry a row as float4 pieces, a wave 64 / L rows
+// (D = 64: four rows per wave, two 4-step butterflies instead of two 6-step ones per ROW, 16-byte requests), the next group's
+// rows requested before this group's arithmetic (round 4: planar_kernel<1> ran at 0.39 of the HBM peak, 68 % of its wave
+// cycles waiting on memory with one 256-byte request in flight per wave).
+template <int L>
+__global__ __launch_bounds__(256) void planar_rows4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           float* __restrict__ lad, const float* __restrict__ w,
+                                                           const float* __restrict__ u_hat, const float* __restrict__ b_ptr,
+                                                           int64_t n, int d, int per_sample) {
+  constexpr int kRows = 64 / L;
+  const int lane = threadIdx.x & 63, sub = lane % L, rw = lane / L;
+  const int d4 = d >> 2;
+  const bool live = sub < d4;
+  const float4 zero4 = float4{0.f, 0.f, 0.f, 0.f};
+  float b = b_ptr[0];
+  float4 wv = (live && !per_sample) ? reinterpret_cast<const float4*>(w)[sub] : zero4;
+  float4 uv = (live && !per_sample) ? reinterpret_cast<const float4*>(u_hat)[sub] : zero4;
+  const int64_t groups = (n + kRows - 1) / kRows;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock;
+  int64_t grp = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+  auto fetch = [&](int64_t g, const float* src) {
+    const int64_t row = g * kRows + rw;
+    return (live && row < n) ? reinterpret_cast<const float4*>(src + row * d)[sub] : zero4;
+  };
+  float4 rnext = grp < groups ? fetch(grp, x) : zero4;
+  for (; grp < groups; grp += stride) {
+    const int64_t row = grp * kRows + rw;
+    const float4 r = rnext;
+    if (grp + stride < groups) rnext = fetch(grp + stride, x);
+    if (per_sample) {
+      wv = fetch(grp, w);
+      uv = fetch(grp, u_hat);
+      b = b_ptr[row < n ? row : n - 1];
+    }
+    float a = (r.x * wv.x + r.y * wv.y) + (r.z * wv.z + r.w * wv.w);
+#pragma unroll
+    for (int o = L >> 1; o > 0; o >>= 1) a += __shfl_xor(a, o, L);
+    a += b;                                      // mm(inputs, w.T) + b
+    const float t = tanhf(a);
+    const float dt = 1.f - t * t;
+    // abs_det = |1 + sum_j u_j * ((1 - tanh^2 a) * w_j)|  (planar.py:43-48)
+    float s = (uv.x * (dt * wv.x) + uv.y * (dt * wv.y)) + (uv.z * (dt * wv.z) + uv.w * (dt * wv.w));
+#pragma unroll
+    for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, L);
+    if (live && row < n)
+      reinterpret_cast<float4*>(y + row * d)[sub] = float4{r.x + uv.x * t, r.y + uv.y * t, r.z + uv.z * t, r.w + uv.w * t};
+    if (sub == 0 && row < n && lad) lad[row] = logf(1e-7f + fabsf(1.f + s));
+  }
+}
+
 // mode 0: y = W x + bias (Wt given)               -- linear.py:45-52 cached path, lu.py:56-68
 // mode 1: y = L (U x) + bias (Ut, Lt given)        -- lu.py:56-68 (two F.linear)
 // mode 2: y = U^-1 L^-1 (x - bias), L unit-lower   -- lu.py:70-91 (two solve_triangular)
@@ -597,6 +647,22 @@ extern "C" int fc_planar(const float* x, float* y, float* logabsdet, const float
   if (n == 0) return hipSuccess;
   if (!x || !y || !w || !u_hat || !b) return hipErrorInvalidValue;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d % 4 == 0 && d <= 256 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)w | (uintptr_t)u_hat) & 15u) == 0) {
+    int lanes = 1;
+    while (lanes < d / 4) lanes <<= 1;
+    const int rows = 64 / lanes;
+    const unsigned grid = fc::row_grid((n + rows - 1) / rows);
+#define FC_PLANAR4(LV)                                                                                          \
+  case LV:                                                                                                      \
+    hipLaunchKernelGGL(fc::planar_rows4_kernel<LV>, dim3(grid), dim3(256), 0, s, x, y, logabsdet, w, u_hat, b, n, d, \
+                       per_sample);                                                                             \
+    break;
+    switch (lanes) {
+      FC_PLANAR4(1) FC_PLANAR4(2) FC_PLANAR4(4) FC_PLANAR4(8) FC_PLANAR4(16) FC_PLANAR4(32) FC_PLANAR4(64)
+    }
+#undef FC_PLANAR4
+    return hipGetLastError();
+  }
   FC_ROW_DISPATCH(d, hipLaunchKernelGGL(fc::planar_kernel<E>, dim3(fc::row_grid(n)), dim3(256), 0, s, x, y,
                                         logabsdet, w, u_hat, b, n, d, per_sample));
   return hipGetLastError();
