@@ -122,3 +122,51 @@ def test_softplus_on_a_4d_batch_against_the_reference_fixture(device):
     assert maxdiff(lad, torch.from_numpy(fx["lad"]).sum(dim=(1, 2))) <= 2e-5
     assert maxdiff(xi, torch.from_numpy(fx["xinv"])) <= 2e-5
     assert maxdiff(ladi, torch.from_numpy(fx["ladinv"]).sum(dim=(1, 2))) <= 2e-4
+
+
+# ---- vector paths added late in round 4: the same answers as the one-element-per-lane forms ------------------------------
+@pytest.mark.parametrize("d", [4, 12, 64, 100, 256, 30])
+@pytest.mark.parametrize("per_sample", [False, True])
+def test_planar_sub_wave_rows_match_float64(d, per_sample, device):
+    """fc_planar on rows of 4k floats runs on sub-wave lane groups with float4 pieces (d = 30: the row-per-wave kernel);
+    both against planar.py:30-49 in float64, shared and per-sample parameters, batches that do not fill the last wave."""
+    from flowconductor_amd import ops
+
+    torch.manual_seed(d)
+    n = 1000 + 3
+    x = torch.randn(n, d)
+    rows = n if per_sample else 1
+    w, u, b = torch.randn(rows, d) * 0.3, torch.randn(rows, d) * 0.3, torch.randn(rows) * 0.2
+    y, lad = ops.planar(x.to(device), w.to(device), u.to(device), b.to(device), per_sample=per_sample)
+    x64, w64, u64, b64 = x.double(), w.double(), u.double(), b.double()
+    a = (x64 * w64).sum(-1) + b64
+    t = torch.tanh(a)
+    ref_y = x64 + u64 * t.unsqueeze(-1)
+    ref_lad = torch.log(1e-7 + (1 + (1 - t ** 2) * (u64 * w64).sum(-1)).abs())
+    a32 = (x * w).sum(-1) + b                     # the float32 sequence of the reference: the noise floor where |1 + s| is small
+    t32 = torch.tanh(a32)
+    lad32 = torch.log(1e-7 + (1 + (1 - t32 ** 2) * (u * w).sum(-1)).abs())
+    assert maxdiff(y.cpu().double(), ref_y) <= 2e-6 * max(1.0, float(ref_y.abs().max()))
+    assert maxdiff(lad.cpu().double(), ref_lad) <= 2e-5 + 4 * maxdiff(lad32.double(), ref_lad)
+
+
+@pytest.mark.parametrize("kind", ["exp", "tanh", "sigmoid", "leaky", "softplus", "cauchy", "logtanh"])
+def test_elementwise_vector_rows_match_scalar_rows(kind, device):
+    """fc_elementwise moves rows of 4k elements as 16-byte pieces; a view that starts 4 bytes into its buffer takes the
+    one-element-per-lane kernel: same outputs bit for bit, row sums equal to the order of the additions."""
+    from flowconductor_amd import transforms as T
+
+    torch.manual_seed(3)
+    t = {"exp": T.Exp, "tanh": T.Tanh, "sigmoid": T.Sigmoid, "leaky": T.LeakyReLU, "softplus": T.Softplus,
+         "cauchy": T.CauchyCDF, "logtanh": T.LogTanh}[kind]().to(device)
+    n, m = 777, 64
+    flat = torch.randn(n * m + 1, device=device) * 1.5
+    aligned = flat[:n * m].reshape(n, m).clone()
+    shifted = flat[1:].reshape(n, m)
+    shifted.copy_(aligned)
+    assert aligned.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 == 4
+    with torch.no_grad():
+        y_v, lad_v = t(aligned)
+        y_s, lad_s = t(shifted)
+    assert torch.equal(y_v, y_s)
+    assert maxdiff(lad_v, lad_s) <= 1e-5 * max(1.0, float(lad_s.abs().max()))
