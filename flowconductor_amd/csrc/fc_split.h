@@ -26,7 +26,10 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // small columns of a row must see them at full precision beside a large column it does not read (rounds 1-3 lifted the
 // maximum to [2^10, 2^11): full precision only down to 2^12 below it -- tools/probe/fuzz_ar_inverse.py found rows of an
 // affine autoregressive inverse, |y| up to 8e3 beside O(1) columns, 4e-3 off).
-constexpr uint32_t kSplitTopExp = 14;
+#ifndef FC_SPLIT_TOP_EXP
+#define FC_SPLIT_TOP_EXP 14      // (probe builds: 10 = the scale of rounds 1-3)
+#endif
+constexpr uint32_t kSplitTopExp = FC_SPLIT_TOP_EXP;
 __device__ __forceinline__ void pow2_scale(float m, float& scale, float& unscale) {
   const uint32_t e = (__float_as_uint(m) >> 23) & 255u;      // biased exponent, floor(log2 m) = e - 127
   const bool ok = e > kSplitTopExp && e < 255u;

@@ -170,3 +170,31 @@ def test_elementwise_vector_rows_match_scalar_rows(kind, device):
         y_s, lad_s = t(shifted)
     assert torch.equal(y_v, y_s)
     assert maxdiff(lad_v, lad_s) <= 1e-5 * max(1.0, float(lad_s.abs().max()))
+
+
+def test_masked_conditioner_keeps_small_columns_beside_a_large_one(device):
+    """fc_split.h lifts a row's maximum to [2^14, 2^15): the two f16 pieces keep 22 bits of entries down to 2^-16 of the row
+    maximum and lose one bit per further factor of two.  A MADE unit that reads only the small columns must see them beside a
+    column 2^20 times larger that it does not read (the reference's masked float32 GEMM multiplies that column by an exact
+    zero): 18 bits here; with the maximum at [2^10, 2^11) (rounds 1-3) 14 bits -- 6e-5 relative, outside this tolerance."""
+    import copy
+
+    from flowconductor_amd import transforms as T
+
+    torch.manual_seed(11)
+    d = 12
+    t = T.MaskedAffineAutoregressiveTransform(d, 64, num_blocks=2).eval()
+    with torch.no_grad():
+        for p in t.parameters():
+            p.mul_(1.5)
+    x = torch.randn(2048, d)
+    x[:, d - 1] *= 2.0 ** 20          # the LAST column: no parameter of dims 0 .. d-2 may depend on it
+    with torch.no_grad():
+        ref_y, ref_lad = O.transform_apply(copy.deepcopy(t).double(), x.double())
+        f32_y, f32_lad = O.transform_apply(t, x)
+        y, lad = t.to(device)(x.to(device))
+    head = slice(0, d - 1)
+    tol = 2e-5 * max(1.0, float(ref_y[:, head].abs().max())) + 4 * maxdiff(f32_y[:, head].double(), ref_y[:, head])
+    assert maxdiff(y[:, head].cpu().double(), ref_y[:, head]) <= tol
+    # (the last dim's own scale enters logabsdet at O(1): still float32-class)
+    assert maxdiff(lad.cpu().double(), ref_lad) <= 2e-4 * max(1.0, float(ref_lad.abs().max()) / 10) + 4 * maxdiff(f32_lad.double(), ref_lad)
