@@ -319,6 +319,9 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // Pick samples-per-tile so that a tile is ~one element per thread of a 256-thread block and
 // fits comfortably in LDS (several tiles resident per CU: 160 KiB per CU on gfx950).
+#ifndef FC_TILE_TARGET_KB
+#define FC_TILE_TARGET_KB 24      // (probe builds sweep it)
+#endif
 inline bool plan_tile(const TileArgs& a, TilePlan* plan) {
   const size_t kLdsSoft = 40 * 1024, kLdsHard = 150 * 1024;
   int S = kMaxBlock / (a.d_t > 0 ? a.d_t : 1);
@@ -332,7 +335,7 @@ inline bool plan_tile(const TileArgs& a, TilePlan* plan) {
   // cheap per-sample rows (affine, small D): grow the tile towards ~24 KiB so that the per-tile
   // barriers and the load latency are amortised over more bytes (threads then loop over elements)
   if (!a.shared_params) {
-    const size_t kTarget = 24 * 1024;
+    const size_t kTarget = FC_TILE_TARGET_KB * 1024;
     while (S >= 4 && bytes(S + 4) <= kTarget && (int64_t)(S + 4) * a.D <= 2 * 4 * kMaxBlock &&
            (int64_t)(S + 4) * a.rowlen <= 8 * 4 * kMaxBlock && (int64_t)(S + 4) * 64 <= a.N)
       S += 4;
