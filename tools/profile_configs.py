@@ -30,7 +30,7 @@ KERNELS = {
     "kernels": {"linear_spline_coupling": "fc::LinearSplineOp", "quadratic_spline_coupling": "fc::QuadraticSplineOp",
                 "cubic_spline_coupling": "fc::CubicSplineOp", "sum_of_sigmoids_forward": "fc::SoSOp", "sum_of_sigmoids_inverse": "fc::SoSOp",
                 "lu_linear_forward": "fc::sylvester_mm_kernel<2", "lu_linear_inverse": "fc::sylvester_mm_kernel<2",
-                "householder_shared": "fc::sylvester_mm_kernel<4", "planar": "fc::planar_kernel", "permutation": "fc::permute_rows_kernel",
+                "householder_shared": "fc::sylvester_mm_kernel<4", "planar": "fc::planar_", "permutation": "fc::permute_rows_kernel",
                 "elementwise_tanh": "fc::elementwise_kernel", "standard_normal_log_prob": "std_normal_kernel",
                 "rq_spline_backward": "rq_backward_wave_kernel"},
 }
