@@ -4,7 +4,8 @@
 #   stage a: kernel trace + FETCH_SIZE / WRITE_SIZE passes of bench.py, traces of the configs and of the training step, summaries
 #   stage b: SQ counters of the two hot kernels, then the un-profiled line with --strict-profiles (every profiles/<tag>_* file
 #            must carry the sha256 of the library that line reports)
-#   (tools/profile_configs.py <tag>: the PMC traffic of every `configs` entry -- a third call, its own ~8 minutes)
+#   (tools/profile_configs.py <tag> [--sq]: the PMC traffic / SQ counters of every `configs` entry -- calls of their own; run them
+#    BEFORE stage b, whose line then carries `configs.*.roofline.traffic` of the same library)
 # Writes raw output under gpurun_out/prof_<tag>/ and the judged summaries under profiles/.
 set -u
 TAG=${1:-r01}
